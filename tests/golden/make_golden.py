@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container, where the reference checkout is mounted
+read-only at /root/reference (it never travels to the GPU box).  It imports
+the reference's own ``scoary.methods`` and records *data only*: inputs the
+reference's tests ship (exampledata) and the outputs the reference computes
+for them.  No reference source text is stored.
+
+    python tests/golden/make_golden.py            # rewrites every fixture
+
+Fixtures written (all consumed by tests/ and by oracle pinning):
+
+  exampledata/*.gz                 the reference's example inputs (test data)
+  setup_results_exampledata.npz    Setup_results() rows for both traits
+  setup_results_collapse.npz       same with collapse=True (Tetracycline)
+  setup_results_restrict.npz       same under -r Restrict_to.csv
+  setup_results_vcf.npz            non-Roary (vcf2scoary output) GPA path
+  csv_no_pairwise/*.csv.gz         `--no_pairwise -p 1.0 --no-time` CSVs
+  csv_no_pairwise_default/*.csv.gz `--no_pairwise` (default -p 0.05) CSVs
+  fisher_grid.npz                  scipy.stats.fisher_exact (SciPy 1.15.3,
+                                   the arithmetic behind methods.py:854) on a
+                                   table grid incl. ties / zero cells / zero
+                                   margins
+  permute_tree_seeded.json         seeded reference Permute() (tree statistic;
+                                   SURVEY D1 -- pinned for the "next" row)
+"""
+import contextlib
+import gzip
+import hashlib
+import io
+import json
+import os
+import random
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+EX = os.path.join(REF, "scoary", "exampledata")
+
+sys.path.insert(0, REF)
+import scipy.stats as ss  # noqa: E402
+
+# scipy.stats.binom_test was removed in SciPy >= 1.12; the reference still
+# calls it (methods.py:1267).  Patched here, outside the reference tree.
+if not hasattr(ss, "binom_test"):
+    ss.binom_test = lambda x, n, p: ss.binomtest(int(x), int(n), p).pvalue
+
+import scoary.methods as rm  # noqa: E402
+
+
+def gz_copy(src, dst):
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    with open(src, "rb") as f, open(dst, "wb") as raw:
+        # mtime=0 => byte-stable output
+        with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, filename="") as g:
+            shutil.copyfileobj(f, g)
+
+
+def gz_write(text, dst):
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    with open(dst, "wb") as raw:
+        with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, filename="") as g:
+            g.write(text.encode())
+
+
+@contextlib.contextmanager
+def quiet():
+    old = sys.stdout
+    sys.stdout = io.StringIO()
+    try:
+        yield
+    finally:
+        sys.stdout = old
+
+
+def load_inputs(gpa, traits, startcol=14, allowed=None, delimiter=","):
+    with open(gpa, "r") as g:
+        gd = rm.Csv_to_dic_Roary(g, delimiter, [], startcol=startcol,
+                                 allowed_isolates=allowed)
+    with open(traits, "r") as t:
+        td, prune = rm.Csv_to_dic(t, delimiter, allowed, gd["Strains"])
+    return gd, td, prune
+
+
+def dump_setup_results(path, genedic, traitsdic, collapse):
+    with quiet():
+        res = rm.Setup_results(genedic, traitsdic, collapse)
+    out = {}
+    traits = list(res["Results"].keys())
+    out["traits"] = np.array(json.dumps(traits))
+    out["all_genes"] = np.array(json.dumps(list(genedic.keys())))
+    for ti, trait in enumerate(traits):
+        rows = res["Results"][trait]
+        genes = list(rows.keys())            # insertion order == file order
+        out["t%d_genes" % ti] = np.array(json.dumps(genes))
+        out["t%d_nugn" % ti] = np.array(json.dumps([rows[g]["NUGN"] for g in genes]))
+        out["t%d_annotation" % ti] = np.array(json.dumps([rows[g]["Annotation"] for g in genes]))
+        out["t%d_counts" % ti] = np.array(
+            [[rows[g]["tpgp"], rows[g]["tpgn"], rows[g]["tngp"], rows[g]["tngn"]]
+             for g in genes], dtype=np.int32)
+        for k in ("sens", "spes", "OR", "p_v", "B_p", "BH_p"):
+            out["t%d_%s" % (ti, k)] = np.array([float(rows[g][k]) for g in genes],
+                                               dtype=np.float64)
+        # the per-isolate AB/Ab/aB/ab map of a few genes (Gene_trait_combinations)
+        gtc = res["Gene_trait_combinations"][trait]
+        pick = genes[:3] + genes[-2:]
+        out["t%d_gtc" % ti] = np.array(json.dumps({g: gtc[g] for g in pick}))
+    np.savez_compressed(path, **out)
+    return res
+
+
+def run_cli(argv, outdir):
+    """Run the reference CLI in-process; returns {filename: text}."""
+    old_argv = sys.argv
+    sys.argv = ["scoary.py"] + argv + ["-o", outdir, "--no-time"]
+    try:
+        with quiet():
+            try:
+                rm.main()
+            except SystemExit as e:
+                if e.code not in (0, None):
+                    raise
+    finally:
+        sys.argv = old_argv
+    out = {}
+    for fn in sorted(os.listdir(outdir)):
+        if fn.endswith(".results.csv"):
+            with open(os.path.join(outdir, fn)) as f:
+                out[fn] = f.read()
+    return out
+
+
+def fisher_grid(path):
+    rng = np.random.default_rng(20260926)
+    tabs = []
+    # every table with total N in {10, 37}
+    for N in (10, 37):
+        for a in range(N + 1):
+            for b in range(N + 1 - a):
+                for c in range(N + 1 - a - b):
+                    d = N - a - b - c
+                    if N == 37 and (a + b + c) % 3:   # thin N=37 to ~1/3
+                        continue
+                    tabs.append((a, b, c, d))
+    # random margins at the survey's sizes (near-null and associated)
+    for N in (100, 500, 2000, 5000, 10000):
+        for _ in range(1000):
+            n1 = int(rng.integers(1, N))           # trait positives
+            n = int(rng.integers(1, N))            # gene margin
+            lo, hi = max(0, n - (N - n1)), min(n, n1)
+            if rng.random() < 0.6:                 # near the null expectation
+                mu = n * n1 / N
+                sd = max(1.0, np.sqrt(mu * (1 - n1 / N) * (1 - n / N)))
+                a = int(np.clip(round(rng.normal(mu, 2.5 * sd)), lo, hi))
+            else:
+                a = int(rng.integers(lo, hi + 1))
+            tabs.append((a, n1 - a, n - a, N - n1 - n + a))
+    # exact ties: symmetric margins (n1 == N/2 makes pmf(x) == pmf(n - x))
+    for N in (20, 100, 500, 2000, 5000, 10000):
+        for _ in range(300):
+            n1 = N // 2
+            n = int(rng.integers(2, N - 1))
+            lo, hi = max(0, n - (N - n1)), min(n, n1)
+            a = int(rng.integers(lo, hi + 1))
+            tabs.append((a, n1 - a, n - a, N - n1 - n + a))
+    # zero cells (inf / 0 odds ratios) and zero margins (nan, 1.0)
+    for a, b, c, d in [(5, 0, 0, 7), (0, 5, 7, 0), (3, 0, 4, 9), (3, 4, 0, 9),
+                       (0, 4, 5, 9), (7, 4, 5, 0), (0, 0, 4, 5), (4, 5, 0, 0),
+                       (0, 4, 0, 5), (4, 0, 5, 0), (1, 0, 0, 0), (0, 0, 0, 0),
+                       (29, 8, 3, 60), (1, 1, 1, 1), (1000, 0, 0, 1000),
+                       (5000, 0, 0, 5000), (2500, 2500, 2500, 2500)]:
+        tabs.append((a, b, c, d))
+    tabs = np.array(tabs, dtype=np.int64)
+    p = np.empty(len(tabs))
+    orr = np.empty(len(tabs))
+    for i, (a, b, c, d) in enumerate(tabs):
+        r = ss.fisher_exact([[a, b], [c, d]])
+        orr[i], p[i] = r[0], r[1]
+    np.savez_compressed(path, tables=tabs, p=p, odds=orr,
+                        scipy_version=np.array(__import__("scipy").__version__))
+    return len(tabs)
+
+
+def main():
+    os.makedirs(HERE, exist_ok=True)
+    manifest = {}
+
+    # -- inputs the reference's own tests ship --------------------------------
+    for fn in ("Gene_presence_absence.csv", "Tetracycline_resistance.csv",
+               "Restrict_to.csv", "ExampleVCFTrait.csv", "Example.vcf",
+               "ExampleTree.nwk"):
+        gz_copy(os.path.join(EX, fn), os.path.join(HERE, "exampledata", fn + ".gz"))
+
+    gpa = os.path.join(EX, "Gene_presence_absence.csv")
+    tr = os.path.join(EX, "Tetracycline_resistance.csv")
+
+    # -- Setup_results on exampledata -----------------------------------------
+    gd, td, prune = load_inputs(gpa, tr)
+    res = dump_setup_results(os.path.join(HERE, "setup_results_exampledata.npz"),
+                             gd["Roarydic"], td, False)
+    top = res["Results"]["Tetracycline_resistance"]["TetRCG"]
+    manifest["TetRCG"] = {k: (float(v) if k not in ("NUGN", "Annotation") else v)
+                          for k, v in top.items()}
+    manifest["prune"] = {k: [x for x in v if x is not None] for k, v in prune.items()}
+    manifest["strains"] = gd["Strains"]
+
+    # -- collapse -------------------------------------------------------------
+    gd2, td2, _ = load_inputs(gpa, tr)
+    dump_setup_results(os.path.join(HERE, "setup_results_collapse.npz"),
+                       gd2["Roarydic"], td2, True)
+
+    # -- restrict_to ----------------------------------------------------------
+    with open(os.path.join(EX, "Restrict_to.csv")) as f:
+        allowed = {iso: "all" for line in f for iso in line.rstrip().split(",")}
+    gd3, td3, _ = load_inputs(gpa, tr, allowed=allowed)
+    dump_setup_results(os.path.join(HERE, "setup_results_restrict.npz"),
+                       gd3["Roarydic"], td3, False)
+    manifest["restrict_strains"] = gd3["Strains"]
+
+    # -- vcf2scoary output -> non-Roary GPA path -----------------------------
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        import scoary.vcf2scoary as v2s
+        old = sys.argv
+        sys.argv = ["vcf2scoary", "--force", os.path.join(EX, "Example.vcf")]
+        with quiet():
+            try:
+                v2s.main()
+            except SystemExit:
+                pass
+        sys.argv = old
+        mpa = os.path.join(tmp, "mutations_presence_absence.csv")
+        gz_copy(mpa, os.path.join(HERE, "exampledata", "mutations_presence_absence.csv.gz"))
+        with open(mpa) as f:
+            header = f.readline().rstrip("\n").split(",")
+        startcol = header.index("DUMMY") + 1 if "DUMMY" in header else 9
+        manifest["vcf_startcol_1based"] = startcol + 1
+        gd4, td4, _ = load_inputs(mpa, os.path.join(EX, "ExampleVCFTrait.csv"),
+                                  startcol=startcol)
+        dump_setup_results(os.path.join(HERE, "setup_results_vcf.npz"),
+                           gd4["Roarydic"], td4, False)
+        manifest["vcf_firstcolnames"] = gd4["Firstcolnames"]
+        manifest["vcf_strains"] = gd4["Strains"]
+    finally:
+        os.chdir(cwd)
+
+    # -- CLI CSVs (the byte-level output contract, StoreTraitResult) ----------
+    for sub, extra in (("csv_no_pairwise", ["-p", "1.0"]),
+                       ("csv_no_pairwise_default", []),
+                       ("csv_no_pairwise_collapse_bh",
+                        ["--collapse", "-c", "I", "BH", "-p", "0.05", "0.01", "-m", "50"])):
+        od = tempfile.mkdtemp()
+        files = run_cli(["-g", gpa, "-t", tr, "--no_pairwise"] + extra, od)
+        for fn, text in files.items():
+            gz_write(text, os.path.join(HERE, sub, fn + ".gz"))
+            manifest.setdefault("csv_sha256", {})[sub + "/" + fn] = \
+                hashlib.sha256(text.encode()).hexdigest()
+    od = tempfile.mkdtemp()
+    files = run_cli(["-g", gpa, "-t", tr, "--no_pairwise", "-r",
+                     os.path.join(EX, "Restrict_to.csv")], od)
+    for fn, text in files.items():
+        gz_write(text, os.path.join(HERE, "csv_no_pairwise_restrict", fn + ".gz"))
+
+    # -- third-party arithmetic: scipy.stats.fisher_exact grid ----------------
+    manifest["fisher_grid_n"] = fisher_grid(os.path.join(HERE, "fisher_grid.npz"))
+
+    # -- seeded tree-statistic Permute (pinned for the "next" row, D1) --------
+    gtc = res["Gene_trait_combinations"]["Tetracycline_resistance"]
+    TDM = rm.CreateTriangularDistanceMatrix(gd["Zero_ones_matrix"], gd["Strains"])
+    QT = rm.PopulateQuadTreeWithDistances(TDM)
+    tree = rm.upgma(QT)
+    obs = rm.ConvertUPGMAtoPhyloTree(tree, gtc["TetRCG"])
+    random.seed(0)
+    with quiet():
+        emp = rm.Permute(tree=tree, GTC=gtc["TetRCG"], permutations=100,
+                         cutoffs={"I": 0.05})
+    with open(os.path.join(HERE, "permute_tree_seeded.json"), "w") as f:
+        json.dump({"gene": "TetRCG", "observed": obs, "seed": 0,
+                   "permutations": 100, "empirical_p": emp}, f, indent=1)
+
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
