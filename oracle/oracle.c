@@ -1,0 +1,344 @@
+/*
+ * oracle.c -- CPU restatement of Scoary's association hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under scoary_amd/ may import, link or
+ * execute this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the reported baseline.
+ *
+ * What it restates (reference = AdmiralenOla/Scoary v1.6.16, paths relative
+ * to the reference checkout):
+ *   orc_counts_dense    scoary/methods.py:930-982  Perform_statistics
+ *   orc_counts_packed   same arithmetic on the bit-packed layout
+ *   orc_fisher          scoary/methods.py:854 -> scipy.stats.fisher_exact
+ *                       (third-party, SciPy 1.15.3 two-sided rule; see below)
+ *   orc_perm_labels     scoary/methods.py:1371-1384 PermuteGTC (label shuffle
+ *                       among valid isolates; counter-based RNG, see S4)
+ *   orc_permute_r       scoary/methods.py:1314-1369 Permute, with the Fisher
+ *                       statistic the north_star prescribes
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks these functions
+ * against tests/golden/ -- vectors captured from the real reference and from
+ * SciPy 1.15.3 by tests/golden/make_golden.py.
+ *
+ * Third-party arithmetic: scipy.stats.fisher_exact is not part of the
+ * reference tree.  Its published two-sided rule is restated here in "set"
+ * form:   p = sum{ pmf(x) : pmf(x) <= pmf(a_obs) * (1 + TIE) } over the
+ * hypergeometric support, min(p, 1); (nan, 1.0) when a margin is zero; sample
+ * odds ratio a*d/(b*c), inf when b*c == 0.  pmf ratios come from the exact
+ * recurrence  w(x+1)/w(x) = (n1-x)(n-x) / ((x+1)(n2-n+x+1))  normalised at the
+ * mode (an lgamma table loses ~ulp(lgamma(N)) and misses 1e-12 at N >= 2000,
+ * SURVEY finding 4).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_TIE 1e-10 /* relative tie window on recurrence weights (spec S3) */
+
+/* ------------------------------------------------------------------ S1 -- */
+/* Row-major bit packing: bit i of word w of a row = isolate 64*w + i.      */
+void orc_pack_rows(const uint8_t *dense, int64_t G, int64_t N, uint64_t *out)
+{
+    int64_t W = (N + 63) / 64;
+    memset(out, 0, (size_t)(G * W) * sizeof(uint64_t));
+    for (int64_t g = 0; g < G; ++g)
+        for (int64_t i = 0; i < N; ++i)
+            if (dense[g * N + i])
+                out[g * W + (i >> 6)] |= (uint64_t)1 << (i & 63);
+}
+
+/* ------------------------------------------------------------------ S2 -- */
+/* Perform_statistics, isolate by isolate (methods.py:940-965).
+ * trait[i]: 0 / 1, or 2 = missing for this trait (the reference drops such
+ * isolates from the traits dict, methods.py:591-598).  out: G x 4 =
+ * tpgp, tpgn, tngp, tngn. */
+void orc_counts_dense(const uint8_t *genes, const uint8_t *trait, int64_t G,
+                      int64_t N, int32_t *out)
+{
+    for (int64_t g = 0; g < G; ++g) {
+        int32_t tpgp = 0, tpgn = 0, tngp = 0, tngn = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            uint8_t t = trait[i], p = genes[g * N + i];
+            if (t > 1)
+                continue;
+            if (t == 1 && p)
+                ++tpgp;
+            else if (t == 1)
+                ++tpgn;
+            else if (p)
+                ++tngp;
+            else
+                ++tngn;
+        }
+        out[g * 4 + 0] = tpgp;
+        out[g * 4 + 1] = tpgn;
+        out[g * 4 + 2] = tngp;
+        out[g * 4 + 3] = tngn;
+    }
+}
+
+/* Same tallies on packed rows: a = popc(g&t), gm = popc(g&m), npos = popc(t),
+ * nval = popc(m)  =>  tpgp = a, tpgn = npos-a, tngp = gm-a,
+ * tngn = nval-npos-gm+a.  out: G x T x 4. */
+void orc_counts_packed(const uint64_t *genes, const uint64_t *traits,
+                       const uint64_t *masks, int64_t G, int64_t T, int64_t W,
+                       int32_t *out)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t g = 0; g < G; ++g) {
+        const uint64_t *gr = genes + g * W;
+        for (int64_t t = 0; t < T; ++t) {
+            const uint64_t *tr = traits + t * W, *mr = masks + t * W;
+            int32_t a = 0, gm = 0, npos = 0, nval = 0;
+            for (int64_t w = 0; w < W; ++w) {
+                a += __builtin_popcountll(gr[w] & tr[w]);
+                gm += __builtin_popcountll(gr[w] & mr[w]);
+                npos += __builtin_popcountll(tr[w]);
+                nval += __builtin_popcountll(mr[w]);
+            }
+            int32_t *o = out + (g * T + t) * 4;
+            o[0] = a;
+            o[1] = npos - a;
+            o[2] = gm - a;
+            o[3] = nval - npos - gm + a;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ S3 -- */
+/* Unnormalised hypergeometric weights over the support [lo, hi] of
+ * x = tpgp given margins (n1 = trait positives, n2 = trait negatives,
+ * n = gene margin), mode weight = 1.  Returns lo; *len = hi-lo+1. */
+static int64_t hg_weights(int64_t n1, int64_t n2, int64_t n, double *w,
+                          int64_t *len)
+{
+    int64_t lo = n - n2 > 0 ? n - n2 : 0;
+    int64_t hi = n < n1 ? n : n1;
+    int64_t mode = (int64_t)(((double)(n + 1) * (double)(n1 + 1)) /
+                             (double)(n1 + n2 + 2));
+    if (mode < lo)
+        mode = lo;
+    if (mode > hi)
+        mode = hi;
+    w[mode - lo] = 1.0;
+    for (int64_t x = mode; x < hi; ++x)
+        w[x + 1 - lo] = w[x - lo] * ((double)(n1 - x) * (double)(n - x)) /
+                        ((double)(x + 1) * (double)(n2 - n + x + 1));
+    for (int64_t x = mode; x > lo; --x)
+        w[x - 1 - lo] = w[x - lo] * ((double)x * (double)(n2 - n + x)) /
+                        ((double)(n1 - x + 1) * (double)(n - x + 1));
+    *len = hi - lo + 1;
+    return lo;
+}
+
+/* Two-sided Fisher exact p and sample odds ratio of [[a, b], [c, d]]
+ * (= [[tpgp, tpgn], [tngp, tngn]], methods.py:842-845). */
+void orc_fisher(int64_t a, int64_t b, int64_t c, int64_t d, double *p_out,
+                double *or_out)
+{
+    int64_t n1 = a + b, n2 = c + d, n = a + c;
+    if (n1 == 0 || n2 == 0 || n == 0 || b + d == 0) {
+        *p_out = 1.0;
+        *or_out = NAN;
+        return;
+    }
+    *or_out = (c > 0 && b > 0) ? ((double)a * (double)d) / ((double)c * (double)b)
+                               : INFINITY;
+    int64_t cap = (n < n1 ? n : n1) + 2;
+    double *w = (double *)malloc((size_t)cap * sizeof(double));
+    int64_t len, lo = hg_weights(n1, n2, n, w, &len);
+    double thr = w[a - lo] * (1.0 + ORC_TIE), tot = 0.0, inc = 0.0;
+    int all = 1;
+    for (int64_t i = 0; i < len; ++i) {
+        tot += w[i];
+        if (w[i] <= thr)
+            inc += w[i];
+        else
+            all = 0;
+    }
+    double p = all ? 1.0 : inc / tot;
+    *p_out = p < 1.0 ? p : 1.0;
+    free(w);
+}
+
+void orc_fisher_many(const int32_t *counts, int64_t M, double *p, double *orr)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64)
+#endif
+    for (int64_t i = 0; i < M; ++i)
+        orc_fisher(counts[i * 4], counts[i * 4 + 1], counts[i * 4 + 2],
+                   counts[i * 4 + 3], p + i, orr + i);
+}
+
+/* ------------------------------------------------------------------ S4 -- */
+/* Philox4x32-10 (Salmon et al., SC'11), the counter-based generator both
+ * sides use so CPU and GPU regenerate identical permutations. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2],
+                       uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+#define ORC_PERM_DOMAIN 0x53434F41u /* "SCOA": counter word 3 */
+
+/* One label permutation of trait `t`, index `pi`: a uniformly random subset
+ * of size npos of the valid isolates (== shuffling the 0/1 labels among the
+ * non-missing isolates, PermuteGTC methods.py:1377-1383), by sequential
+ * selection sampling (Knuth 3.4.2 Algorithm S).  Isolate i consumes the
+ * 64-bit draw u = Philox(key = seed, ctr = (i>>1, pi, t, "SCOA")) words
+ * (2*(i&1), 2*(i&1)+1); it is selected iff  mulhi64(u, remaining) < needed. */
+void orc_perm_labels(uint64_t seed, uint32_t t, uint32_t pi,
+                     const uint64_t *mask, int64_t npos, int64_t N,
+                     uint64_t *out)
+{
+    int64_t W = (N + 63) / 64;
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint64_t needed = (uint64_t)npos, remaining = 0;
+    for (int64_t w = 0; w < W; ++w)
+        remaining += (uint64_t)__builtin_popcountll(mask[w]);
+    memset(out, 0, (size_t)W * sizeof(uint64_t));
+    uint32_t rnd[4] = {0, 0, 0, 0};
+    for (int64_t i = 0; i < N; ++i) {
+        if (!(i & 1)) {
+            uint32_t ctr[4] = {(uint32_t)(i >> 1), pi, t, ORC_PERM_DOMAIN};
+            orc_philox4x32_10(ctr, key, rnd);
+        }
+        if (!((mask[i >> 6] >> (i & 63)) & 1))
+            continue;
+        uint64_t u = (i & 1) ? ((uint64_t)rnd[3] << 32 | rnd[2])
+                             : ((uint64_t)rnd[1] << 32 | rnd[0]);
+        uint64_t hi = (uint64_t)(((unsigned __int128)u * remaining) >> 64);
+        if (hi < needed) {
+            out[i >> 6] |= (uint64_t)1 << (i & 63);
+            --needed;
+        }
+        --remaining;
+    }
+}
+
+/* ------------------------------------------------------------------ S5 -- */
+/* r[g][t] = #{ pi < P : the permuted table is as or less probable than the
+ * observed one }, i.e. w(a_pi) <= w(a_obs) * (1 + TIE) under the (gene, trait)
+ * margins -- the rejection region of the two-sided Fisher test, so
+ * "p_pi <= p_obs".  Empirical p = (r+1)/(P+1) (methods.py:1365).  Genes the
+ * reference skips (all-absent / all-present among valid isolates,
+ * methods.py:804-814) and degenerate traits get r = P.
+ * perm_base: permutation indices are perm_base .. perm_base+P-1. */
+void orc_permute_r(const uint64_t *genes, const uint64_t *traits,
+                   const uint64_t *masks, int64_t G, int64_t T, int64_t N,
+                   int64_t P, uint64_t seed, int64_t perm_base, uint32_t *r_out)
+{
+    enum { PB = 64 };
+    int64_t W = (N + 63) / 64;
+    uint64_t *labs = (uint64_t *)malloc((size_t)(PB * W) * sizeof(uint64_t));
+    memset(r_out, 0, (size_t)(G * T) * sizeof(uint32_t));
+    for (int64_t t = 0; t < T; ++t) {
+        const uint64_t *tr = traits + t * W, *mr = masks + t * W;
+        int64_t npos = 0, nval = 0;
+        for (int64_t w = 0; w < W; ++w) {
+            npos += __builtin_popcountll(tr[w]);
+            nval += __builtin_popcountll(mr[w]);
+        }
+        int64_t nneg = nval - npos;
+        /* per gene: margin, observed a, and the exceedance table over a */
+        int32_t *gm = (int32_t *)malloc((size_t)G * sizeof(int32_t));
+        int32_t *aobs = (int32_t *)malloc((size_t)G * sizeof(int32_t));
+        /* memo over gene margin: weights array + support offset */
+        double **wtab = (double **)calloc((size_t)(nval + 2), sizeof(double *));
+        int64_t *wlo = (int64_t *)calloc((size_t)(nval + 2), sizeof(int64_t));
+        for (int64_t g = 0; g < G; ++g) {
+            int32_t a = 0, m = 0;
+            for (int64_t w = 0; w < W; ++w) {
+                a += __builtin_popcountll(genes[g * W + w] & tr[w]);
+                m += __builtin_popcountll(genes[g * W + w] & mr[w]);
+            }
+            gm[g] = m;
+            aobs[g] = a;
+            if (npos > 0 && nneg > 0 && m > 0 && m < nval && !wtab[m]) {
+                int64_t cap = (m < npos ? m : npos) + 2, len;
+                wtab[m] = (double *)malloc((size_t)cap * sizeof(double));
+                wlo[m] = hg_weights(npos, nneg, m, wtab[m], &len);
+            }
+        }
+        for (int64_t p0 = 0; p0 < P; p0 += PB) {
+            int64_t nb = P - p0 < PB ? P - p0 : PB;
+            for (int64_t j = 0; j < nb; ++j)
+                orc_perm_labels(seed, (uint32_t)t, (uint32_t)(perm_base + p0 + j),
+                                mr, npos, N, labs + j * W);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+            for (int64_t g = 0; g < G; ++g) {
+                const uint64_t *gr = genes + g * W;
+                int32_t m = gm[g];
+                uint32_t cnt = 0;
+                if (!wtab[m]) {
+                    cnt = (uint32_t)nb;
+                } else {
+                    const double *w = wtab[m];
+                    int64_t lo = wlo[m];
+                    double thr = w[aobs[g] - lo] * (1.0 + ORC_TIE);
+                    for (int64_t j = 0; j < nb; ++j) {
+                        const uint64_t *lr = labs + j * W;
+                        int32_t a = 0;
+                        for (int64_t k = 0; k < W; ++k)
+                            a += __builtin_popcountll(gr[k] & lr[k]);
+                        cnt += w[a - lo] <= thr;
+                    }
+                }
+                r_out[g * T + t] += cnt;
+            }
+        }
+        for (int64_t m = 0; m < nval + 2; ++m)
+            free(wtab[m]);
+        free(wtab);
+        free(wlo);
+        free(gm);
+        free(aobs);
+    }
+    free(labs);
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
