@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- gene x permutation Fisher tests/s on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path over the headline synthetic batch
+(BASELINE.json configs[2]: 50k genes x 2000 isolates x 10 traits, 10k label
+permutations): contingency counts -> Fisher p + rejection regions -> label
+permutation generation -> permutation exceedance counts, inputs resident in
+HBM.  tests per step = G*T*P per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: genes shard across ranks (every rank holds its own G-gene shard of a
+G*N-gene matrix: weak scaling); trait / permutation vectors are regenerated
+identically on every rank from the seed (no broadcast); the one exchange step
+of the path -- gathering per-gene results -- is an RCCL all_gather inside the
+timed region.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (upper bound)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--genes", type=int, default=None, help="override G (per GPU)")
+    ap.add_argument("--permutations", type=int, default=None, help="override P")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(genes, traits, N, seed, target_s):
+    """Time the CPU oracle (the C restatement, OpenMP over genes) on a bounded
+    sample of the same workload: all T traits, a gene subsample, P_s
+    permutations; whole path (counts + Fisher weights + permutations)."""
+    from oracle import oracle as orc
+    from scoary_amd.engine import pack_bits_rows
+    cores = orc.num_threads()
+    T = traits.shape[0]
+    Gs = min(genes.shape[0], 4096)
+    gb = orc.pack_rows(genes[:Gs])
+    tb = pack_bits_rows((traits == 1).astype(np.uint8))
+    mb = pack_bits_rows((traits != 2).astype(np.uint8))
+    t0 = time.perf_counter()
+    orc.permute_r(gb, tb, mb, N, 64, seed)
+    probe = time.perf_counter() - t0
+    rate = Gs * T * 64 / probe
+    Ps = int(max(64, min(20000, target_s * rate / (Gs * T))))
+    t0 = time.perf_counter()
+    orc.permute_r(gb, tb, mb, N, Ps, seed)
+    dt = time.perf_counter() - t0
+    return {"value": Gs * T * Ps / dt, "unit": "gene-permutation Fisher tests/s",
+            "cores": cores, "kind": "port",
+            "sample": "oracle/oracle.c orc_permute_r (counts + Fisher weights + label "
+                      "permutations + exceedance), %d genes x %d isolates x %d traits x %d "
+                      "permutations, %d OpenMP threads, %.1f s" % (Gs, N, T, Ps, cores, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); none visible")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from scoary_amd import synth
+    from scoary_amd.engine import AssociationEngine, pack_bits_rows
+
+    # every rank: its own gene shard (different seed offset), same traits
+    genes, traits, P, seed = synth.make_config(args.config, G=args.genes)
+    if rank > 0:
+        rng = np.random.default_rng(seed + 1000 * rank)
+        genes = synth.make_genes(genes.shape[0], genes.shape[1], rng,
+                                 kind="rare" if args.config == "cfg4" else "uniform",
+                                 core_frac=0.05 if args.config == "cfg3" else 0.0)
+    if args.permutations:
+        P = args.permutations
+    G, N = genes.shape
+    T = traits.shape[0]
+
+    eng = AssociationEngine(local_rank)
+    gm = eng.pack_dense(genes)                     # bit-packed once into HBM
+    trv = eng.vecrows(pack_bits_rows((traits == 1).astype(np.uint8)), N)
+    mkv = eng.vecrows(pack_bits_rows((traits != 2).astype(np.uint8)), N)
+    pbatch = eng.perm_batch(T, N, P)
+    perm_buf = torch.empty((T, pbatch, eng.row_words(N)), dtype=torch.int32, device=eng.device)
+    gather_buf = None
+    if world > 1:
+        rec_words = 4 + 2 + 2 + 1            # counts, p, odds, r as int32 words
+        gather_buf = torch.empty((world, T, G, rec_words), dtype=torch.int32, device=eng.device)
+
+    def step():
+        res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, perm_buffer=perm_buf)
+        if world > 1:
+            rec = torch.cat([res["counts"],
+                             res["p"].view(torch.int32).view(T, G, 2),
+                             res["odds"].view(torch.int32).view(T, G, 2),
+                             res["r"].view(T, G, 1)], dim=2).contiguous()
+            dist.all_gather_into_tensor(gather_buf, rec)
+        return res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    k3_ms = eng.kernel_ms("k_permute")
+    kernel_ms = {k: eng.kernel_ms(k) for k in
+                 ("k_margins", "k_counts", "k_fisher", "k_perm_generate", "k_permute")}
+    eng.set_timing(False)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    tests_per_step = G * T * P * world
+    value = tests_per_step * args.steps / dt
+
+    if rank == 0:
+        W64 = (N + 63) // 64
+        launches_per_step = -(-P // pbatch)
+        tests_per_launch = G * T * min(P, pbatch)
+        alg_bytes = 16.0 * W64 * tests_per_launch        # 16*W bytes / test
+        achieved = alg_bytes / (k3_ms * 1e-3) / 1e9
+        w32 = -(-N // 32)
+        valu_ops = tests_per_launch * (2.0 * w32 + 6)
+        out = {
+            "metric": "gene x permutation Fisher tests/sec",
+            "value": value,
+            "unit": "tests/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 bit-words (AND + popcount), f64 for Fisher p",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d genes x %d isolates x %d traits, --permute %d per GPU; "
+                                   "counts + Fisher + label permutations + exceedance counts"
+                                   % (args.config, G, N, T, P),
+                       "genes_per_gpu": G, "isolates": N, "traits": T, "permutations": P,
+                       "parallelism": "gene-shard x%d" % world},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_permute",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "model": "operand bytes 16*ceil(N/64) B per test (SURVEY 8d); frac > 1 means the "
+                         "kernel left the HBM-bound regime (operands reused from VGPR/SGPR)",
+                "kernel_ms": k3_ms,
+                "launches_per_step": launches_per_step,
+                "valu_frac_of_2.4GHz_simd32_peak": valu_ops / (k3_ms * 1e-3) / VALU_LANE_OPS_PER_S,
+            },
+            "kernel_ms": kernel_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(genes, traits, N, seed, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+/*
+ * scoary_hip.h -- C-ABI of the MI355X-native association engine for Scoary.
+ *
+ * Drop-in boundary for ONE path of AdmiralenOla/Scoary (v1.6.16): the per-gene
+ * 2x2 contingency counting + Fisher exact test of Setup_results /
+ * Perform_statistics and the --permute label-shuffling empirical-p loop.
+ * The reference is pure Python and has no FFI of its own; each entry point
+ * below names the reference code it replaces (paths relative to the reference
+ * checkout) -- that call site is where a maintainer binds it (ctypes stub in
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - every `d_` pointer is DEVICE memory on the handle's GPU, owned by the
+ *     caller (e.g. a torch tensor's data_ptr()); nothing is allocated or freed
+ *     behind the caller's back except a small per-handle scratch;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream) and never synchronises the device;
+ *   - return value: 0 = ok, negative = error (see scoary_last_error); the
+ *     library never calls exit();
+ *   - one handle per GPU; a handle is used by one host thread at a time.
+ *
+ * Device layouts (all little-endian)
+ *   rows64   : uint64 [R][W64], W64 = ceil(N/64); bit i of word w of a row is
+ *              isolate 64*w+i; pad bits are zero.  (How the reference's
+ *              genedic / traitsdic 0/1 values are bit-packed)
+ *   tiled    : the gene matrix as the kernels read it: uint32 [Qp][Gp][4]
+ *              ("word-quad-major"): the 16 bytes at ((q*Gp)+g)*16 hold 32-bit
+ *              words 4q..4q+3 of gene g's row.  Qp = scoary_tiled_quads(N),
+ *              Gp = scoary_tiled_genes(G); padding genes / words are zero.
+ *              One lane owns one gene, so a wavefront's loads are 1 KiB
+ *              coalesced and the per-trait operand is wave-uniform.
+ *   vecrows  : trait / validity-mask / permuted-label vectors: uint32 [R][Wp],
+ *              Wp = scoary_row_words(N) = 4*Qp >= 2*W64 (a rows64 row followed
+ *              by zero padding).
+ */
+#ifndef SCOARY_HIP_H
+#define SCOARY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCOARY_ABI_VERSION 1
+
+/* error codes */
+#define SCOARY_OK 0
+#define SCOARY_ERR_ARG (-1)    /* bad argument (null pointer, negative size) */
+#define SCOARY_ERR_HIP (-2)    /* a HIP runtime call failed */
+#define SCOARY_ERR_SIZE (-3)   /* problem size outside what the kernels support */
+#define SCOARY_ERR_DEVICE (-4) /* no such device / not a gfx950 code object */
+
+typedef struct scoary_ctx *scoary_handle;
+typedef void *scoary_stream_t; /* hipStream_t */
+
+int scoary_abi_version(void);
+
+/* Create / destroy the per-GPU context. */
+int scoary_create(int device, scoary_handle *out);
+void scoary_destroy(scoary_handle h);
+/* Message of the last failing call on this handle ("" if none). */
+const char *scoary_last_error(scoary_handle h);
+
+/* Layout arithmetic (pure functions, usable without a GPU). */
+int64_t scoary_tiled_quads(int64_t N);            /* Qp */
+int64_t scoary_tiled_genes(int64_t G);            /* Gp */
+int64_t scoary_tiled_bytes(int64_t G, int64_t N); /* 16*Qp*Gp */
+int64_t scoary_row_words(int64_t N);              /* Wp */
+
+/* ---- a1: genedic -> packed bits ---------------------------------------
+ * Replaces the dict-of-dicts the reference builds in Csv_to_dic_Roary
+ * (scoary/methods.py:445-491; presence rule :476-485 applied by the caller).
+ * scoary_pack_dense : d_dense is uint8 [G][N], non-zero = present.
+ * scoary_tile_rows  : d_rows64 is rows64 [G][W64].
+ * Both write the full tiled buffer (scoary_tiled_bytes), padding included. */
+int scoary_pack_dense(scoary_handle h, const uint8_t *d_dense, int64_t G,
+                      int64_t N, uint32_t *d_tiled, scoary_stream_t stream);
+int scoary_tile_rows(scoary_handle h, const uint64_t *d_rows64, int64_t G,
+                     int64_t N, uint32_t *d_tiled, scoary_stream_t stream);
+
+/* ---- a3: Perform_statistics (scoary/methods.py:930-982) ----------------
+ * For every (trait, gene): tpgp, tpgn, tngp, tngn over the isolates that are
+ * valid for that trait.  d_traits / d_masks are vecrows [T][Wp] (label bits,
+ * validity bits; traits & ~masks must be 0).
+ *   d_counts  : int32 [T][G][4]   (tpgp, tpgn, tngp, tngn)  -- bit-exact
+ *   d_margins : int32 [T][2]      (npos, nval) per trait */
+int scoary_counts(scoary_handle h, const uint32_t *d_tiled,
+                  const uint32_t *d_traits, const uint32_t *d_masks, int64_t G,
+                  int64_t T, int64_t N, int32_t *d_counts, int32_t *d_margins,
+                  scoary_stream_t stream);
+
+/* ---- a5: scipy.stats.fisher_exact(obs_table) at scoary/methods.py:854 ---
+ * Two-sided Fisher exact p and sample odds ratio for M 2x2 tables
+ * [[tpgp, tpgn], [tngp, tngn]] (d_tables int32 [M][4]); SciPy >= 1.7
+ * semantics: (nan, 1.0) when a margin is zero, inf odds when tpgn*tngp == 0.
+ *   d_p, d_or : double [M]
+ *   d_crit    : uint32 [M][2] or NULL -- the rejection region of table m as
+ *               (base, span): a permuted table with overlap count a' is "as
+ *               or more extreme" iff (uint32)(a' - base) >= span.  Consumed by
+ *               scoary_permute.  Tables the reference never tests
+ *               (gene absent / present in all valid isolates,
+ *               scoary/methods.py:804-814) get p = 1, odds = nan, span = 0. */
+int scoary_fisher(scoary_handle h, const int32_t *d_tables, int64_t M,
+                  double *d_p, double *d_or, uint32_t *d_crit,
+                  scoary_stream_t stream);
+
+/* ---- a8: PermuteGTC (scoary/methods.py:1371-1384) ----------------------
+ * Label permutations pi = perm_base .. perm_base+P-1 of every trait: the
+ * trait's npos positive labels placed on a uniformly random subset of its
+ * valid isolates (counter-based: Philox4x32-10 keyed by `seed`, counter
+ * (isolate>>1, pi, trait, "SCOA"), sequential selection sampling -- DESIGN.md
+ * spec S4; the CPU oracle regenerates the same bits).
+ *   d_perms : vecrows [T][P][Wp] */
+int scoary_perm_generate(scoary_handle h, const uint32_t *d_masks,
+                         const int32_t *d_margins, int64_t T, int64_t N,
+                         int64_t P, int64_t perm_base, uint64_t seed,
+                         uint32_t *d_perms, scoary_stream_t stream);
+
+/* ---- a7: Permute (scoary/methods.py:1314-1369), Fisher statistic --------
+ * d_r[t][g] += #{ pi < P : popcount(gene_g & perm_{t,pi}) lies in the
+ * rejection region d_crit[t][g] }.  The caller zeroes d_r (uint32 [T][G])
+ * before the first chunk of permutations; Empirical_p = (r+1)/(P_total+1)
+ * (scoary/methods.py:1365). */
+int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
+                   const uint32_t *d_perms, const uint32_t *d_crit, int64_t G,
+                   int64_t T, int64_t N, int64_t P, uint32_t *d_r,
+                   scoary_stream_t stream);
+
+/* Name + average device time (ms, hipEvent on `stream`) of the kernels the
+ * last scoary_permute call launched; for bench.py's roofline line.  Costs a
+ * stream sync; timing is recorded only after scoary_set_timing(h, 1). */
+int scoary_set_timing(scoary_handle h, int enabled);
+int scoary_last_kernel_ms(scoary_handle h, const char *kernel, double *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCOARY_HIP_H */

@@ -1,0 +1,681 @@
+// scoary_hip.hip -- gfx950 (MI355X / CDNA4) kernels + C-ABI for Scoary's
+// association hot path.  See include/scoary_hip.h for the contract and
+// DESIGN.md for layouts, byte models and the specs S1-S5 shared with the CPU
+// oracle.
+//
+// Design in one paragraph: the gene presence/absence matrix lives in HBM as
+// 32-bit words in "word-quad-major" order, so ONE LANE OWNS ONE GENE: a
+// wavefront's gene loads are 1 KiB coalesced dwordx4, while the other operand
+// of every AND -- a trait / mask / permuted-label word -- is wave-uniform and
+// is fetched through the SCALAR cache into SGPRs.  The inner loop is therefore
+// exactly two VALU ops per 32 isolates per (gene, vector) pair:
+//     v_and_b32  tmp, s_vec, v_gene ;  v_bcnt_u32_b32  acc, tmp, acc
+// with no LDS traffic and no cross-lane reduction.  There is no MFMA: CDNA4
+// has no AND-popcount matrix mode, and this is integer/bit work.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "scoary_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kGeneAlign = 256;
+constexpr double kTie = 1e-10;             // spec S3: relative tie window
+constexpr uint32_t kPermDomain = 0x53434F41u;  // "SCOA", spec S4
+
+// Row sizes (in quads of four 32-bit words) for which a gene row is held
+// entirely in VGPRs by k_permute_reg.
+constexpr int kRegQuads[] = {1, 2, 4, 6, 8, 12, 16, 20, 24, 32, 40, 48};
+constexpr int kMaxRegQuads = 48;
+constexpr int kChunkQuads = 8;  // k_permute_chunked: quads per register chunk
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+inline int64_t tiled_quads(int64_t N) {
+  int64_t q = (((N + 31) / 32) + 3) / 4;
+  if (q < 1) q = 1;
+  for (int r : kRegQuads)
+    if (r >= q) return r;
+  return round_up(q, kChunkQuads);
+}
+
+// ----------------------------------------------------------------------------
+// a1: packing
+// ----------------------------------------------------------------------------
+// One thread per (gene, 32-bit word): 32 presence bytes -> one word.
+__global__ __launch_bounds__(256) void k_pack_dense(const uint8_t* __restrict__ dense,
+                                                    int64_t G, int64_t N, int64_t Gp,
+                                                    int64_t Qp, uint32_t* __restrict__ tiled) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t k = blockIdx.y;  // 32-bit word index, < 4*Qp
+  if (g >= Gp) return;
+  uint32_t word = 0;
+  if (g < G) {
+    const int64_t i0 = k * 32;
+    const uint8_t* row = dense + g * N;
+    for (int b = 0; b < 32; ++b) {
+      const int64_t i = i0 + b;
+      if (i < N && row[i] != 0) word |= 1u << b;
+    }
+  }
+  tiled[((k >> 2) * Gp + g) * 4 + (k & 3)] = word;
+}
+
+// One thread per (gene, quad): 16 bytes of a row-major bit row -> its tile slot.
+__global__ __launch_bounds__(256) void k_tile_rows(const uint32_t* __restrict__ rows32,
+                                                   int64_t G, int64_t W32, int64_t Gp,
+                                                   uint4* __restrict__ tiled) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t q = blockIdx.y;
+  if (g >= Gp) return;
+  uint32_t w[4] = {0, 0, 0, 0};
+  if (g < G) {
+    const uint32_t* row = rows32 + g * W32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < W32) w[j] = row[q * 4 + j];
+  }
+  tiled[q * Gp + g] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ----------------------------------------------------------------------------
+// a3: contingency counts
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_margins(const uint32_t* __restrict__ traits,
+                                                const uint32_t* __restrict__ masks, int Wp,
+                                                int32_t* __restrict__ margins) {
+  const int t = blockIdx.x;
+  int npos = 0, nval = 0;
+  for (int k = threadIdx.x; k < Wp; k += kWave) {
+    npos += __popc(traits[(int64_t)t * Wp + k]);
+    nval += __popc(masks[(int64_t)t * Wp + k]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    npos += __shfl_down(npos, off);
+    nval += __shfl_down(nval, off);
+  }
+  if (threadIdx.x == 0) {
+    margins[2 * t] = npos;
+    margins[2 * t + 1] = nval;
+  }
+}
+
+__device__ __forceinline__ int popc4(const uint4 a, const uint4 b) {
+  return __popc(a.x & b.x) + __popc(a.y & b.y) + __popc(a.z & b.z) + __popc(a.w & b.w);
+}
+
+// acc += popcount(x) as ONE v_bcnt_u32_b32 (its second operand is the
+// accumulator).  Opaque to the optimiser on purpose: left to itself LLVM
+// reassociates the accumulate chain into short chains joined by v_add3_u32,
+// ~15 % more VALU work in the permutation inner loop.
+__device__ __forceinline__ void bcnt_acc(uint32_t& acc, uint32_t x) {
+  asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+}
+
+// Lane = gene; blockIdx.y = group of TB traits.  Gene quads stream once per
+// trait group (coalesced 16 B / lane); trait and mask quads are wave-uniform
+// (scalar loads).
+template <int TB>
+__global__ __launch_bounds__(256) void k_counts(const uint4* __restrict__ tiled,
+                                                const uint32_t* __restrict__ traits,
+                                                const uint32_t* __restrict__ masks,
+                                                const int32_t* __restrict__ margins, int G,
+                                                int Gp, int Qp, int T, int4* __restrict__ counts) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int t0 = blockIdx.y * TB;
+  const int Wp = Qp * 4;
+  int a[TB], m[TB];
+  const uint4* trow[TB];
+  const uint4* mrow[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    a[j] = 0;
+    m[j] = 0;
+    const int t = min(t0 + j, T - 1);
+    trow[j] = reinterpret_cast<const uint4*>(traits + (int64_t)t * Wp);
+    mrow[j] = reinterpret_cast<const uint4*>(masks + (int64_t)t * Wp);
+  }
+  for (int q = 0; q < Qp; ++q) {
+    const uint4 gw = tiled[(int64_t)q * Gp + g];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      a[j] += popc4(gw, trow[j][q]);
+      m[j] += popc4(gw, mrow[j][q]);
+    }
+  }
+  if (g >= G) return;
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    const int t = t0 + j;
+    if (t < T) {
+      const int npos = margins[2 * t], nval = margins[2 * t + 1];
+      counts[(int64_t)t * G + g] =
+          make_int4(a[j], npos - a[j], m[j] - a[j], nval - npos - m[j] + a[j]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// a5: two-sided Fisher exact test (spec S3)
+// ----------------------------------------------------------------------------
+// Hypergeometric weights by the exact ratio recurrence, normalised at the
+// mode; same operation order as the oracle's hg_weights so the weights (and
+// hence the rejection regions) are bit-identical on both sides.
+__device__ __forceinline__ double w_up(double w, int x, int n1, int n2, int n) {
+  return w * ((double)(n1 - x) * (double)(n - x)) / ((double)(x + 1) * (double)(n2 - n + x + 1));
+}
+__device__ __forceinline__ double w_down(double w, int x, int n1, int n2, int n) {
+  return w * ((double)x * (double)(n2 - n + x)) / ((double)(n1 - x + 1) * (double)(n - x + 1));
+}
+
+__global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, int64_t M,
+                                               double* __restrict__ p_out,
+                                               double* __restrict__ or_out,
+                                               uint2* __restrict__ crit) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M) return;
+  const int4 c = tables[idx];
+  const int a = c.x, b = c.y, cc = c.z, d = c.w;
+  const int n1 = a + b, n2 = cc + d, n = a + cc;
+  if (n1 == 0 || n2 == 0 || n == 0 || b + d == 0) {
+    p_out[idx] = 1.0;
+    or_out[idx] = __longlong_as_double(0x7ff8000000000000LL);
+    if (crit) crit[idx] = make_uint2(0u, 0u);
+    return;
+  }
+  or_out[idx] = (cc > 0 && b > 0) ? ((double)a * (double)d) / ((double)cc * (double)b)
+                                  : __longlong_as_double(0x7ff0000000000000LL);
+  const int lo = max(0, n - n2), hi = min(n, n1);
+  int mode = (int)(((double)(n + 1) * (double)(n1 + 1)) / (double)(n1 + n2 + 2));
+  mode = min(max(mode, lo), hi);
+
+  double w = 1.0;
+  if (a > mode)
+    for (int x = mode; x < a; ++x) w = w_up(w, x, n1, n2, n);
+  else
+    for (int x = mode; x > a; --x) w = w_down(w, x, n1, n2, n);
+  const double thr = w * (1.0 + kTie);
+
+  double tot = 0.0, inc = 0.0;
+  int H = hi + 1, L = lo - 1;
+  w = 1.0;
+  for (int x = mode; x <= hi; ++x) {
+    tot += w;
+    if (w <= thr) {
+      inc += w;
+      if (H > hi) H = x;
+    }
+    w = w_up(w, x, n1, n2, n);
+  }
+  w = 1.0;
+  for (int x = mode; x > lo; --x) {
+    w = w_down(w, x, n1, n2, n);  // weight of x-1
+    tot += w;
+    if (w <= thr) {
+      inc += w;
+      if (L < lo) L = x - 1;
+    }
+  }
+  const bool all = (H == mode);
+  const double p = all ? 1.0 : inc / tot;
+  p_out[idx] = p < 1.0 ? p : 1.0;
+  if (crit) crit[idx] = all ? make_uint2(0u, 0u) : make_uint2((uint32_t)(L + 1), (uint32_t)(H - L - 1));
+}
+
+// ----------------------------------------------------------------------------
+// a8: label permutations (spec S4)
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0;
+    c1 = l1;
+    c2 = n2;
+    c3 = l0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+// One thread per (trait, permutation): sequential selection sampling over the
+// isolates, 32 at a time; the validity word is wave-uniform (blockIdx.y =
+// trait), the 64-bit draws come from Philox keyed by (isolate>>1, pi, trait).
+__global__ __launch_bounds__(64) void k_perm_generate(const uint32_t* __restrict__ masks,
+                                                      const int32_t* __restrict__ margins, int N,
+                                                      int Wp, int64_t P, int64_t perm_base,
+                                                      uint32_t k0, uint32_t k1,
+                                                      uint32_t* __restrict__ perms) {
+  const int t = blockIdx.y;
+  const int64_t pl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl >= P) return;
+  const uint32_t pi = (uint32_t)(perm_base + pl);
+  uint64_t needed = (uint64_t)margins[2 * t], remaining = (uint64_t)margins[2 * t + 1];
+  const uint32_t* mrow = masks + (int64_t)t * Wp;
+  uint32_t* out = perms + ((int64_t)t * P + pl) * Wp;
+  const int nw = (N + 31) / 32;
+  for (int k = 0; k < nw; ++k) {
+    const uint32_t mw = mrow[k];
+    uint32_t word = 0;
+#pragma unroll 4
+    for (int jj = 0; jj < 16; ++jj) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)(k * 16 + jj), pi, (uint32_t)t, kPermDomain, k0, k1, r);
+      if ((mw >> (2 * jj)) & 1u) {
+        const uint64_t u = ((uint64_t)r[1] << 32) | r[0];
+        if (__umul64hi(u, remaining) < needed) {
+          word |= 1u << (2 * jj);
+          --needed;
+        }
+        --remaining;
+      }
+      if ((mw >> (2 * jj + 1)) & 1u) {
+        const uint64_t u = ((uint64_t)r[3] << 32) | r[2];
+        if (__umul64hi(u, remaining) < needed) {
+          word |= 1u << (2 * jj + 1);
+          --needed;
+        }
+        --remaining;
+      }
+    }
+    out[k] = word;
+  }
+  for (int k = nw; k < Wp; ++k) out[k] = 0u;
+}
+
+// ----------------------------------------------------------------------------
+// a7: permutation exceedance counts
+// ----------------------------------------------------------------------------
+// Register-resident variant: a lane keeps GL whole gene rows (RQ quads each)
+// in VGPRs and walks a chunk of permuted label rows, which arrive as scalar
+// loads.  Work per (gene, permutation): 8*RQ VALU ops + 3 for the region test.
+// grid = (Gp / (64*GL), perm chunks, T), block = one wavefront.
+template <int RQ, int GL>
+__global__ __launch_bounds__(64) void k_permute_reg(const uint4* __restrict__ tiled,
+                                                    const uint32_t* __restrict__ perms,
+                                                    const uint2* __restrict__ crit, int G, int Gp,
+                                                    int64_t P, int pchunk,
+                                                    uint32_t* __restrict__ r) {
+  const int t = blockIdx.z;
+  const int lane = threadIdx.x;
+  const int g0 = blockIdx.x * (kWave * GL) + lane;
+  const int64_t p0 = (int64_t)blockIdx.y * pchunk;
+  const int np = (int)min((int64_t)pchunk, P - p0);
+
+  uint4 gw[GL][RQ];
+  uint32_t base[GL], span[GL], cnt[GL];
+#pragma unroll
+  for (int gl = 0; gl < GL; ++gl) {
+    const int g = g0 + gl * kWave;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) gw[gl][q] = tiled[(int64_t)q * Gp + g];
+    const uint2 cr = (g < G) ? crit[(int64_t)t * G + g] : make_uint2(0u, 0u);
+    base[gl] = cr.x;
+    span[gl] = cr.y;
+    cnt[gl] = 0;
+  }
+
+  const uint4* prow = reinterpret_cast<const uint4*>(perms + ((int64_t)t * P + p0) * (RQ * 4));
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+  for (int i = 0; i < np; ++i, prow += RQ) {
+    uint32_t acc[GL][4];
+#pragma unroll
+    for (int gl = 0; gl < GL; ++gl) acc[gl][0] = acc[gl][1] = acc[gl][2] = acc[gl][3] = 0;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const uint4 s = prow[q];  // wave-uniform address -> s_load
+#pragma unroll
+      for (int gl = 0; gl < GL; ++gl) {
+        bcnt_acc(acc[gl][0], gw[gl][q].x & s.x);
+        bcnt_acc(acc[gl][1], gw[gl][q].y & s.y);
+        bcnt_acc(acc[gl][2], gw[gl][q].z & s.z);
+        bcnt_acc(acc[gl][3], gw[gl][q].w & s.w);
+      }
+    }
+#pragma unroll
+    for (int gl = 0; gl < GL; ++gl) {
+      const uint32_t a = (acc[gl][0] + acc[gl][1]) + (acc[gl][2] + acc[gl][3]);
+      cnt[gl] += ((a - base[gl]) >= span[gl]) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int gl = 0; gl < GL; ++gl) {
+    const int g = g0 + gl * kWave;
+    if (g < G && cnt[gl]) atomicAdd(&r[(int64_t)t * G + g], cnt[gl]);
+  }
+}
+
+// General variant for rows too long to keep in registers: CQ-quad register
+// chunks of the gene row, PB permutations accumulated per pass.
+template <int CQ, int PB>
+__global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict__ tiled,
+                                                        const uint32_t* __restrict__ perms,
+                                                        const uint2* __restrict__ crit, int G,
+                                                        int Gp, int Qp, int64_t P, int pchunk,
+                                                        uint32_t* __restrict__ r) {
+  const int t = blockIdx.z;
+  const int g = blockIdx.x * kWave + threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.y * pchunk;
+  const int np = (int)min((int64_t)pchunk, P - p0);
+  const uint2 cr = (g < G) ? crit[(int64_t)t * G + g] : make_uint2(0u, 0u);
+  const int nchunks = Qp / CQ;
+  uint32_t cnt = 0;
+  const uint4* pbase = reinterpret_cast<const uint4*>(perms + ((int64_t)t * P + p0) * ((int64_t)Qp * 4));
+  for (int i0 = 0; i0 < np; i0 += PB) {
+    uint32_t acc[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[j] = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      uint4 gw[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) gw[q] = tiled[(int64_t)(c * CQ + q) * Gp + g];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const int i = min(i0 + j, np - 1);
+        const uint4* pr = pbase + (int64_t)i * Qp + c * CQ;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) acc[j] += popc4(gw[q], pr[q]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      if (i0 + j < np) cnt += ((acc[j] - cr.x) >= cr.y) ? 1u : 0u;
+  }
+  if (g < G && cnt) atomicAdd(&r[(int64_t)t * G + g], cnt);
+}
+
+}  // namespace
+
+// ============================================================================
+// Host side: context, error handling, launches
+// ============================================================================
+struct scoary_ctx {
+  int device = 0;
+  int num_cu = 256;
+  std::string err;
+  bool timing = false;
+  struct Timed {
+    std::string name;
+    hipEvent_t start, stop;
+  };
+  std::vector<Timed> timed;
+};
+
+namespace {
+
+int fail(scoary_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(h, SCOARY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// Sets the handle's device for the duration of a call and restores the
+// caller's (torch's) current device afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+struct KernelTimer {
+  scoary_handle h;
+  hipStream_t s;
+  hipEvent_t start = nullptr, stop = nullptr;
+  KernelTimer(scoary_handle h_, hipStream_t s_, const char* name) : h(h_), s(s_) {
+    if (!h->timing) return;
+    if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) {
+      start = stop = nullptr;
+      return;
+    }
+    (void)hipEventRecord(start, s);
+    h->timed.push_back({name, start, stop});
+  }
+  ~KernelTimer() {
+    if (stop) (void)hipEventRecord(stop, s);
+  }
+};
+
+template <int RQ, int GL>
+void launch_permute_reg(dim3 grid, hipStream_t s, const uint32_t* tiled, const uint32_t* perms,
+                        const uint32_t* crit, int G, int Gp, int64_t P, int pchunk, uint32_t* r) {
+  hipLaunchKernelGGL((k_permute_reg<RQ, GL>), grid, dim3(kWave), 0, s,
+                     reinterpret_cast<const uint4*>(tiled), perms,
+                     reinterpret_cast<const uint2*>(crit), G, Gp, P, pchunk, r);
+}
+
+}  // namespace
+
+extern "C" {
+
+int scoary_abi_version(void) { return SCOARY_ABI_VERSION; }
+
+int64_t scoary_tiled_quads(int64_t N) { return tiled_quads(N); }
+int64_t scoary_tiled_genes(int64_t G) { return round_up(G < 1 ? 1 : G, kGeneAlign); }
+int64_t scoary_tiled_bytes(int64_t G, int64_t N) {
+  return 16 * scoary_tiled_quads(N) * scoary_tiled_genes(G);
+}
+int64_t scoary_row_words(int64_t N) { return 4 * scoary_tiled_quads(N); }
+
+int scoary_create(int device, scoary_handle* out) {
+  if (!out) return SCOARY_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SCOARY_ERR_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SCOARY_ERR_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::fprintf(stderr, "scoary_hip: device %d is %s; this library is built for gfx950 only\n",
+                 device, prop.gcnArchName);
+    return SCOARY_ERR_DEVICE;
+  }
+  scoary_ctx* h = new scoary_ctx();
+  h->device = device;
+  h->num_cu = prop.multiProcessorCount;
+  *out = h;
+  return SCOARY_OK;
+}
+
+void scoary_destroy(scoary_handle h) {
+  if (!h) return;
+  for (auto& t : h->timed) {
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  delete h;
+}
+
+const char* scoary_last_error(scoary_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int scoary_pack_dense(scoary_handle h, const uint8_t* d_dense, int64_t G, int64_t N,
+                      uint32_t* d_tiled, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_dense || !d_tiled || G < 1 || N < 1) return fail(h, SCOARY_ERR_ARG, "scoary_pack_dense: bad argument");
+  DeviceGuard guard(h->device);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_pack_dense");
+  hipLaunchKernelGGL(k_pack_dense, dim3((unsigned)(Gp / 256), (unsigned)(Qp * 4)), dim3(256), 0, s,
+                     d_dense, G, N, Gp, Qp, d_tiled);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_tile_rows(scoary_handle h, const uint64_t* d_rows64, int64_t G, int64_t N,
+                     uint32_t* d_tiled, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_rows64 || !d_tiled || G < 1 || N < 1) return fail(h, SCOARY_ERR_ARG, "scoary_tile_rows: bad argument");
+  DeviceGuard guard(h->device);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+  const int64_t W32 = 2 * ((N + 63) / 64);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_tile_rows");
+  hipLaunchKernelGGL(k_tile_rows, dim3((unsigned)(Gp / 256), (unsigned)Qp), dim3(256), 0, s,
+                     reinterpret_cast<const uint32_t*>(d_rows64), G, W32, Gp,
+                     reinterpret_cast<uint4*>(d_tiled));
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_counts(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_traits,
+                  const uint32_t* d_masks, int64_t G, int64_t T, int64_t N, int32_t* d_counts,
+                  int32_t* d_margins, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_traits || !d_masks || !d_counts || !d_margins || G < 1 || T < 1 || N < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_counts: bad argument");
+  if (G > (int64_t)1 << 30 || T > 65535 * 8) return fail(h, SCOARY_ERR_SIZE, "scoary_counts: G or T too large");
+  DeviceGuard guard(h->device);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    KernelTimer kt(h, s, "k_margins");
+    hipLaunchKernelGGL(k_margins, dim3((unsigned)T), dim3(kWave), 0, s, d_traits, d_masks,
+                       (int)(Qp * 4), d_margins);
+  }
+  constexpr int TB = 4;
+  {
+    KernelTimer kt(h, s, "k_counts");
+    hipLaunchKernelGGL((k_counts<TB>), dim3((unsigned)(Gp / 256), (unsigned)((T + TB - 1) / TB)),
+                       dim3(256), 0, s, reinterpret_cast<const uint4*>(d_tiled), d_traits, d_masks,
+                       d_margins, (int)G, (int)Gp, (int)Qp, (int)T, reinterpret_cast<int4*>(d_counts));
+  }
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_fisher(scoary_handle h, const int32_t* d_tables, int64_t M, double* d_p, double* d_or,
+                  uint32_t* d_crit, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tables || !d_p || !d_or || M < 1) return fail(h, SCOARY_ERR_ARG, "scoary_fisher: bad argument");
+  if ((M + kWave - 1) / kWave > 0x7fffffffLL) return fail(h, SCOARY_ERR_SIZE, "scoary_fisher: M too large");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_fisher");
+  hipLaunchKernelGGL(k_fisher, dim3((unsigned)((M + kWave - 1) / kWave)), dim3(kWave), 0, s,
+                     reinterpret_cast<const int4*>(d_tables), M, d_p, d_or,
+                     reinterpret_cast<uint2*>(d_crit));
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_perm_generate(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
+                         int64_t T, int64_t N, int64_t P, int64_t perm_base, uint64_t seed,
+                         uint32_t* d_perms, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_masks || !d_margins || !d_perms || T < 1 || N < 1 || P < 1 || perm_base < 0)
+    return fail(h, SCOARY_ERR_ARG, "scoary_perm_generate: bad argument");
+  if (T > 65535 || perm_base + P > 0xffffffffLL)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate: T > 65535 or permutation index >= 2^32");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_perm_generate");
+  hipLaunchKernelGGL(k_perm_generate, dim3((unsigned)((P + kWave - 1) / kWave), (unsigned)T),
+                     dim3(kWave), 0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P,
+                     perm_base, (uint32_t)seed, (uint32_t)(seed >> 32), d_perms);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_permute(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_perms,
+                   const uint32_t* d_crit, int64_t G, int64_t T, int64_t N, int64_t P,
+                   uint32_t* d_r, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_perms || !d_crit || !d_r || G < 1 || T < 1 || N < 1 || P < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_permute: bad argument");
+  if (T > 65535 || G > (int64_t)1 << 30) return fail(h, SCOARY_ERR_SIZE, "scoary_permute: T > 65535 or G > 2^30");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+
+  // Enough independent wave-tasks to fill 256 CUs x 4 SIMDs several times
+  // over: split the permutation range when there are few gene-waves.
+  const int GL = 1;
+  const int64_t gene_waves = Gp / (kWave * GL);
+  const int64_t want_tasks = (int64_t)h->num_cu * 4 * 32;
+  int64_t nch = (want_tasks + gene_waves * T - 1) / (gene_waves * T);
+  const int64_t max_ch = (P + 63) / 64;  // keep >= 64 permutations per task
+  if (nch > max_ch) nch = max_ch;
+  if (nch < 1) nch = 1;
+  if (nch > 65535) nch = 65535;
+  const int pchunk = (int)((P + nch - 1) / nch);
+  nch = (P + pchunk - 1) / pchunk;
+  dim3 grid((unsigned)gene_waves, (unsigned)nch, (unsigned)T);
+
+  if (Qp <= kMaxRegQuads) {
+    KernelTimer kt(h, s, "k_permute");
+    switch (Qp) {
+#define CASE_RQ(RQ)                                                                          \
+  case RQ:                                                                                   \
+    launch_permute_reg<RQ, 1>(grid, s, d_tiled, d_perms, d_crit, (int)G, (int)Gp, P, pchunk, d_r); \
+    break;
+      CASE_RQ(1) CASE_RQ(2) CASE_RQ(4) CASE_RQ(6) CASE_RQ(8) CASE_RQ(12) CASE_RQ(16) CASE_RQ(20)
+      CASE_RQ(24) CASE_RQ(32) CASE_RQ(40) CASE_RQ(48)
+#undef CASE_RQ
+      default:
+        return fail(h, SCOARY_ERR_SIZE, "scoary_permute: unsupported tiled row size");
+    }
+  } else {
+    KernelTimer kt(h, s, "k_permute");
+    hipLaunchKernelGGL((k_permute_chunked<kChunkQuads, 8>), grid, dim3(kWave), 0, s,
+                       reinterpret_cast<const uint4*>(d_tiled), d_perms,
+                       reinterpret_cast<const uint2*>(d_crit), (int)G, (int)Gp, (int)Qp, P, pchunk,
+                       d_r);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_set_timing(scoary_handle h, int enabled) {
+  if (!h) return SCOARY_ERR_ARG;
+  for (auto& t : h->timed) {
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  h->timed.clear();
+  h->timing = enabled != 0;
+  return SCOARY_OK;
+}
+
+int scoary_last_kernel_ms(scoary_handle h, const char* kernel, double* ms_out) {
+  if (!h || !kernel || !ms_out) return SCOARY_ERR_ARG;
+  DeviceGuard guard(h->device);
+  double total = 0.0;
+  int n = 0;
+  for (auto& t : h->timed) {
+    if (t.name != kernel) continue;
+    HIP_TRY(h, hipEventSynchronize(t.stop));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, t.start, t.stop));
+    total += ms;
+    ++n;
+  }
+  if (n == 0) return fail(h, SCOARY_ERR_ARG, std::string("no timed launches of ") + kernel);
+  *ms_out = total / n;
+  return SCOARY_OK;
+}
+
+}  // extern "C"

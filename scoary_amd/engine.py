@@ -1,0 +1,219 @@
+"""Device-side association engine: thin Python over the C-ABI.
+
+PyTorch-ROCm is used for device memory and streams only; every computation of
+the hot path happens in libscoary_hip.so (scoary_amd/csrc/scoary_hip.hip).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _abi
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def pack_bits_rows(dense01):
+    """Host helper (spec S1): (R, N) 0/1 array -> (R, W64) uint64 rows, bit i
+    of word w = column 64*w+i.  Pure numpy; this is input preparation, the
+    same bit-packing the CSV reader produces."""
+    dense01 = np.ascontiguousarray(dense01, dtype=np.uint8)
+    R, N = dense01.shape
+    W = (N + 63) // 64
+    by = np.packbits(dense01, axis=1, bitorder="little")
+    out = np.zeros((R, W * 8), dtype=np.uint8)
+    out[:, :by.shape[1]] = by
+    return out.view("<u8")
+
+
+class GeneMatrix:
+    """The bit-packed gene presence/absence matrix resident in HBM (tiled)."""
+
+    def __init__(self, tiled, G, N):
+        self.tiled = tiled      # torch.int32 [Qp, Gp, 4]
+        self.G = int(G)
+        self.N = int(N)
+
+
+class AssociationEngine:
+    def __init__(self, device=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _abi.ScoaryHipError(
+                "no GPU visible: scoary_amd runs on MI355X (gfx950) only and has no CPU path")
+        self.lib = _abi.load()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", int(device) if not isinstance(device, torch.device)
+                                   else device.index or 0)
+        h = ctypes.c_void_p()
+        rc = self.lib.scoary_create(self.device.index, ctypes.byref(h))
+        if rc != 0:
+            raise _abi.ScoaryHipError("scoary_create(device=%d) failed: %d" % (self.device.index, rc))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.scoary_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing -----------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.scoary_last_error(self.h)
+            raise _abi.ScoaryHipError("%s failed (%d): %s" % (what, rc, (msg or b"").decode()))
+
+    @staticmethod
+    def _ptr(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def quads(self, N):
+        return int(self.lib.scoary_tiled_quads(int(N)))
+
+    def row_words(self, N):
+        return int(self.lib.scoary_row_words(int(N)))
+
+    def padded_genes(self, G):
+        return int(self.lib.scoary_tiled_genes(int(G)))
+
+    def _empty(self, shape, dtype):
+        return _torch().empty(shape, dtype=dtype, device=self.device)
+
+    # -- a1: packing ----------------------------------------------------------
+    def pack_dense(self, dense):
+        """dense: (G, N) uint8 (numpy or device tensor), non-zero = present."""
+        torch = _torch()
+        if isinstance(dense, np.ndarray):
+            dense = torch.from_numpy(np.ascontiguousarray(dense, dtype=np.uint8))
+        dense = dense.to(self.device, dtype=torch.uint8).contiguous()
+        G, N = dense.shape
+        tiled = self._empty((self.quads(N), self.padded_genes(G), 4), torch.int32)
+        self._check(self.lib.scoary_pack_dense(self.h, self._ptr(dense), G, N, self._ptr(tiled),
+                                               self._stream()), "scoary_pack_dense")
+        return GeneMatrix(tiled, G, N)
+
+    def tile_rows(self, rows64, N):
+        """rows64: (G, W64) uint64 bit rows (numpy or int64 device tensor)."""
+        torch = _torch()
+        if isinstance(rows64, np.ndarray):
+            rows64 = torch.from_numpy(np.ascontiguousarray(rows64).view(np.int64))
+        rows64 = rows64.to(self.device).contiguous()
+        G, W = rows64.shape
+        if W != (N + 63) // 64:
+            raise ValueError("rows64 has %d words per row, N=%d needs %d" % (W, N, (N + 63) // 64))
+        tiled = self._empty((self.quads(N), self.padded_genes(G), 4), torch.int32)
+        self._check(self.lib.scoary_tile_rows(self.h, self._ptr(rows64), G, N, self._ptr(tiled),
+                                              self._stream()), "scoary_tile_rows")
+        return GeneMatrix(tiled, G, N)
+
+    def vecrows(self, rows64, N):
+        """(R, W64) uint64 host rows -> device vecrows int32 [R, Wp] (zero padded)."""
+        torch = _torch()
+        rows64 = np.ascontiguousarray(rows64, dtype=np.uint64)
+        R, W = rows64.shape
+        Wp = self.row_words(N)
+        buf = np.zeros((R, Wp), dtype=np.uint32)
+        buf[:, :2 * W] = rows64.view(np.uint32).reshape(R, 2 * W)
+        return torch.from_numpy(buf.view(np.int32)).to(self.device)
+
+    # -- a3: counts -----------------------------------------------------------
+    def counts(self, genes, traits, masks):
+        torch = _torch()
+        T = traits.shape[0]
+        counts = self._empty((T, genes.G, 4), torch.int32)
+        margins = self._empty((T, 2), torch.int32)
+        self._check(self.lib.scoary_counts(self.h, self._ptr(genes.tiled), self._ptr(traits),
+                                           self._ptr(masks), genes.G, T, genes.N,
+                                           self._ptr(counts), self._ptr(margins), self._stream()),
+                    "scoary_counts")
+        return counts, margins
+
+    # -- a5: Fisher -----------------------------------------------------------
+    def fisher(self, tables, want_crit=True):
+        """tables: int32 device tensor [..., 4] -> (p, odds, crit) shaped [...]."""
+        torch = _torch()
+        tables = tables.contiguous()
+        shape = tables.shape[:-1]
+        M = int(np.prod(shape)) if len(shape) else 1
+        p = self._empty(shape, torch.float64)
+        odds = self._empty(shape, torch.float64)
+        crit = self._empty(tuple(shape) + (2,), torch.int32) if want_crit else None
+        self._check(self.lib.scoary_fisher(self.h, self._ptr(tables), M, self._ptr(p),
+                                           self._ptr(odds),
+                                           self._ptr(crit) if want_crit else None,
+                                           self._stream()), "scoary_fisher")
+        return p, odds, crit
+
+    # -- a8 / a7: permutations -------------------------------------------------
+    def perm_generate(self, masks, margins, N, P, perm_base, seed, out=None):
+        torch = _torch()
+        T = masks.shape[0]
+        Wp = self.row_words(N)
+        if out is None:
+            out = self._empty((T, P, Wp), torch.int32)
+        self._check(self.lib.scoary_perm_generate(self.h, self._ptr(masks), self._ptr(margins), T,
+                                                  N, P, perm_base, ctypes.c_uint64(seed),
+                                                  self._ptr(out), self._stream()),
+                    "scoary_perm_generate")
+        return out
+
+    def permute(self, genes, perms, crit, r):
+        T, P = perms.shape[0], perms.shape[1]
+        self._check(self.lib.scoary_permute(self.h, self._ptr(genes.tiled), self._ptr(perms),
+                                            self._ptr(crit), genes.G, T, genes.N, P,
+                                            self._ptr(r), self._stream()), "scoary_permute")
+        return r
+
+    def perm_batch(self, T, N, P, budget_bytes=8 << 30):
+        """Permutations per generate/permute round so the label buffer stays
+        under budget_bytes."""
+        per = T * self.row_words(N) * 4
+        return int(max(1, min(P, budget_bytes // max(per, 1))))
+
+    # -- the whole hot path ----------------------------------------------------
+    def associate(self, genes, traits, masks, permutations=0, seed=0, perm_buffer=None):
+        """counts -> Fisher -> (optional) permutation exceedance counts.
+        Returns dict of device tensors: counts [T,G,4], margins [T,2],
+        p / odds [T,G], r [T,G] (uint32 bit pattern in int32) or None."""
+        torch = _torch()
+        counts, margins = self.counts(genes, traits, masks)
+        p, odds, crit = self.fisher(counts, want_crit=permutations > 0)
+        r = None
+        if permutations > 0:
+            T = traits.shape[0]
+            r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
+            if perm_buffer is not None:
+                batch = perm_buffer.shape[1]
+            else:
+                batch = self.perm_batch(T, genes.N, permutations)
+            done = 0
+            while done < permutations:
+                nb = min(batch, permutations - done)
+                buf = None
+                if perm_buffer is not None:
+                    buf = perm_buffer[:, :nb] if nb == batch else None
+                perms = self.perm_generate(masks, margins, genes.N, nb, done, seed, out=buf)
+                self.permute(genes, perms, crit, r)
+                done += nb
+        return {"counts": counts, "margins": margins, "p": p, "odds": odds, "crit": crit, "r": r}
+
+    # -- timing (bench.py) ------------------------------------------------------
+    def set_timing(self, on):
+        self._check(self.lib.scoary_set_timing(self.h, 1 if on else 0), "scoary_set_timing")
+
+    def kernel_ms(self, name):
+        ms = ctypes.c_double()
+        self._check(self.lib.scoary_last_kernel_ms(self.h, name.encode(), ctypes.byref(ms)),
+                    "scoary_last_kernel_ms")
+        return ms.value
