@@ -48,6 +48,29 @@ def parse():
     return ap.parse_args()
 
 
+def load_traffic(config, default_sizes):
+    """HBM bytes per k_permute launch from the committed PMC summary
+    (profiles/r*_pmc.json, produced by tools/profile.sh + tools/rocpd_summary.py
+    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command).  None when no summary matches the workload being run."""
+    import glob
+    if not default_sizes:
+        return None, None
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("_meta", {}).get("workload") != config:
+            continue
+        for k, v in d.items():
+            if k.startswith("k_permute") and "hbm_traffic_bytes_per_launch" in v:
+                best = (v["hbm_traffic_bytes_per_launch"], os.path.relpath(path, ROOT))
+    return best if best else (None, None)
+
+
 def cpu_baseline(genes, traits, N, seed, target_s):
     """Time the CPU oracle (the C restatement, OpenMP over genes) on a bounded
     sample of the same workload: all T traits, a gene subsample, P_s
@@ -161,6 +184,8 @@ def main():
         tests_per_launch = G * T * min(P, pbatch)
         alg_bytes = 16.0 * W64 * tests_per_launch        # 16*W bytes / test
         achieved = alg_bytes / (k3_ms * 1e-3) / 1e9
+        traffic, traffic_src = load_traffic(
+            args.config, args.genes is None and args.permutations is None)
         w32 = -(-N // 32)
         valu_ops = tests_per_launch * (2.0 * w32 + 6)
         out = {
@@ -188,7 +213,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": alg_bytes,
                 "model": "operand bytes 16*ceil(N/64) B per test (SURVEY 8d); frac > 1 means the "
                          "kernel left the HBM-bound regime (operands reused from VGPR/SGPR)",
                 "kernel_ms": k3_ms,

@@ -254,7 +254,7 @@ void orc_permute_r(const uint64_t *genes, const uint64_t *traits,
                    const uint64_t *masks, int64_t G, int64_t T, int64_t N,
                    int64_t P, uint64_t seed, int64_t perm_base, uint32_t *r_out)
 {
-    enum { PB = 64 };
+    enum { PB = 256 };
     int64_t W = (N + 63) / 64;
     uint64_t *labs = (uint64_t *)malloc((size_t)(PB * W) * sizeof(uint64_t));
     memset(r_out, 0, (size_t)(G * T) * sizeof(uint32_t));
@@ -288,6 +288,9 @@ void orc_permute_r(const uint64_t *genes, const uint64_t *traits,
         }
         for (int64_t p0 = 0; p0 < P; p0 += PB) {
             int64_t nb = P - p0 < PB ? P - p0 : PB;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
             for (int64_t j = 0; j < nb; ++j)
                 orc_perm_labels(seed, (uint32_t)t, (uint32_t)(perm_base + p0 + j),
                                 mr, npos, N, labs + j * W);

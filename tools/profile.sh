@@ -1,0 +1,18 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats of bench.py and
+# the HBM-traffic PMC passes (separate runs, as MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE and WRITE_SIZE cannot share a pass; never combined with sys-trace).
+# Outputs land in gpurun_out/prof_<tag>/ ; copy the summaries into profiles/.
+#   tools/profile.sh <tag> [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- $BENCH --steps 5 --warmup 2 > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- $BENCH --steps 2 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o write -- $BENCH --steps 2 --warmup 1 > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d "$OUT/pmc_sq" -o sq -- $BENCH --steps 2 --warmup 1 > "$OUT/pmc_sq.log" 2>&1
+find "$OUT" -type f | head -50
