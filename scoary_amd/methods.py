@@ -1,0 +1,917 @@
+"""Host-side mirror of the reference's interface for the association path.
+
+Same entry points, argument meaning and result shapes as scoary/methods.py of
+AdmiralenOla/Scoary v1.6.16 -- but array-based inside, with every count,
+Fisher test and permutation evaluated by the HIP library (scoary_amd.engine):
+
+  Csv_to_dic_Roary   scoary/methods.py:335-508   gene presence/absence reader
+  Csv_to_dic         scoary/methods.py:546-614   traits reader
+  Perform_statistics scoary/methods.py:930-982   one (gene, trait) 2x2 table
+  Setup_results      scoary/methods.py:757-928   counts + Fisher + B/BH per trait
+  Permute            scoary/methods.py:1314-1369 empirical p (Fisher statistic,
+                                                 SURVEY D1 / DESIGN.md)
+  StoreResults / StoreTraitResult  :987-1197     per-trait results CSV
+  ScoaryArgumentParser / main      :1551-1744, :49-330   the CLI
+
+There is no CPU fallback: without the GPU library these functions raise.
+"""
+import argparse
+import csv
+import logging
+import os
+import sys
+import time as _time
+from collections.abc import Mapping
+
+import numpy as np
+
+from . import SCOARY_COMPAT_VERSION, __version__
+from .engine import AssociationEngine, pack_bits_rows
+
+log = logging.getLogger("scoary_amd")
+log.setLevel(logging.DEBUG)
+
+ABSENT_CELLS = ("", "0", "-")                     # methods.py:476
+MISSING_TRAIT = ("NA", "-", ".", " ", "")         # methods.py:592
+ALLOWED_TRAIT = ("0", "1") + MISSING_TRAIT        # methods.py:576
+ROARY_HEAD = ["Gene", "Non-unique Gene name", "Annotation"]
+ROARY_COLS = set(ROARY_HEAD + [
+    "No. isolates", "No. sequences", "Avg sequences per isolate", "Genome Fragment",
+    "Order within Fragment", "Accessory Fragment", "Accessory Order with Fragment", "QC",
+    "Min group size nuc", "Max group size nuc", "Avg group size nuc",
+    "Order within fragment", "Genome fragment", "Accessory fragment"])
+
+DEFAULT_SEED = 0x5C0A27
+
+
+# ---------------------------------------------------------------------------
+# Input containers
+# ---------------------------------------------------------------------------
+class GeneTable(Mapping):
+    """The reference's ``genedic`` (gene id -> {strain: 0/1, "Non-unique Gene
+    name", "Annotation", "<col>_name"}) held as arrays: ordered ids, metadata
+    columns and bit-packed presence rows (rows64, spec S1).  Behaves as a
+    read-only mapping with the reference's shape, so code written against
+    ``genedic[gene][strain]`` keeps working."""
+
+    def __init__(self, ids, nugn, annotation, strains, rows64, extra=None):
+        self.ids = list(ids)
+        self.nugn = list(nugn)
+        self.annotation = list(annotation)
+        self.strains = list(strains)
+        self.rows64 = np.ascontiguousarray(rows64, dtype=np.uint64)
+        self.extra = extra or {}                 # "<col>_name" -> list per gene
+        self._index = {g: i for i, g in enumerate(self.ids)}
+        self._device = None                      # (engine, GeneMatrix) cache
+
+    @classmethod
+    def from_genedic(cls, genedic, strains=None):
+        """Pack a plain reference-style dict of dicts."""
+        ids = list(genedic.keys())
+        meta = ("Non-unique Gene name", "Annotation")
+        if strains is None:
+            first = genedic[ids[0]] if ids else {}
+            strains = [k for k in first if k not in meta and not str(k).endswith("_name")]
+        dense = np.zeros((len(ids), len(strains)), dtype=np.uint8)
+        for i, g in enumerate(ids):
+            row = genedic[g]
+            dense[i] = [1 if row[s] else 0 for s in strains]
+        extra_keys = [k for k in (genedic[ids[0]] if ids else {}) if str(k).endswith("_name")]
+        extra = {k: [genedic[g].get(k, "") for g in ids] for k in extra_keys}
+        return cls(ids, [genedic[g].get(meta[0], "") for g in ids],
+                   [genedic[g].get(meta[1], "") for g in ids], strains,
+                   pack_bits_rows(dense), extra)
+
+    # Mapping interface --------------------------------------------------
+    def __len__(self):
+        return len(self.ids)
+
+    def __iter__(self):
+        return iter(self.ids)
+
+    def __getitem__(self, gene):
+        i = self._index[gene]
+        bits = np.unpackbits(self.rows64[i].view(np.uint8), bitorder="little")
+        row = {"Non-unique Gene name": self.nugn[i], "Annotation": self.annotation[i]}
+        for j, s in enumerate(self.strains):
+            row[s] = int(bits[j])
+        for k, col in self.extra.items():
+            row[k] = col[i]
+        return row
+
+    def index(self, gene):
+        return self._index[gene]
+
+    def dense(self):
+        """(G, N) uint8 presence matrix."""
+        N = len(self.strains)
+        by = self.rows64.view(np.uint8).reshape(len(self.ids), -1)
+        return np.unpackbits(by, axis=1, bitorder="little")[:, :N]
+
+    def on_device(self, engine):
+        if self._device is None or self._device[0] is not engine:
+            self._device = (engine, engine.tile_rows(self.rows64, len(self.strains)))
+        return self._device[1]
+
+
+def _trait_arrays(traitsdic, strains):
+    """traitsdic (trait -> {strain: "0"/"1"}, missing isolates absent) ->
+    names, (T, N) uint8 with 2 = missing.  A strain named in a trait but not in
+    the gene table is the reference's fatal KeyError path (methods.py:974-980)."""
+    names = list(traitsdic.keys())
+    col = {s: j for j, s in enumerate(strains)}
+    arr = np.full((len(names), len(strains)), 2, dtype=np.uint8)
+    for t, name in enumerate(names):
+        for s, v in traitsdic[name].items():
+            if s not in col:
+                log.critical("CRITICAL: Could not find %s in the genes file." % str(s))
+                sys.exit("Make sure strains are named the same in your traits file as in "
+                         "your gene presence/absence file")
+            if v in ("0", "1", 0, 1):
+                arr[t, col[s]] = int(v)
+            elif v in MISSING_TRAIT or v == "NA":
+                arr[t, col[s]] = 2
+            else:
+                sys.exit("There was a problem with comparing your traits and gene "
+                         "presence/absence files: unexpected trait value %r" % (v,))
+    return names, arr
+
+
+class TraitResults(Mapping):
+    """``Results[trait]``: gene -> row dict, array-backed (one numpy column per
+    field, rows materialised on access).  Keys are the testable genes in the
+    reference's insertion order."""
+
+    FIELDS = ("tpgp", "tngp", "tpgn", "tngn", "sens", "spes", "OR", "p_v", "B_p", "BH_p")
+
+    def __init__(self, genes, nugn, annotation, cols, number_of_tests, members=None):
+        self.genes = list(genes)
+        self.nugn = list(nugn)
+        self.annotation = list(annotation)
+        self.cols = cols                         # field -> ndarray
+        self.number_of_tests = number_of_tests
+        self.members = members                   # collapse: row -> list of source gene ids
+        self._index = {g: i for i, g in enumerate(self.genes)}
+
+    def __len__(self):
+        return len(self.genes)
+
+    def __iter__(self):
+        return iter(self.genes)
+
+    def __getitem__(self, gene):
+        i = self._index[gene]
+        row = {"NUGN": self.nugn[i], "Annotation": self.annotation[i]}
+        for k, col in self.cols.items():
+            v = col[i]
+            row[k] = int(v) if k in ("tpgp", "tngp", "tpgn", "tngn") else \
+                (float(v) if k in ("sens", "spes") else v)
+        return row
+
+    def column(self, name):
+        return self.cols[name]
+
+
+class GeneTraitCombinations(Mapping):
+    """``Gene_trait_combinations[trait]``: gene -> {strain: "AB"|"Ab"|"aB"|"ab"}
+    over the trait's valid isolates (methods.py:953-965), computed lazily --
+    only the tree stage of the reference consumes it."""
+
+    def __init__(self, table, genes, members, trait_row):
+        self.table, self.genes, self.members, self.trait_row = table, list(genes), members, trait_row
+        self._index = {g: i for i, g in enumerate(self.genes)}
+
+    def __len__(self):
+        return len(self.genes)
+
+    def __iter__(self):
+        return iter(self.genes)
+
+    def __getitem__(self, gene):
+        i = self._index[gene]
+        src = self.members[i][-1] if self.members is not None else gene
+        gi = self.table.index(src)
+        bits = np.unpackbits(self.table.rows64[gi].view(np.uint8), bitorder="little")
+        out = {}
+        for j, s in enumerate(self.table.strains):
+            t = self.trait_row[j]
+            if t == 2:
+                continue
+            out[s] = ("A" if bits[j] else "a") + ("B" if t == 1 else "b")
+        return out
+
+
+# ---------------------------------------------------------------------------
+# Engine singleton
+# ---------------------------------------------------------------------------
+_ENGINE = None
+
+
+def get_engine():
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = AssociationEngine()
+    return _ENGINE
+
+
+# ---------------------------------------------------------------------------
+# Readers
+# ---------------------------------------------------------------------------
+def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolates=None,
+                     writereducedset=False, time="", outdir="./"):
+    """Read a Roary-style gene presence/absence table (methods.py:335-508).
+
+    Returns the reference's dict: "Roarydic" (a GeneTable), "Zero_ones_matrix"
+    (strain-major 0/1 lists of the variable genes, for tree building),
+    "Strains", "Extracols", "Firstcolnames"."""
+    opened = None
+    if writereducedset:
+        opened = open(ReduceSet(genefile, delimiter, grabcols, startcol, allowed_isolates,
+                                time, outdir), "r", newline=None)
+        genefile = opened
+    reader = csv.reader(genefile, skipinitialspace=True, delimiter=delimiter)
+    header = next(reader)
+    if grabcols == [-999]:
+        grabcols = list(range(3, len(header)))
+    if startcol >= len(header):
+        sys.exit("The startcol (-s) you have specified does not seem to correspond to any "
+                 "column in your gene presence/absence file.")
+    strains = header[startcol:]
+    extracols = [header[c] for c in grabcols]
+    roary = header[0:3] == ROARY_HEAD
+
+    # -s sanity hints (methods.py:382-414): same diagnostics, same conditions
+    if roary and strains[0] in ROARY_COLS:
+        guess = next((startcol + c for c, s in enumerate(strains) if s not in ROARY_COLS), None)
+        log.error("ERROR: Make sure you have set the -s parameter correctly. You are running "
+                  "with -s %s. This correponds to the column %s. If this is not an isolate, "
+                  "Scoary might crash or produce strange results. Scoary thinks you should have "
+                  "run with -s %s instead" % (startcol + 1, strains[0],
+                                              (guess + 1) if guess is not None else "?"))
+    if roary:
+        suspicious = []
+        for name in reversed(header[:startcol]):
+            if name not in ROARY_COLS:
+                suspicious.append(name)
+            else:
+                if suspicious:
+                    log.error("ERROR: Make sure you have set the -s parameter correctly. You "
+                              "are running with -s %s. Scoary thinks you should have used %s. "
+                              "This excludes the following, which Scoary thinks are isolates: %s"
+                              % (startcol + 1, startcol - len(suspicious) + 1,
+                                 ", ".join(suspicious)))
+                break
+
+    keep = [c for c, s in enumerate(strains)
+            if allowed_isolates is None or s in allowed_isolates]
+    kept_strains = [strains[c] for c in keep]
+    if roary:
+        try:
+            genecol, nugcol, anncol = (header.index(h) for h in ROARY_HEAD)
+        except ValueError:
+            genecol, nugcol, anncol = 0, 1, 2
+        firstcolnames = list(ROARY_HEAD)
+    else:
+        genecol, nugcol, anncol = 0, 1, 2
+        firstcolnames = header[0:3]
+
+    index, ids, nugn, ann, rows = {}, [], [], [], []
+    extra = {header[c] + "_name": [] for c in grabcols}
+    for q in reader:
+        try:
+            ident = q[genecol] if roary else "_|_".join((q[genecol], q[nugcol], q[anncol]))
+            present = [q[startcol + c] not in ABSENT_CELLS for c in keep]
+            meta = (q[nugcol], q[anncol])
+        except IndexError:
+            sys.exit("CRITICAL: Could not read gene presence absence file. Verify that this "
+                     "file is a proper Roary file using the specified delimiter (default is ',').")
+        # a repeated identifier replaces the earlier row but keeps its position
+        # (dict overwrite in the reference)
+        if ident in index:
+            i = index[ident]
+            nugn[i], ann[i], rows[i] = meta[0], meta[1], present
+            for c in grabcols:
+                extra[header[c] + "_name"][i] = q[c]
+        else:
+            index[ident] = len(ids)
+            ids.append(ident)
+            nugn.append(meta[0])
+            ann.append(meta[1])
+            rows.append(present)
+            for c in grabcols:
+                extra[header[c] + "_name"].append(q[c])
+    if opened is not None:
+        opened.close()
+    dense = np.array(rows, dtype=np.uint8).reshape(len(ids), len(keep))
+    table = GeneTable(ids, nugn, ann, kept_strains, pack_bits_rows(dense), extra)
+    tot = dense.sum(axis=1)
+    variable = (tot > 0) & (tot < dense.shape[1])
+    zero_ones = dense[variable].T.tolist() if len(keep) else []
+    return {"Roarydic": table, "Zero_ones_matrix": zero_ones, "Strains": kept_strains,
+            "Extracols": extracols, "Firstcolnames": firstcolnames}
+
+
+def ReduceSet(genefile, delimiter, grabcols, startcol=14, allowed_isolates=None, time="",
+              outdir="./"):
+    """-r/-w: write the column subset of the table (methods.py:510-544)."""
+    reader = csv.reader(genefile, skipinitialspace=True, delimiter=delimiter)
+    header = next(reader)
+    cols = list(range(startcol)) + [c for c in range(len(header)) if header[c] in allowed_isolates]
+    log.info("Writing gene presence absence file for the reduced set of isolates")
+    name = "%sgene_presence_absence_reduced%s.csv" % (outdir, time)
+    with open(name, "w") as out:
+        w = csv.writer(out, delimiter=delimiter)
+        w.writerow([header[c] for c in cols])
+        for r in reader:
+            w.writerow([r[c] for c in cols])
+    log.info("Finished writing reduced gene presence absence list to file %s" % name)
+    return name
+
+
+def Csv_to_dic(csvfile, delimiter, allowed_isolates, strains):
+    """Read the traits table (methods.py:546-614): returns (traitsdic, Prunedic);
+    isolates with a missing value are dropped from that trait only."""
+    cols = list(zip(*csv.reader(csvfile, delimiter=delimiter)))
+    if len(cols) < 2:
+        sys.exit("Please check that your traits file is formatted properly and contains at "
+                 "least one trait")
+    traitsdic, prunedic = {}, {}
+    for tcol in cols[1:]:
+        p = dict(zip(cols[0], tcol))
+        if "" in p:
+            name = p.pop("")
+        elif "Name" in p:
+            name = p.pop("Name")
+        else:
+            sys.exit("Make sure the top-left cell in the traits file is either empty or "
+                     "'Name'. Do not include empty rows")
+        if allowed_isolates is not None:
+            p = {s: v for s, v in p.items() if s in allowed_isolates}
+        if not all(v in ALLOWED_TRAIT for v in p.values()):
+            sys.exit("Unrecognized character found in trait file. Allowed values (no "
+                     "commas): %s" % ",".join(["0", "1", "NA", ".", "-", " ", ""]))
+        missing = [s for s, v in p.items() if v in MISSING_TRAIT]
+        if missing:
+            log.warning("WARNING: Some isolates have missing values for trait %s. "
+                        "Missing-value isolates will not be counted in association analysis "
+                        "towards this trait." % str(name))
+        kept = {s: v for s, v in p.items() if v not in MISSING_TRAIT} if missing else p
+        prune = list(missing)
+        if not all(s in p for s in strains):
+            log.error("ERROR: Some isolates in your gene presence absence file were not "
+                      "represented in your traits file. These will count as MISSING data and "
+                      "will not be included.")
+            prune += [s for s in strains if s not in p and s not in prune]
+        traitsdic[name] = kept
+        prunedic[name] = prune + [None]
+    return traitsdic, prunedic
+
+
+# ---------------------------------------------------------------------------
+# Statistics
+# ---------------------------------------------------------------------------
+def _as_table(genedic):
+    return genedic if isinstance(genedic, GeneTable) else GeneTable.from_genedic(genedic)
+
+
+def Perform_statistics(traits, genes):
+    """One (gene, trait) table (methods.py:930-982): ``traits`` {strain: "0"/"1"},
+    ``genes`` {strain: 0/1, ...}.  Counted on the GPU through the same kernel as
+    the batched path."""
+    strains = list(traits.keys())
+    for s in strains:
+        if s not in genes:
+            log.critical("CRITICAL: Could not find %s in the genes file." % str(s))
+            sys.exit("Make sure strains are named the same in your traits file as in your "
+                     "gene presence/absence file")
+    g = np.array([[1 if genes[s] else 0 for s in strains]], dtype=np.uint8)
+    t = np.array([[2 if traits[s] in ("NA", "-", ".") else int(traits[s]) for s in strains]],
+                 dtype=np.uint8)
+    eng = get_engine()
+    N = len(strains)
+    counts, _ = eng.counts(eng.pack_dense(g), eng.vecrows(pack_bits_rows(t == 1), N),
+                           eng.vecrows(pack_bits_rows(t != 2), N))
+    tpgp, tpgn, tngp, tngn = (int(x) for x in counts.cpu().numpy()[0, 0])
+    gene_trait = {}
+    for j, s in enumerate(strains):
+        gene_trait[s] = "NA" if t[0, j] == 2 else \
+            ("A" if g[0, j] else "a") + ("B" if t[0, j] == 1 else "b")
+    pattern = "".join(str(int(x)) for x in g[0])
+    return {"statistics": {"tpgp": tpgp, "tpgn": tpgn, "tngp": tngp, "tngn": tngn},
+            "hash": int(pattern, 2) if pattern else 0, "gene_trait": gene_trait}
+
+
+def bonferroni_bh(p_sorted_input, number_of_tests):
+    """Bonferroni and step-up Benjamini-Hochberg exactly as methods.py:903-925.
+
+    ``p_sorted_input``: p-values in insertion order.  The reference sorts
+    stably, keeps the least significant p as is, and walks towards the most
+    significant with  bh = last if tie else min(last, p*ntests/rank), where
+    tie = exact equality with the next sorted p.  Vectorised without changing
+    a single floating-point operation: inside a run of equal p only the run's
+    last (highest-rank) element evaluates min(); every other member copies it.
+    So: reversed cumulative minimum over the run ends, broadcast to the runs."""
+    p = np.asarray(p_sorted_input, dtype=np.float64)
+    n = p.shape[0]
+    if n == 0:
+        # the reference raises IndexError at methods.py:914 here
+        raise IndexError("no testable genes for this trait")
+    order = np.argsort(p, kind="stable")
+    sp = p[order]
+    v = sp * number_of_tests / (np.arange(n, dtype=np.float64) + 1.0)
+    v[n - 1] = sp[n - 1]
+    is_end = np.ones(n, dtype=bool)
+    is_end[:-1] = sp[:-1] != sp[1:]
+    ends = np.nonzero(is_end)[0]
+    bh_ends = np.minimum.accumulate(v[ends][::-1])[::-1]
+    run = np.cumsum(is_end) - is_end
+    bh = np.empty(n, dtype=np.float64)
+    bh[order] = bh_ends[run]
+    return np.minimum(p * number_of_tests, 1.0), np.minimum(bh, 1.0)
+
+
+def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED):
+    eng = get_engine()
+    N = len(table.strains)
+    trv = eng.vecrows(pack_bits_rows(tarr == 1), N)
+    mkv = eng.vecrows(pack_bits_rows(tarr != 2), N)
+    res = eng.associate(table.on_device(eng), trv, mkv, permutations=permutations, seed=seed)
+    out = {k: res[k].cpu().numpy() for k in ("counts", "p", "odds")}
+    out["r"] = res["r"].cpu().numpy().view(np.uint32) if res["r"] is not None else None
+    return out
+
+
+def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEED):
+    """Counts, Fisher's exact test and B/BH correction for every trait x gene
+    (methods.py:757-928).  ``permutations`` >= 10 additionally attaches the
+    Fisher-statistic ``Empirical_p`` (= (r+1)/(P+1), methods.py:1365) to every
+    row -- the north_star's replacement for the tree-statistic Permute loop."""
+    table = _as_table(genedic)
+    names, tarr = _trait_arrays(traitsdic, table.strains)
+    dev = _associate(table, tarr, permutations if permutations >= 10 else 0, seed)
+    all_traits, combos = {}, {}
+    G = len(table)
+    for t, trait in enumerate(names):
+        log.info("Gene-wise counting and Fisher's exact tests for trait: %s" % str(trait))
+        c = dev["counts"][t]                                   # tpgp, tpgn, tngp, tngn
+        testable = ((c[:, 0] + c[:, 2]) != 0) & ((c[:, 1] + c[:, 3]) != 0)
+        number_of_tests = G - int((~testable).sum())
+        idx = np.nonzero(testable)[0]
+        p_all, or_all = dev["p"][t], dev["odds"][t]
+        emp = None
+        if dev["r"] is not None:
+            emp = (dev["r"][t].astype(np.float64) + 1.0) / (permutations + 1.0)
+
+        if not collapse:
+            rows_idx, members, names_out = idx, None, [table.ids[i] for i in idx]
+            nugn = [table.nugn[i] for i in idx]
+            ann = [table.annotation[i] for i in idx]
+            plist = p_all[idx]
+            bh_rank_p = plist
+        else:
+            # identical presence pattern over the trait's valid isolates => one
+            # merged unit (methods.py:816-840); the merged unit moves to the end
+            # of the insertion order and keeps the LAST member's statistics.
+            maskrow = pack_bits_rows((tarr[t:t + 1] != 2))[0]
+            keyed = (table.rows64 & maskrow[None, :])
+            units, by_hash, appended = {}, {}, []          # name -> (members), hash -> name
+            for i in idx:
+                h = keyed[i].tobytes()
+                g = table.ids[i]
+                if h in by_hash:
+                    old = by_hash[h]
+                    new = old + "--" + g
+                    units[new] = units.pop(old) + [i]
+                    by_hash[h] = new
+                    number_of_tests -= 1
+                    appended.append((new, p_all[i]))
+                else:
+                    by_hash[h] = g
+                    units[g] = [i]
+                    appended.append((g, p_all[i]))
+            names_out = list(units.keys())
+            members_idx = [units[k] for k in names_out]
+            rows_idx = np.array([m[-1] for m in members_idx], dtype=np.int64)
+            members = [[table.ids[i] for i in m] for m in members_idx]
+            nugn = ["--".join(table.nugn[i] for i in m) for m in members_idx]
+            ann = ["--".join(table.annotation[i] for i in m) for m in members_idx]
+            plist = p_all[rows_idx]
+            # the reference's p_value_list keeps the superseded names
+            # (methods.py:873/892), so BH ranks count them
+            bh_rank_p = np.array([p for _, p in appended], dtype=np.float64)
+            bh_names = [n for n, _ in appended]
+
+        cc = c[rows_idx]
+        num_pos = (cc[:, 0] + cc[:, 1]).astype(np.float64)
+        num_neg = (cc[:, 2] + cc[:, 3]).astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sens = np.where(num_pos > 0, cc[:, 0].astype(np.float64) / num_pos * 100, 0.0)
+            spes = np.where(num_neg > 0, cc[:, 3].astype(np.float64) / num_neg * 100, 0.0)
+        if len(names_out) == 0:
+            raise IndexError("Trait %s has no testable genes" % trait)
+        if not collapse:
+            B, BH = bonferroni_bh(plist, number_of_tests)
+        else:
+            _, bh_all = bonferroni_bh(bh_rank_p, number_of_tests)
+            last = {}
+            for k, n in enumerate(bh_names):
+                last[n] = bh_all[k]              # later entries overwrite (dict semantics)
+            BH = np.array([last[n] for n in names_out], dtype=np.float64)
+            B = np.minimum(plist * number_of_tests, 1.0)
+        cols = {"tpgp": cc[:, 0], "tngp": cc[:, 2], "tpgn": cc[:, 1], "tngn": cc[:, 3],
+                "sens": sens, "spes": spes, "OR": or_all[rows_idx], "p_v": plist,
+                "B_p": B, "BH_p": BH}
+        if emp is not None:
+            cols["Empirical_p"] = emp[rows_idx]
+        all_traits[trait] = TraitResults(names_out, nugn, ann, cols, number_of_tests, members)
+        combos[trait] = GeneTraitCombinations(table, names_out, members, tarr[t])
+    return {"Results": all_traits, "Gene_trait_combinations": combos}
+
+
+def Permute(tree, GTC, permutations, cutoffs, seed=DEFAULT_SEED):
+    """Empirical p of ONE gene by label permutation (methods.py:1314-1369),
+    with the Fisher statistic: the fraction (r+1)/(P+1) of label
+    shuffles whose 2x2 table is as or more extreme than the observed one.
+    ``tree`` is accepted for signature compatibility and ignored; ``GTC`` is
+    the gene's {strain: "AB"|"Ab"|"aB"|"ab"} map."""
+    if permutations < 10:
+        sys.stdout.write("Number of permutations too few. The absolute minimum is 10.")
+        return None
+    strains = list(GTC.keys())
+    g = np.array([[1 if GTC[s][0] == "A" else 0 for s in strains]], dtype=np.uint8)
+    t = np.array([[1 if GTC[s][-1] == "B" else 0 for s in strains]], dtype=np.uint8)
+    table = GeneTable(["gene"], [""], [""], strains, pack_bits_rows(g))
+    dev = _associate(table, t, permutations, seed)
+    return (float(dev["r"][0, 0]) + 1.0) / (permutations + 1.0)
+
+
+# ---------------------------------------------------------------------------
+# Output
+# ---------------------------------------------------------------------------
+def _fmt(x):
+    """str() of the reference's cells: ints as decimals, floats as Python's
+    shortest round-trip repr."""
+    if isinstance(x, (int, np.integer)):
+        return str(int(x))
+    return repr(float(x))
+
+
+def SortResultsAndSetKey(genedic, key="p_v"):
+    """{rank: gene} ascending by ``key``, stable (methods.py:1448-1454)."""
+    if isinstance(genedic, TraitResults):
+        order = np.argsort(np.asarray(genedic.column(key), dtype=np.float64), kind="stable")
+        return {i: genedic.genes[j] for i, j in enumerate(order)}
+    return {i: g for i, g in enumerate(sorted(genedic, key=lambda x: genedic[x][key]))}
+
+
+CUT_FIELD = {"I": "p_v", "B": "B_p", "BH": "BH_p", "PW": "Plowest", "EPW": "Pboth",
+             "P": "Empirical_p"}
+
+
+def StoreResults(Results, max_hits, cutoffs, upgmatree, GTC, Prunedic, outdir, permutations,
+                 num_threads, no_pairwise, genedic, extracolstoprint, firstcolnames, time="",
+                 delimiter=","):
+    for Trait in Results:
+        sys.stdout.write("\n")
+        log.info("Storing results: " + Trait)
+        StoreTraitResult(Results[Trait], Trait, max_hits, cutoffs, upgmatree, GTC, Prunedic,
+                         outdir, permutations, num_threads, no_pairwise, genedic,
+                         extracolstoprint, firstcolnames, time, delimiter)
+
+
+def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Prunedic, outdir,
+                     permutations, num_threads, no_pairwise, genedic, extracolstoprint,
+                     firstcolnames, time="", delimiter=","):
+    """Write ``<outdir><Trait><time>.results.csv`` (methods.py:1003-1197):
+    header, rows sorted by naive p (stable), every active cutoff applied, every
+    cell double-quoted."""
+    if not no_pairwise:
+        sys.exit("Pairwise comparisons (the tree-based population-structure stage, "
+                 "scoary/methods.py:1208-1312) are not part of this build yet; run with "
+                 "--no_pairwise.")
+    permutations = int(permutations)
+    fname = outdir + Traitname + time + ".results.csv"
+    columns = list(firstcolnames) + [
+        "Number_pos_present_in", "Number_neg_present_in", "Number_pos_not_present_in",
+        "Number_neg_not_present_in", "Sensitivity", "Specificity", "Odds_ratio", "Naive_p",
+        "Bonferroni_p", "Benjamini_H_p"]
+    with_emp = permutations >= 10
+    if with_emp:
+        columns.append("Empirical_p")
+    columns += list(extracolstoprint)
+    table = _as_table(genedic) if extracolstoprint else None
+
+    n = len(Trait)
+    num_results = n if max_hits is None else min(max_hits, n)
+    if isinstance(Trait, TraitResults):
+        order = np.argsort(np.asarray(Trait.column("p_v"), dtype=np.float64), kind="stable")
+        order = order[:num_results]
+        keep = np.ones(order.shape[0], dtype=bool)
+        for method, cut in cutoffs.items():
+            keep &= np.asarray(Trait.column(CUT_FIELD[method]))[order] <= cut
+        rows = order[keep]
+        get = lambda k: Trait.column(k)          # noqa: E731
+        names, nugn, ann = Trait.genes, Trait.nugn, Trait.annotation
+        members = Trait.members
+    else:                                        # plain dict of row dicts
+        names = list(Trait.keys())
+        order = sorted(range(n), key=lambda i: Trait[names[i]]["p_v"])[:num_results]
+        rows = [i for i in order
+                if all(Trait[names[i]][CUT_FIELD[m]] <= c for m, c in cutoffs.items())]
+        cache = {}
+
+        def get(k):
+            if k not in cache:
+                cache[k] = [Trait[g][k] for g in names]
+            return cache[k]
+        nugn, ann, members = get("NUGN"), get("Annotation"), None
+
+    log.info("Skipping population structure-aware analyses." if not with_emp else
+             "Performing %s label permutations per gene on the GPU (Fisher statistic)"
+             % permutations)
+    log.info("Storing results to file")
+    fields = ["tpgp", "tngp", "tpgn", "tngn", "sens", "spes", "OR", "p_v", "B_p", "BH_p"]
+    if with_emp:
+        fields.append("Empirical_p")
+    data = [get(k) for k in fields]
+    with open(fname, "w") as out:
+        out.write(delimiter.join('"' + c + '"' for c in columns) + "\n")
+        for i in rows:
+            gene = names[i]
+            if "_|_" in gene:
+                cells = gene.split("_|_")
+            else:
+                cells = [gene, str(nugn[i]), str(ann[i])]
+            cells += [_fmt(col[i]) for col in data]
+            for colname in extracolstoprint:
+                key = colname + "_name"
+                if "--" in gene:
+                    parts = members[i] if members is not None else gene.split("--")
+                    cells.append("--".join(str(table.extra[key][table.index(g)]) for g in parts))
+                else:
+                    cells.append(str(table.extra[key][table.index(gene)]))
+            out.write(delimiter.join('"' + c + '"' for c in cells) + "\n")
+    return fname
+
+
+def filtrationoptions(cutoffs, collapse):
+    long_names = {"I": "Individual (Naive)", "B": "Bonferroni", "BH": "Benjamini-Hochberg",
+                  "PW": "Pairwise comparison (Best)", "EPW": "Pairwise comparison (Entire range)",
+                  "P": "Empirical p-value (permutation-based)"}
+    lines = ["-- Filtration options --"]
+    lines += ["%s:    %s" % (long_names[k], v) for k, v in cutoffs.items()]
+    lines.append("Collapse genes:    %s\n\n" % collapse)
+    return lines
+
+
+# ---------------------------------------------------------------------------
+# CLI
+# ---------------------------------------------------------------------------
+def grabcoltype(string):
+    """--include_input_columns: "4,6,8,16-23" / "ALL" -> 0-based column list
+    (methods.py:1510-1549; ranges are half-open there, kept as is)."""
+    if string == "ALL":
+        return [-999]
+    if string == "":
+        return []
+    cols = []
+    for part in string.split(","):
+        try:
+            if "-" in part:
+                a, b = part.split("-")
+                if not int(b) > int(a):
+                    raise ValueError(part)
+                cols += list(range(int(a), int(b)))
+            else:
+                cols.append(int(part))
+        except (ValueError, TypeError):
+            sys.exit("Could not understand --include_input_columns argument %s" % part)
+    cols = [c - 1 for c in cols if c - 1 not in (0, 1, 2)]
+    if not all(c > 1 for c in cols):
+        sys.exit("Could not understand --include_input_columns argument. Make sure all "
+                 "numbers are positive and real.")
+    return list(set(cols))
+
+
+def ScoaryArgumentParser(argv=None):
+    """Same flags, dests, types and defaults as methods.py:1551-1744, plus
+    --seed for reproducible permutations."""
+    ap = argparse.ArgumentParser(
+        description="scoary_amd %s - MI355X-native pan-genome association "
+                    "(Scoary %s compatible command line)" % (__version__, SCOARY_COMPAT_VERSION))
+    g = ap.add_argument_group("Input options")
+    g.add_argument("-t", "--traits", help="Trait table (csv): strains in rows, traits in "
+                   "columns, 1 = trait present, 0 = absent, NA/./- = missing")
+    g.add_argument("-g", "--genes", help="Gene presence/absence table (csv, Roary format); "
+                   "strain names must match the trait table")
+    g.add_argument("-n", "--newicktree", default=None,
+                   help="Custom Newick tree for the pairwise-comparison stage")
+    g.add_argument("-s", "--start_col", type=int, default=15,
+                   help="1-based column where isolates start in the gene table (default 15)")
+    g.add_argument("--delimiter", type=str, default=",",
+                   help="Single-character cell delimiter of input and output files")
+    g.add_argument("-r", "--restrict_to", help="File with a comma-separated list of isolates "
+                   "to restrict the analysis to")
+    o = ap.add_argument_group("Output options")
+    o.add_argument("-o", "--outdir", default="./", help="Output directory (default .)")
+    o.add_argument("-u", "--upgma_tree", action="store_true", default=False,
+                   help="Write the calculated UPGMA tree to a newick file")
+    o.add_argument("-p", "--p_value_cutoff", nargs="+", type=float, default=[0.05],
+                   help="P-value cut-off(s): one for all correction methods or one per "
+                   "method in -c order (default 0.05; 1.0 reports every gene)")
+    o.add_argument("-c", "--correction", nargs="*", default=["I"],
+                   choices=["I", "B", "BH", "PW", "EPW", "P"],
+                   help="Filtration measures: I naive, B Bonferroni, BH Benjamini-Hochberg, "
+                   "PW best pairwise, EPW entire pairwise range, P empirical (permutation)")
+    o.add_argument("-m", "--max_hits", type=int, help="Report at most this many hits per trait")
+    o.add_argument("--include_input_columns", dest="grabcols", type=grabcoltype, default=[],
+                   help="Columns of the gene table to copy to the output, e.g. 4,6,8,16-23 or ALL")
+    o.add_argument("-w", "--write_reduced", action="store_true", default=False,
+                   help="With -r: also write the reduced gene presence/absence table")
+    o.add_argument("--no-time", dest="no_time", action="store_true", default=False,
+                   help="No timestamp in output file names")
+    a = ap.add_argument_group("Analysis options")
+    a.add_argument("-e", "--permute", type=int, default=0,
+                   help="Number of trait-label permutations per gene for empirical p-values "
+                   "(0 = off, minimum 10)")
+    a.add_argument("--no_pairwise", action="store_true", default=False,
+                   help="Population-structure-naive analysis only (Fisher's test, odds ratios)")
+    a.add_argument("--collapse", action="store_true", default=False,
+                   help="Merge genes with identical distribution patterns into one unit")
+    a.add_argument("--seed", type=int, default=DEFAULT_SEED,
+                   help="Seed of the counter-based permutation generator (scoary_amd extension)")
+    m = ap.add_argument_group("Misc options")
+    m.add_argument("--threads", type=int, default=1,
+                   help="Accepted for compatibility; the GPU path does not use host threads")
+    m.add_argument("--test", action="store_true", default=False,
+                   help="Run on the bundled example data (needs the path in SCOARY_EXAMPLEDATA)")
+    m.add_argument("--citation", action="store_true", default=False,
+                   help="Show citation information and exit")
+    m.add_argument("--version", action="version", version=SCOARY_COMPAT_VERSION)
+    args = ap.parse_args(argv)
+    if len(args.p_value_cutoff) == 1:
+        cutoffs = {c: args.p_value_cutoff[0] for c in args.correction}
+    else:
+        cutoffs = dict(zip(args.correction, args.p_value_cutoff))
+    return args, cutoffs
+
+
+CITATION = ("If you use Scoary, please cite: Brynildsrud O, Bohlin J, Scheffer L, Eldholm V. "
+            "Rapid scoring of genes in microbial pan-genome-wide association studies with "
+            "Scoary. Genome Biol. 2016;17:238.  (scoary_amd re-implements Scoary's Fisher / "
+            "permutation path for AMD MI355X.)")
+
+
+def main(**kwargs):
+    """The command-line flow of methods.py:49-330 for the association path."""
+    if len(kwargs) == 0:
+        args, cutoffs = ScoaryArgumentParser()
+    else:
+        args, cutoffs = kwargs["args"], kwargs["cutoffs"]
+        if "statusbar" in kwargs:
+            sys.stdout = kwargs["statusbar"]
+    if args.citation:
+        sys.exit(CITATION)
+    if args.test:
+        ex = os.environ.get("SCOARY_EXAMPLEDATA")
+        if not ex:
+            sys.exit("--test needs SCOARY_EXAMPLEDATA=<dir with Gene_presence_absence.csv and "
+                     "Tetracycline_resistance.csv>")
+        args.correction, args.delimiter, args.grabcols = ["I", "EPW"], ",", []
+        args.genes = os.path.join(ex, "Gene_presence_absence.csv")
+        args.traits = os.path.join(ex, "Tetracycline_resistance.csv")
+        args.max_hits = args.newicktree = args.restrict_to = None
+        args.no_pairwise, args.outdir, args.permute = False, "./", 0
+        args.p_value_cutoff, args.start_col, args.threads = [0.05, 0.05], 15, 4
+        args.upgma_tree, args.write_reduced, args.no_time, args.collapse = True, False, False, False
+        cutoffs = {"I": 0.05, "EPW": 0.05}
+
+    start = _time.time()
+    stamp = "" if args.no_time else _time.strftime("_%d_%m_%Y_%H%M")
+    if not args.outdir.endswith("/"):
+        args.outdir += "/"
+    os.makedirs(args.outdir, exist_ok=True)
+    console = logging.StreamHandler(sys.stdout)
+    console.setFormatter(logging.Formatter("%(message)s"))
+    console.setLevel(logging.INFO)
+    logfile = logging.FileHandler(os.path.join(args.outdir, "scoary%s.log" % stamp), mode="w")
+    logfile.setFormatter(logging.Formatter("%(asctime)s    %(message)s", "%m/%d/%Y %I:%M:%S %p"))
+    log.addHandler(console)
+    log.addHandler(logfile)
+    counts = _LevelCounter()
+    log.addHandler(counts)
+    log.info("==== Scoary started ====")
+    log.info("Command: " + " ".join(sys.argv))
+    try:
+        _validate(args, cutoffs)
+        seed = getattr(args, "seed", DEFAULT_SEED)
+        allowed = None
+        if args.restrict_to is not None:
+            with open(args.restrict_to, "r") as f:
+                allowed = {iso: "all" for line in f for iso in line.rstrip().split(",")}
+        elif args.write_reduced:
+            sys.exit("You cannot use the -w argument without specifying a subset (-r)")
+        with open(args.genes, "r", newline=None) as genes, \
+                open(args.traits, "r", newline=None) as traits:
+            log.info("Reading gene presence absence file")
+            grab = [-999] if args.grabcols == "ALL" else args.grabcols
+            gd = Csv_to_dic_Roary(genes, args.delimiter, grab, startcol=int(args.start_col) - 1,
+                                  allowed_isolates=allowed, writereducedset=args.write_reduced,
+                                  time=stamp, outdir=args.outdir)
+            genedic, strains = gd["Roarydic"], gd["Strains"]
+            if not args.no_pairwise:
+                sys.exit("Pairwise comparisons (UPGMA tree + the tree-based population-"
+                         "structure stage, scoary/methods.py:619-707 and :1208-1312) are not "
+                         "part of this build yet; run with --no_pairwise.")
+            log.info("Ignoring relatedness among input sample and performing only population "
+                     "structure-naive analysis.")
+            log.info("Reading traits file")
+            traitsdic, prunedic = Csv_to_dic(traits, args.delimiter, allowed, strains)
+        log.info("Finished loading files into memory.\n\n")
+        log.info("==== Performing statistics ====")
+        for line in filtrationoptions(cutoffs, args.collapse):
+            log.info(line)
+        log.info("Tallying genes and performing statistical analyses")
+        res = Setup_results(genedic, traitsdic, args.collapse, permutations=args.permute,
+                            seed=seed)
+        StoreResults(res["Results"], args.max_hits, cutoffs, None,
+                     res["Gene_trait_combinations"], prunedic, args.outdir, args.permute,
+                     args.threads, args.no_pairwise, genedic, gd["Extracols"],
+                     gd["Firstcolnames"], time=stamp, delimiter=args.delimiter)
+        log.info("\n")
+        log.info("==== Finished ====")
+        log.info("Checked a total of %d genes for associations to %d trait(s). Total time "
+                 "used: %d seconds." % (len(genedic), len(traitsdic), int(_time.time() - start)))
+    except SystemExit as e:
+        log.exception("CRITICAL:")
+        for hnd in (logfile, console, counts):
+            log.removeHandler(hnd)
+        sys.exit(e.code)
+    if counts.n.get("CRITICAL", 0):
+        log.info("Scoary finished successfully, but with CRITICAL ERRORS. Please check your log file.")
+    elif counts.n.get("ERROR", 0):
+        log.info("Scoary finished successfully, but with ERRORS. Please check your log file.")
+    elif counts.n.get("WARNING", 0):
+        log.info("Scoary finished successfully, but with WARNINGS. Please check your log file.")
+    else:
+        log.info("No warnings were recorded.")
+    for hnd in (logfile, console, counts):
+        log.removeHandler(hnd)
+    logfile.close()
+    sys.exit(0)
+
+
+class _LevelCounter(logging.Handler):
+    def __init__(self):
+        super().__init__(logging.WARNING)
+        self.n = {}
+
+    def emit(self, record):
+        self.n[record.levelname] = self.n.get(record.levelname, 0) + 1
+
+
+def _validate(args, cutoffs):
+    """Argument checks of methods.py:126-181 (same conditions, same exits)."""
+    if args.traits is None or args.genes is None:
+        sys.exit("The following arguments are required: -t/--traits, -g/--genes")
+    if args.threads <= 0:
+        sys.exit("Number of threads must be positive")
+    if not os.path.isfile(args.traits):
+        sys.exit("Could not find the traits file: %s" % args.traits)
+    if not os.path.isfile(args.genes):
+        sys.exit("Could not find the gene presence absence file: %s" % args.genes)
+    if args.newicktree is not None and not os.path.isfile(args.newicktree):
+        sys.exit("Could not find the custom tree file: %s" % args.newicktree)
+    if not all(0.0 < p <= 1.0 for p in args.p_value_cutoff):
+        sys.exit("P must be between 0.0 and 1.0 or exactly 1.0")
+    if len(args.delimiter) > 1:
+        sys.exit("Delimiter must be a single character string. There is no support for tab.")
+    if len(args.p_value_cutoff) != len(args.correction) and len(args.p_value_cutoff) != 1:
+        sys.exit("You can not use more p-value cutoffs than correction methods. Either provide "
+                 "a single p-value that will be applied to all correction methods, or provide "
+                 "exactly as many as the number of correction methods and in corresponding "
+                 "sequence. e.g. -c I EPW -p 0.1 0.05 will apply an individual p-value cutoff "
+                 "of 0.1 AND a pairwise comparisons p-value cutoff of 0.05.")
+    if "P" in cutoffs and args.permute == 0:
+        sys.exit("Cannot use empirical p-values in filtration without performing "
+                 "permutations. Use '--permute X' where X is a number equal to or larger than 10")
+    if args.permute < 10 and args.permute != 0:
+        sys.exit("The absolute minimum number of permutations is 10 (or 0 to deactivate)")
+    if "P" in cutoffs and cutoffs["P"] < (1.0 / args.permute):
+        sys.exit("Permutation cutoff too low for this number of permutations")
+    if args.permute > 10000:
+        log.info("Note: You have set Scoary to do a high number of permutations. "
+                 "This may take a while.")
+    if args.no_pairwise:
+        # The reference also zeroes --permute here (methods.py:174-181) because
+        # its permutations need the tree.  The Fisher-statistic permutations of
+        # this build do not, so --permute stays active (documented extension).
+        log.info("Performing no pairwise comparisons. Ignoring all tree related options "
+                 "(user tree, population aware-correction).")
+        args.newicktree = None
+        for m in ("PW", "EPW"):
+            cutoffs.pop(m, None)
+
+
+if __name__ == "__main__":
+    main()

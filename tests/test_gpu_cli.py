@@ -1,0 +1,232 @@
+"""Drop-in boundary on the GPU: the scoary command line (-g/-t/-p/-c/--permute/
+--no_pairwise/--collapse/-r/-m/--no-time) and the Setup_results / Permute call
+sites, against files and dictionaries captured from the real reference."""
+import csv
+import gzip
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_text, read_dense
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+
+
+def run_cli(argv, outdir):
+    from scoary_amd import methods as m
+    old = sys.argv
+    sys.argv = ["scoary"] + argv + ["-o", str(outdir), "--no-time"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            m.main()
+        assert e.value.code in (0, None), e.value.code
+    finally:
+        sys.argv = old
+    out = {}
+    for fn in sorted(os.listdir(outdir)):
+        if fn.endswith(".results.csv"):
+            with open(os.path.join(outdir, fn), newline="") as f:
+                out[fn] = f.read()
+    return out
+
+
+def _inputs(exampledir):
+    return ["-g", os.path.join(exampledir, "Gene_presence_absence.csv"),
+            "-t", os.path.join(exampledir, "Tetracycline_resistance.csv")]
+
+
+def _assert_csv_equal(got, want, p_tol=1e-12):
+    """Byte-identical where possible; otherwise identical structure, integer and
+    text cells exact, and float cells within the north_star tolerance (the GPU
+    Fisher p may differ from SciPy's in the last bits)."""
+    if got == want:
+        return "bytes"
+    g = list(csv.reader(io.StringIO(got)))
+    w = list(csv.reader(io.StringIO(want)))
+    assert g[0] == w[0], "header differs"
+    assert len(g) == len(w), "row count differs: %d vs %d" % (len(g), len(w))
+    gi = {r[0]: r for r in g[1:]}
+    for wr in w[1:]:
+        gr = gi[wr[0]]
+        for k, (a, b) in enumerate(zip(gr, wr)):
+            if a == b:
+                continue
+            fa, fb = float(a), float(b)
+            tol = p_tol * (6000 if g[0][k] in ("Bonferroni_p", "Benjamini_H_p") else 1)
+            assert abs(fa - fb) <= tol + 1e-11 * abs(fb), (wr[0], g[0][k], a, b)
+    # row ORDER must agree wherever the sort keys are distinguishable
+    gp = [float(r[g[0].index("Naive_p")]) for r in g[1:]]
+    assert all(gp[i] <= gp[i + 1] * (1 + 1e-9) for i in range(len(gp) - 1))
+    return "tolerance"
+
+
+@pytest.mark.parametrize("sub,extra", [
+    ("csv_no_pairwise", ["-p", "1.0"]),
+    ("csv_no_pairwise_default", []),
+    ("csv_no_pairwise_collapse_bh", ["--collapse", "-c", "I", "BH", "-p", "0.05", "0.01", "-m", "50"]),
+    ("csv_no_pairwise_restrict", ["-r", "RESTRICT"]),
+])
+def test_cli_results_csv_vs_reference(exampledir, tmp_path, sub, extra):
+    extra = [os.path.join(exampledir, "Restrict_to.csv") if x == "RESTRICT" else x for x in extra]
+    files = run_cli(_inputs(exampledir) + ["--no_pairwise"] + extra, tmp_path)
+    assert sorted(files) == ["Bogus_trait.results.csv", "Tetracycline_resistance.results.csv"]
+    modes = []
+    for fn, text in files.items():
+        want = golden_text(os.path.join(sub, fn + ".gz"))
+        modes.append(_assert_csv_equal(text, want))
+    print(sub, modes)
+    # the log file exists and is named as in the reference
+    assert os.path.exists(os.path.join(tmp_path, "scoary.log"))
+
+
+def test_cli_top_hit_is_the_reference_travis_row(exampledir, tmp_path):
+    """tests/test_scoary_output.py:12-14 of the reference, applied to our CSV."""
+    files = run_cli(_inputs(exampledir) + ["--no_pairwise"], tmp_path)
+    rows = list(csv.reader(io.StringIO(files["Tetracycline_resistance.results.csv"])))
+    d = rows[1]
+    assert d[0] == "TetRCG" and d[1] == "" and d[2].startswith("A fictitious gene")
+    assert [int(x) for x in d[3:7]] == [29, 8, 3, 60]
+    assert abs(float(d[7]) - 90.625) < 0.01 and abs(float(d[8]) - 88.2352941176) < 0.01
+    assert abs(float(d[9]) - 72.5) < 0.1
+    assert abs(float(d[10]) - 1.08621066108E-014) < 1e-15
+    assert abs(float(d[11]) - 6.45209132679E-011) < 1e-12
+    assert abs(float(d[12]) - 6.45209132679E-011) < 1e-12
+
+
+def _load(exampledir, allowed=None):
+    from scoary_amd import methods as m
+    with open(os.path.join(exampledir, "Gene_presence_absence.csv")) as f:
+        gd = m.Csv_to_dic_Roary(f, ",", [], startcol=14, allowed_isolates=allowed)
+    with open(os.path.join(exampledir, "Tetracycline_resistance.csv")) as f:
+        td, prune = m.Csv_to_dic(f, ",", allowed, gd["Strains"])
+    return gd, td
+
+
+@pytest.mark.parametrize("fixture,collapse", [("setup_results_exampledata.npz", False),
+                                              ("setup_results_collapse.npz", True)])
+def test_setup_results_vs_reference_dump(exampledir, fixture, collapse):
+    from scoary_amd import methods as m
+    gd, td = _load(exampledir)
+    res = m.Setup_results(gd["Roarydic"], td, collapse)
+    z = np.load(os.path.join(GOLDEN, fixture))
+    assert list(res["Results"]) == json.loads(str(z["traits"]))
+    for t, trait in enumerate(res["Results"]):
+        R = res["Results"][trait]
+        assert list(R) == json.loads(str(z["t%d_genes" % t]))      # names AND order
+        assert R.nugn == json.loads(str(z["t%d_nugn" % t]))
+        assert R.annotation == json.loads(str(z["t%d_annotation" % t]))
+        want = z["t%d_counts" % t]                                  # tpgp,tpgn,tngp,tngn
+        got = np.stack([R.column(k) for k in ("tpgp", "tpgn", "tngp", "tngn")], 1)
+        assert np.array_equal(got, want)
+        assert np.array_equal(R.column("sens"), z["t%d_sens" % t])
+        assert np.array_equal(R.column("spes"), z["t%d_spes" % t])
+        go = z["t%d_OR" % t]
+        fin = np.isfinite(go)
+        assert np.array_equal(R.column("OR")[fin], go[fin])
+        assert np.array_equal(np.isinf(R.column("OR")), np.isinf(go))
+        gp = z["t%d_p_v" % t]
+        assert np.max(np.abs(R.column("p_v") - gp)) < 1e-12
+        assert np.max(np.abs(R.column("B_p") - z["t%d_B_p" % t])) < 1e-12 * R.number_of_tests
+        assert np.max(np.abs(R.column("BH_p") - z["t%d_BH_p" % t])) < 1e-12 * R.number_of_tests
+        # row dict has the reference's keys
+        row = R[list(R)[0]]
+        assert set(row) == {"NUGN", "Annotation", "tpgp", "tngp", "tpgn", "tngn", "sens",
+                            "spes", "OR", "p_v", "B_p", "BH_p"}
+        # Gene_trait_combinations for the genes the fixture sampled
+        gtc = json.loads(str(z["t%d_gtc" % t]))
+        for g, want_map in gtc.items():
+            assert res["Gene_trait_combinations"][trait][g] == want_map
+    if collapse:
+        assert res["Results"]["Tetracycline_resistance"].number_of_tests == 5925
+
+
+def test_setup_results_accepts_reference_style_dicts(exampledir):
+    """The internal call site: plain dict-of-dicts genedic as the reference's
+    reader builds it (methods.py:445-491)."""
+    from scoary_amd import methods as m
+    ids, strains, genes, names, traits = read_dense(
+        golden_text("exampledata/Gene_presence_absence.csv.gz"),
+        golden_text("exampledata/Tetracycline_resistance.csv.gz"))
+    pick = [ids.index("TetRCG")] + list(range(0, len(ids), 90))
+    genedic = {ids[i]: dict({"Non-unique Gene name": "", "Annotation": "x"},
+                            **{s: int(genes[i, j]) for j, s in enumerate(strains)}) for i in pick}
+    traitsdic = {names[0]: {s: str(int(traits[0, j])) for j, s in enumerate(strains)}}
+    res = m.Setup_results(genedic, traitsdic, False)
+    row = res["Results"][names[0]]["TetRCG"]
+    assert (row["tpgp"], row["tngp"], row["tpgn"], row["tngn"]) == (29, 8, 3, 60)
+    assert abs(row["p_v"] - 1.0862106610751687e-14) < 1e-15
+
+
+def test_perform_statistics_call_site(exampledir):
+    from scoary_amd import methods as m
+    gd, td = _load(exampledir)
+    st = m.Perform_statistics(td["Tetracycline_resistance"], gd["Roarydic"]["TetRCG"])
+    assert st["statistics"] == {"tpgp": 29, "tpgn": 3, "tngp": 8, "tngn": 60}
+    assert sorted(set(st["gene_trait"].values())) == ["AB", "Ab", "aB", "ab"]
+    assert len(st["gene_trait"]) == 100
+
+
+def test_cli_permute_fisher_empirical_p(exampledir, tmp_path):
+    """--permute with --no_pairwise (documented extension): the
+    Empirical_p column follows Benjamini_H_p and equals (r+1)/(P+1) with r from
+    the oracle on the same (seed, trait, permutation) counters."""
+    from oracle import oracle as orc
+    from scoary_amd.engine import pack_bits_rows
+    P, seed = 200, 1234
+    files = run_cli(_inputs(exampledir) + ["--no_pairwise", "-e", str(P), "--seed", str(seed),
+                                           "-c", "I", "P", "-p", "0.05", "1.0"], tmp_path)
+    ids, strains, genes, names, traits = read_dense(
+        golden_text("exampledata/Gene_presence_absence.csv.gz"),
+        golden_text("exampledata/Tetracycline_resistance.csv.gz"))
+    gb = orc.pack_rows(genes)
+    tb = pack_bits_rows((traits == 1).astype(np.uint8))
+    mb = pack_bits_rows((traits != 2).astype(np.uint8))
+    r = orc.permute_r(gb, tb, mb, len(strains), P, seed)
+    for t, trait in enumerate(names):
+        rows = list(csv.reader(io.StringIO(files[trait + ".results.csv"])))
+        assert rows[0][12] == "Benjamini_H_p" and rows[0][13] == "Empirical_p"
+        assert len(rows) > 10
+        for d in rows[1:]:
+            want = (float(r[ids.index(d[0]), t]) + 1.0) / (P + 1.0)
+            assert d[13] == repr(want), (trait, d[0], d[13], want)
+
+
+def test_permute_call_site_matches_oracle(exampledir):
+    from oracle import oracle as orc
+    from scoary_amd import methods as m
+    from scoary_amd.engine import pack_bits_rows
+    gd, td = _load(exampledir)
+    res = m.Setup_results(gd["Roarydic"], td, False)
+    gtc = res["Gene_trait_combinations"]["Bogus_trait"]["gene_8004"]
+    assert len(gtc) == 97                                  # missing isolates are not in GTC
+    emp = m.Permute(tree=None, GTC=gtc, permutations=150, cutoffs={"I": 0.05}, seed=9)
+    strains = list(gtc)
+    g = np.array([[1 if gtc[s][0] == "A" else 0 for s in strains]], dtype=np.uint8)
+    t = np.array([[1 if gtc[s][1] == "B" else 0 for s in strains]], dtype=np.uint8)
+    r = orc.permute_r(orc.pack_rows(g), pack_bits_rows(t), pack_bits_rows(np.ones_like(t)),
+                      len(strains), 150, 9)
+    assert emp == (float(r[0, 0]) + 1.0) / 151.0
+    assert m.Permute(None, gtc, 5, {}) is None
+
+
+def test_pairwise_mode_fails_loudly(exampledir, tmp_path):
+    from scoary_amd import methods as m
+    old = sys.argv
+    sys.argv = ["scoary"] + _inputs(exampledir) + ["-o", str(tmp_path), "--no-time"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            m.main()
+        assert "no_pairwise" in str(e.value.code)
+    finally:
+        sys.argv = old

@@ -1,0 +1,216 @@
+"""CPU-side tests: host logic of the path (readers, B/BH, argument parser, CSV
+formatting) and the shape of the C-ABI -- no GPU compute here."""
+import ctypes
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden_text, read_dense
+
+
+# ---------------------------------------------------------------- C-ABI ------
+def _header_functions():
+    with open(os.path.join(ROOT, "include", "scoary_hip.h")) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scoary_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """The C-ABI library loads without a GPU and exports exactly what
+    include/scoary_hip.h declares; the ctypes binding covers all of it."""
+    from scoary_amd import _abi
+    if not os.path.exists(_abi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    declared = _header_functions()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), "library does not export " + name
+    assert sorted(_abi.SIGNATURES) == declared
+    lib.scoary_abi_version.restype = ctypes.c_int
+    assert lib.scoary_abi_version() == _abi.ABI_VERSION
+
+
+def test_abi_layout_arithmetic():
+    from scoary_amd import _abi
+    lib = _abi.load()
+    for N, quads in [(1, 1), (32, 1), (128, 1), (129, 2), (500, 4), (2000, 16), (2048, 16),
+                     (2049, 20), (5000, 40), (6144, 48), (6145, 56), (10000, 80)]:
+        assert lib.scoary_tiled_quads(N) == quads, N
+        assert lib.scoary_row_words(N) == 4 * quads
+        assert 4 * quads * 32 >= N
+    for G, gp in [(1, 256), (256, 256), (257, 512), (50000, 50176)]:
+        assert lib.scoary_tiled_genes(G) == gp
+    assert lib.scoary_tiled_bytes(50000, 2000) == 16 * 16 * 50176
+
+
+def test_no_gpu_means_loud_failure():
+    """The product path never falls back to the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from scoary_amd import _abi
+    from scoary_amd.engine import AssociationEngine
+    with pytest.raises(_abi.ScoaryHipError):
+        AssociationEngine()
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "scoary_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+                assert "liboracle" not in src and "orc_" not in src, fn
+                assert not re.search(r"#include\s+[\"<][^\n]*oracle", src), fn
+
+
+# -------------------------------------------------------------- readers ------
+def test_gpa_reader_matches_reference_shapes(exampledir, manifest):
+    from scoary_amd import methods as m
+    with open(os.path.join(exampledir, "Gene_presence_absence.csv")) as f:
+        gd = m.Csv_to_dic_Roary(f, ",", [], startcol=14)
+    assert gd["Strains"] == manifest["strains"]
+    assert gd["Firstcolnames"] == ["Gene", "Non-unique Gene name", "Annotation"]
+    table = gd["Roarydic"]
+    z = np.load(os.path.join(GOLDEN, "setup_results_exampledata.npz"))
+    assert list(table) == json.loads(str(z["all_genes"]))
+    ids, strains, genes, names, traits = read_dense(
+        golden_text("exampledata/Gene_presence_absence.csv.gz"),
+        golden_text("exampledata/Tetracycline_resistance.csv.gz"))
+    assert np.array_equal(table.dense(), genes)
+    # mapping view has the reference's genedic shape
+    row = table["TetRCG"]
+    assert row["Annotation"].startswith("A fictitious gene") and row["Isolate_1"] in (0, 1)
+    assert sum(row[s] for s in strains) == int(genes[ids.index("TetRCG")].sum())
+    # Zero_ones_matrix: strain-major, variable genes only (methods.py:496-502)
+    zm = np.array(gd["Zero_ones_matrix"])
+    tot = genes.sum(1)
+    assert zm.shape == (len(strains), int(((tot > 0) & (tot < len(strains))).sum()))
+
+
+def test_traits_reader_missing_values_and_prunedic(exampledir, manifest):
+    from scoary_amd import methods as m
+    with open(os.path.join(exampledir, "Tetracycline_resistance.csv")) as f:
+        td, prune = m.Csv_to_dic(f, ",", None, manifest["strains"])
+    assert list(td) == ["Tetracycline_resistance", "Bogus_trait"]
+    assert len(td["Tetracycline_resistance"]) == 100 and len(td["Bogus_trait"]) == 97
+    for k, v in manifest["prune"].items():
+        assert prune[k] == v + [None]
+    assert set(td["Bogus_trait"].values()) == {"0", "1"}
+
+
+def test_restrict_to_reader(exampledir, manifest):
+    from scoary_amd import methods as m
+    with open(os.path.join(exampledir, "Restrict_to.csv")) as f:
+        allowed = {iso: "all" for line in f for iso in line.rstrip().split(",")}
+    with open(os.path.join(exampledir, "Gene_presence_absence.csv")) as f:
+        gd = m.Csv_to_dic_Roary(f, ",", [], startcol=14, allowed_isolates=allowed)
+    assert gd["Strains"] == manifest["restrict_strains"]
+
+
+def test_non_roary_reader_vcf(exampledir, manifest):
+    from scoary_amd import methods as m
+    with open(os.path.join(exampledir, "mutations_presence_absence.csv")) as f:
+        gd = m.Csv_to_dic_Roary(f, ",", [], startcol=manifest["vcf_startcol_1based"] - 1)
+    z = np.load(os.path.join(GOLDEN, "setup_results_vcf.npz"))
+    assert list(gd["Roarydic"]) == json.loads(str(z["all_genes"]))   # duplicate ids collapse
+    assert gd["Firstcolnames"] == manifest["vcf_firstcolnames"]
+    assert gd["Strains"] == manifest["vcf_strains"]
+
+
+def test_traits_reader_rejects_bad_input():
+    from scoary_amd import methods as m
+    with pytest.raises(SystemExit):
+        m.Csv_to_dic(io.StringIO(",T\nA,2\nB,0\n"), ",", None, ["A", "B"])
+    with pytest.raises(SystemExit):
+        m.Csv_to_dic(io.StringIO("X,T\nA,1\nB,0\n"), ",", None, ["A", "B"])
+    with pytest.raises(SystemExit):
+        m.Csv_to_dic(io.StringIO("Name\nA\n"), ",", None, ["A"])
+
+
+# ---------------------------------------------------------------- B / BH -----
+def test_bonferroni_bh_bit_exact_vs_reference():
+    """Vectorised B/BH == the reference's sequential loop, bit for bit, on the
+    reference's own p-values (both traits of exampledata)."""
+    from scoary_amd.methods import bonferroni_bh
+    z = np.load(os.path.join(GOLDEN, "setup_results_exampledata.npz"))
+    for t in range(2):
+        p = z["t%d_p_v" % t]
+        B, BH = bonferroni_bh(p, len(p))
+        assert np.array_equal(B, z["t%d_B_p" % t])
+        assert np.array_equal(BH, z["t%d_BH_p" % t])
+
+
+def test_bonferroni_bh_ties_and_loop_equivalence():
+    from oracle import oracle as orc
+    from scoary_amd.methods import bonferroni_bh
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 17, 400):
+        p = rng.choice(np.concatenate([rng.random(max(1, n // 3)), [1.0, 1e-300, 0.5]]), size=n)
+        for ntests in (n, n + 5, max(1, n - 3)):
+            B, BH = bonferroni_bh(p, ntests)
+            B2, BH2 = orc.bonferroni_bh([float(x) for x in p], ntests)
+            assert np.array_equal(B, np.array(B2)) and np.array_equal(BH, np.array(BH2))
+    with pytest.raises(IndexError):
+        bonferroni_bh([], 0)
+
+
+# ------------------------------------------------------------------- CLI -----
+def test_argument_parser_defaults_and_cutoffs():
+    from scoary_amd.methods import ScoaryArgumentParser
+    args, cut = ScoaryArgumentParser(["-g", "g.csv", "-t", "t.csv"])
+    assert (args.start_col, args.delimiter, args.permute, args.threads) == (15, ",", 0, 1)
+    assert args.no_pairwise is False and args.collapse is False and args.outdir == "./"
+    assert cut == {"I": 0.05}
+    args, cut = ScoaryArgumentParser(["-g", "g", "-t", "t", "-c", "I", "BH", "-p", "0.1", "0.01",
+                                      "-e", "100", "--no_pairwise", "--no-time", "-m", "5"])
+    assert cut == {"I": 0.1, "BH": 0.01} and args.permute == 100 and args.max_hits == 5
+    args, cut = ScoaryArgumentParser(["-g", "g", "-t", "t", "-c", "B", "P", "-p", "0.2"])
+    assert cut == {"B": 0.2, "P": 0.2}
+    with pytest.raises(SystemExit):
+        ScoaryArgumentParser(["-c", "XYZ"])
+
+
+def test_grabcoltype():
+    from scoary_amd.methods import grabcoltype
+    assert grabcoltype("ALL") == [-999] and grabcoltype("") == []
+    assert sorted(grabcoltype("4,6,8,16-19")) == [3, 5, 7, 15, 16, 17]
+    assert sorted(grabcoltype("1,2,3,4")) == [3]
+    with pytest.raises(SystemExit):
+        grabcoltype("9-4")
+
+
+def test_validation_exits(tmp_path):
+    from scoary_amd import methods as m
+    g = tmp_path / "g.csv"; g.write_text("x")
+    t = tmp_path / "t.csv"; t.write_text("x")
+    base = ["-g", str(g), "-t", str(t)]
+    for extra in (["-e", "5"], ["-p", "1.5"], ["--delimiter", ";;"], ["--threads", "0"],
+                  ["-c", "P"], ["-c", "I", "B", "-p", "0.1", "0.2", "0.3"],
+                  ["-c", "P", "-e", "10", "-p", "0.01"]):
+        args, cut = m.ScoaryArgumentParser(base + extra)
+        with pytest.raises(SystemExit):
+            m._validate(args, cut)
+    args, cut = m.ScoaryArgumentParser(["-t", str(t)])
+    with pytest.raises(SystemExit):
+        m._validate(args, cut)
+    args, cut = m.ScoaryArgumentParser(base + ["--no_pairwise", "-c", "I", "EPW", "-e", "50"])
+    m._validate(args, cut)
+    assert "EPW" not in cut and args.permute == 50     # documented extension: permute survives
+
+
+def test_cell_formatting_is_shortest_roundtrip():
+    from scoary_amd.methods import _fmt
+    assert _fmt(np.int32(29)) == "29"
+    assert _fmt(90.625) == "90.625" and _fmt(np.float64(88.23529411764706)) == "88.23529411764706"
+    assert _fmt(np.float64(1.0862106610751687e-14)) == "1.0862106610751687e-14"
+    assert _fmt(float("inf")) == "inf" and _fmt(float("nan")) == "nan" and _fmt(0.0) == "0.0"
+    assert _fmt(np.float64(1.0)) == "1.0"
