@@ -136,19 +136,15 @@ def main():
     mkv = eng.vecrows(pack_bits_rows((traits != 2).astype(np.uint8)), N)
     pbatch = eng.perm_batch(T, N, P)
     perm_buf = torch.empty((T, pbatch, eng.row_words(N)), dtype=torch.int32, device=eng.device)
-    gather_buf = None
-    if world > 1:
-        rec_words = 4 + 2 + 2 + 1            # counts, p, odds, r as int32 words
-        gather_buf = torch.empty((world, T, G, rec_words), dtype=torch.int32, device=eng.device)
+    from scoary_amd import dist as sdist
 
     def step():
         res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, perm_buffer=perm_buf)
         if world > 1:
-            rec = torch.cat([res["counts"],
-                             res["p"].view(torch.int32).view(T, G, 2),
-                             res["odds"].view(torch.int32).view(T, G, 2),
-                             res["r"].view(T, G, 1)], dim=2).contiguous()
-            dist.all_gather_into_tensor(gather_buf, rec)
+            # the path's one exchange step: per-gene records of every shard to
+            # every rank (RCCL all_gather over xGMI), same code as the CLI uses
+            rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
+            res["gathered"] = sdist.all_gather_genes(rec, G * world)
         return res
 
     def barrier():

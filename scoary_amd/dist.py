@@ -1,0 +1,136 @@
+"""Gene sharding across the GPUs of one node (one process per GPU).
+
+Genes are independent units of the path, so the packed matrix is split into
+contiguous row blocks, one per rank; trait, mask and permutation vectors are
+replicated (permutations are regenerated identically on every rank from the
+counter-based seed -- zero traffic).  The path's only exchange step is the
+gather of per-gene result records at the end: one ``all_gather`` over RCCL
+(xGMI) on GPU tensors, or gloo on CPU tensors in the tests.  This replaces the
+reference's stride partition + pickled result weave over a multiprocessing
+Pool (scoary/methods.py:1076-1097, :1115-1122).
+"""
+import os
+
+import numpy as np
+
+REC_WORDS = 9   # int32 words per (trait, gene): 4 counts, p (2), odds (2), r (1)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def shard_bounds(G, world):
+    """Contiguous, balanced [start, stop) per rank; the first G % world ranks
+    get one extra gene."""
+    base, extra = divmod(int(G), int(world))
+    out, start = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+def max_shard(G, world):
+    return -(-int(G) // int(world))
+
+
+def pack_records(counts, p, odds, r):
+    """counts int32 [T,Gs,4], p/odds float64 [T,Gs], r int32 [T,Gs] or None ->
+    int32 [T,Gs,9] (bit patterns preserved)."""
+    torch = _torch()
+    T, Gs = p.shape
+    if r is None:
+        r = torch.zeros((T, Gs), dtype=torch.int32, device=p.device)
+    return torch.cat([counts.reshape(T, Gs, 4),
+                      p.contiguous().view(torch.int32).view(T, Gs, 2),
+                      odds.contiguous().view(torch.int32).view(T, Gs, 2),
+                      r.reshape(T, Gs, 1)], dim=2).contiguous()
+
+
+def unpack_records(rec):
+    torch = _torch()
+    T, G, _ = rec.shape
+    rec = rec.contiguous()
+    return {"counts": rec[:, :, 0:4].contiguous(),
+            "p": rec[:, :, 4:6].contiguous().view(torch.float64).view(T, G),
+            "odds": rec[:, :, 6:8].contiguous().view(torch.float64).view(T, G),
+            "r": rec[:, :, 8].contiguous()}
+
+
+def is_distributed():
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return False
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_rank():
+    if not is_distributed():
+        return 1, 0
+    import torch.distributed as dist
+    return dist.get_world_size(), dist.get_rank()
+
+
+def init_from_env():
+    """Join the process group described by torchrun's environment (RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_*), backend nccl (= RCCL on ROCm).  No-op for
+    a single process.  Returns (world, rank, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch = _torch()
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            if torch.cuda.is_available():
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+    return world, rank, local_rank
+
+
+def all_gather_genes(rec_local, G, group=None):
+    """rec_local: this rank's [T, Gs, W] block (Gs = its shard length) ->
+    the full [T, G, W] on every rank.  Shards are padded to a common length for
+    the collective and trimmed afterwards."""
+    torch = _torch()
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    bounds = shard_bounds(G, world)
+    T, Gs, W = rec_local.shape
+    cap = max_shard(G, world)
+    send = rec_local
+    if Gs != cap:
+        send = torch.zeros((T, cap, W), dtype=rec_local.dtype, device=rec_local.device)
+        send[:, :Gs] = rec_local
+    # concatenated-along-dim-0 output form: accepted by both RCCL and gloo
+    recv = torch.empty((world * T, cap, W), dtype=rec_local.dtype, device=rec_local.device)
+    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    recv = recv.view(world, T, cap, W)
+    parts = [recv[r, :, :b - a] for r, (a, b) in enumerate(bounds)]
+    return torch.cat(parts, dim=1).contiguous()
+
+
+def associate_sharded(local_compute, G, group=None):
+    """Run ``local_compute(start, stop) -> int32 records [T, stop-start, 9]`` on
+    this rank's gene shard and gather the records of all ranks."""
+    world, rank = world_rank()
+    if world == 1:
+        return local_compute(0, G)
+    a, b = shard_bounds(G, world)[rank]
+    return all_gather_genes(local_compute(a, b), G, group)
+
+
+def numpy_records(rec):
+    d = unpack_records(rec)
+    out = {k: v.cpu().numpy() for k, v in d.items()}
+    out["r"] = out["r"].view(np.uint32)
+    return out

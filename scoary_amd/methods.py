@@ -431,13 +431,26 @@ def bonferroni_bh(p_sorted_input, number_of_tests):
 
 
 def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED):
+    """Whole hot path for all traits; under torchrun (world > 1) every rank
+    takes a contiguous gene shard and the per-gene records are all-gathered
+    over RCCL (scoary_amd.dist), so every rank returns the full arrays."""
+    import torch
+    from . import dist
     eng = get_engine()
-    N = len(table.strains)
+    G, N, T = len(table), len(table.strains), tarr.shape[0]
     trv = eng.vecrows(pack_bits_rows(tarr == 1), N)
     mkv = eng.vecrows(pack_bits_rows(tarr != 2), N)
-    res = eng.associate(table.on_device(eng), trv, mkv, permutations=permutations, seed=seed)
-    out = {k: res[k].cpu().numpy() for k in ("counts", "p", "odds")}
-    out["r"] = res["r"].cpu().numpy().view(np.uint32) if res["r"] is not None else None
+
+    def local(a, b):
+        if b <= a:
+            return torch.zeros((T, 0, dist.REC_WORDS), dtype=torch.int32, device=eng.device)
+        gm = table.on_device(eng) if (a, b) == (0, G) else eng.tile_rows(table.rows64[a:b], N)
+        res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed)
+        return dist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
+
+    out = dist.numpy_records(dist.associate_sharded(local, G))
+    if permutations <= 0:
+        out["r"] = None
     return out
 
 
@@ -786,6 +799,8 @@ def main(**kwargs):
         args.upgma_tree, args.write_reduced, args.no_time, args.collapse = True, False, False, False
         cutoffs = {"I": 0.05, "EPW": 0.05}
 
+    from . import dist
+    world, rank, _local = dist.init_from_env()
     start = _time.time()
     stamp = "" if args.no_time else _time.strftime("_%d_%m_%Y_%H%M")
     if not args.outdir.endswith("/"):
@@ -794,7 +809,8 @@ def main(**kwargs):
     console = logging.StreamHandler(sys.stdout)
     console.setFormatter(logging.Formatter("%(message)s"))
     console.setLevel(logging.INFO)
-    logfile = logging.FileHandler(os.path.join(args.outdir, "scoary%s.log" % stamp), mode="w")
+    logfile = logging.FileHandler(os.path.join(
+        args.outdir, "scoary%s%s.log" % (stamp, "" if rank == 0 else ".rank%d" % rank)), mode="w")
     logfile.setFormatter(logging.Formatter("%(asctime)s    %(message)s", "%m/%d/%Y %I:%M:%S %p"))
     log.addHandler(console)
     log.addHandler(logfile)
@@ -834,10 +850,11 @@ def main(**kwargs):
         log.info("Tallying genes and performing statistical analyses")
         res = Setup_results(genedic, traitsdic, args.collapse, permutations=args.permute,
                             seed=seed)
-        StoreResults(res["Results"], args.max_hits, cutoffs, None,
-                     res["Gene_trait_combinations"], prunedic, args.outdir, args.permute,
-                     args.threads, args.no_pairwise, genedic, gd["Extracols"],
-                     gd["Firstcolnames"], time=stamp, delimiter=args.delimiter)
+        if rank == 0:           # every rank holds the gathered results; one writes
+            StoreResults(res["Results"], args.max_hits, cutoffs, None,
+                         res["Gene_trait_combinations"], prunedic, args.outdir, args.permute,
+                         args.threads, args.no_pairwise, genedic, gd["Extracols"],
+                         gd["Firstcolnames"], time=stamp, delimiter=args.delimiter)
         log.info("\n")
         log.info("==== Finished ====")
         log.info("Checked a total of %d genes for associations to %d trait(s). Total time "

@@ -1,0 +1,115 @@
+"""Multi-process path on CPU: world_size 2 (and 3, uneven shards) over gloo.
+Each rank computes its gene shard -- here with the CPU oracle standing in for
+the GPU engine, which is what the rank-local step is on a GPU box -- and the
+per-gene records are all-gathered by scoary_amd.dist exactly as under RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _case():
+    rng = np.random.default_rng(21)
+    G, N, T, P = 203, 90, 3, 40
+    genes = (rng.random((G, N)) < rng.uniform(0.05, 0.95, (G, 1))).astype(np.uint8)
+    traits = (rng.random((T, N)) < 0.45).astype(np.uint8)
+    traits[1, ::11] = 2
+    return genes, traits, N, P, 77
+
+
+def _worker(rank, world, port, outq):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from oracle import oracle as orc
+    from scoary_amd import dist as sd
+    from scoary_amd.engine import pack_bits_rows
+    w, r, _ = sd.init_from_env()            # gloo: no GPU visible here
+    assert (w, r) == (world, rank) and sd.is_distributed()
+    genes, traits, N, P, seed = _case()
+    tb = pack_bits_rows((traits == 1).astype(np.uint8))
+    mb = pack_bits_rows((traits != 2).astype(np.uint8))
+    T = traits.shape[0]
+
+    def local(a, b):
+        if b <= a:
+            return torch.zeros((T, 0, sd.REC_WORDS), dtype=torch.int32)
+        gb = orc.pack_rows(genes[a:b])
+        c = orc.counts_packed(gb, tb, mb).transpose(1, 0, 2).copy()
+        o, p = orc.fisher_many(c.reshape(-1, 4))
+        rr = orc.permute_r(gb, tb, mb, N, P, seed).T.copy()
+        return sd.pack_records(torch.from_numpy(c), torch.from_numpy(p.reshape(T, -1)),
+                               torch.from_numpy(o.reshape(T, -1)),
+                               torch.from_numpy(rr.view(np.int32)))
+
+    rec = sd.associate_sharded(local, genes.shape[0])
+    out = sd.numpy_records(rec)
+    outq.put((rank, out["counts"], out["p"], out["odds"], out["r"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gene_shard_all_gather_gloo(world):
+    from oracle import oracle as orc
+    from scoary_amd.engine import pack_bits_rows
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    genes, traits, N, P, seed = _case()
+    gb = orc.pack_rows(genes)
+    tb = pack_bits_rows((traits == 1).astype(np.uint8))
+    mb = pack_bits_rows((traits != 2).astype(np.uint8))
+    c = orc.counts_packed(gb, tb, mb).transpose(1, 0, 2)
+    o, p = orc.fisher_many(np.ascontiguousarray(c).reshape(-1, 4))
+    r = orc.permute_r(gb, tb, mb, N, P, seed).T
+    for rank, gc, gp, go, gr in got:         # every rank holds the full result
+        assert np.array_equal(gc, c)
+        assert np.array_equal(gp.ravel(), p)
+        np.testing.assert_array_equal(go.ravel(), o)
+        assert np.array_equal(gr, r)
+
+
+def test_shard_bounds_cover_exactly():
+    from scoary_amd.dist import max_shard, shard_bounds
+    for G in (1, 7, 8, 9, 50000, 200000, 1000003):
+        for world in (1, 2, 3, 8):
+            b = shard_bounds(G, world)
+            assert b[0][0] == 0 and b[-1][1] == G and len(b) == world
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [y - x for x, y in b]
+            assert max(sizes) - min(sizes) <= 1 and max(sizes) == max_shard(G, world)
+
+
+def test_record_pack_roundtrip():
+    from scoary_amd import dist as sd
+    rng = np.random.default_rng(0)
+    T, G = 3, 17
+    c = torch.from_numpy(rng.integers(0, 5000, (T, G, 4)).astype(np.int32))
+    p = torch.from_numpy(rng.random((T, G)))
+    o = torch.from_numpy(np.where(rng.random((T, G)) < 0.2, np.inf, rng.random((T, G)) * 50))
+    o[0, 0] = float("nan")
+    r = torch.from_numpy(rng.integers(0, 2**31 - 1, (T, G)).astype(np.int32))
+    d = sd.unpack_records(sd.pack_records(c, p, o, r))
+    assert torch.equal(d["counts"], c) and torch.equal(d["p"], p) and torch.equal(d["r"], r)
+    assert torch.equal(d["odds"].view(torch.int64), o.view(torch.int64))   # bit pattern, nan incl.
