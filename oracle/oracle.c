@@ -345,3 +345,139 @@ void orc_set_num_threads(int n)
     (void)n;
 #endif
 }
+
+/* ------------------------------------------------------------------ S6 -- */
+/* Maximum number of contrasting pairs on a binary tree: restatement of
+ * PhyloTree / Tip (scoary/classes.py:199-592).  State index: 0 = "AB",
+ * 1 = "Ab", 2 = "aB", 3 = "ab", 4 = "0" (no free path).  Every node carries,
+ * per state, (total pairs, supporting pairs, opposing pairs); -1 = the state
+ * cannot be reached.
+ *
+ * The tree is given as a stack program over its tips (children order does not
+ * matter: the candidate list of classes.py:320-405 is symmetric in left/right):
+ *   ops[k] >= 0  : push Tip(tipstate[ops[k]])          (classes.py:575-592)
+ *   ops[k] == -1 : pop right, pop left, push the merged node
+ * out = (max_contrasting_pairs, max_contrasting_propairs,
+ *        max_contrasting_antipairs) of the root (classes.py:246-249: three
+ * independent maxima over the five states). */
+typedef struct { int32_t tot[5], pro[5], anti[5]; } orc_node;
+
+static void tree_merge(const orc_node *L, const orc_node *R, orc_node *out)
+{
+    for (int c = 0; c < 4; ++c) { /* calculate_max_condition, classes.py:268-457 */
+        int ls[9], rs[9], n = 0;
+        ls[n] = c; rs[n++] = 4;
+        for (int o = 0; o < 4; ++o) if (o != c) { ls[n] = c; rs[n++] = o; }
+        ls[n] = c; rs[n++] = c;
+        ls[n] = 4; rs[n++] = c;
+        for (int o = 0; o < 4; ++o) if (o != c) { ls[n] = o; rs[n++] = c; }
+        int32_t tot[9], pro[9], anti[9], best = -1;
+        for (int k = 0; k < 9; ++k) {
+            tot[k] = pro[k] = anti[k] = -1;
+            if (L->tot[ls[k]] > -1 && R->tot[rs[k]] > -1) {
+                tot[k] = L->tot[ls[k]] + R->tot[rs[k]];
+                pro[k] = L->pro[ls[k]] + R->pro[rs[k]];
+                anti[k] = L->anti[ls[k]] + R->anti[rs[k]];
+            }
+            if (tot[k] > best) best = tot[k];
+        }
+        int32_t bp = -1, ba = -1;
+        for (int k = 0; k < 9; ++k)
+            if (tot[k] == best) {
+                if (pro[k] > bp) bp = pro[k];
+                if (anti[k] > ba) ba = anti[k];
+            }
+        out->tot[c] = best; out->pro[c] = bp; out->anti[c] = ba;
+    }
+    { /* calculate_max_nofree, classes.py:459-572 */
+        static const int ls[5] = {4, 0, 3, 1, 2}, rs[5] = {4, 3, 0, 2, 1};
+        static const int dpro[5] = {0, 1, 1, 0, 0}, danti[5] = {0, 0, 0, 1, 1};
+        int32_t tot[5], pro[5], anti[5], best = -1;
+        for (int k = 0; k < 5; ++k) {
+            tot[k] = pro[k] = anti[k] = -1;
+            if (L->tot[ls[k]] > -1 && R->tot[rs[k]] > -1) {
+                tot[k] = L->tot[ls[k]] + R->tot[rs[k]] + (k > 0);
+                pro[k] = L->pro[ls[k]] + R->pro[rs[k]] + dpro[k];
+                anti[k] = L->anti[ls[k]] + R->anti[rs[k]] + danti[k];
+            }
+            if (tot[k] > best) best = tot[k];
+        }
+        int32_t bp = -1, ba = -1;
+        for (int k = 0; k < 5; ++k)
+            if (tot[k] == best) {
+                if (pro[k] > bp) bp = pro[k];
+                if (anti[k] > ba) ba = anti[k];
+            }
+        out->tot[4] = best; out->pro[4] = bp; out->anti[4] = ba;
+    }
+}
+
+int orc_tree_dp(const int32_t *ops, int64_t nops, const uint8_t *tipstate,
+                int32_t out[3])
+{
+    orc_node *st = (orc_node *)malloc((size_t)(nops + 1) * sizeof(orc_node));
+    int64_t sp = 0;
+    for (int64_t k = 0; k < nops; ++k) {
+        if (ops[k] >= 0) {
+            orc_node *t = &st[sp++];
+            for (int c = 0; c < 5; ++c)
+                t->tot[c] = t->pro[c] = t->anti[c] = (c == tipstate[ops[k]]) ? 0 : -1;
+        } else {
+            if (sp < 2) { free(st); return -1; }
+            orc_node m;
+            tree_merge(&st[sp - 2], &st[sp - 1], &m);
+            st[sp - 2] = m;
+            --sp;
+        }
+    }
+    if (sp != 1) { free(st); return -1; }
+    out[0] = out[1] = out[2] = -1;
+    for (int c = 0; c < 5; ++c) {
+        if (st[0].tot[c] > out[0]) out[0] = st[0].tot[c];
+        if (st[0].pro[c] > out[1]) out[1] = st[0].pro[c];
+        if (st[0].anti[c] > out[2]) out[2] = st[0].anti[c];
+    }
+    free(st);
+    return 0;
+}
+
+/* Tree-statistic permutations (Permute, scoary/methods.py:1314-1369) for one
+ * gene: gbits / the trait's label+validity bits are rows64 over isolates;
+ * tips[k] = isolate index of tip k of the (pruned) tree program.  For each
+ * permutation pi (labels by spec S4) writes exceed[pi] = 1 iff
+ * float(New[key])/New["Total"] >= observed estimator, key = Pro if the
+ * observed tree has Pro >= Anti else Anti (methods.py:1333-1355).  A permuted
+ * tree with Total == 0 (ZeroDivisionError in the reference) counts as 0.
+ * out_obs = observed (Total, Pro, Anti). */
+int orc_tree_permute(const int32_t *ops, int64_t nops, const int32_t *tips,
+                     int64_t ntips, const uint64_t *gbits, const uint64_t *tbits,
+                     const uint64_t *mbits, int64_t N, uint32_t t, int64_t P,
+                     uint64_t seed, int32_t out_obs[3], uint8_t *exceed)
+{
+    int64_t W = (N + 63) / 64, npos = 0;
+    for (int64_t w = 0; w < W; ++w) npos += __builtin_popcountll(tbits[w]);
+    uint8_t *ts = (uint8_t *)malloc((size_t)ntips);
+    uint64_t *lab = (uint64_t *)malloc((size_t)W * sizeof(uint64_t));
+#define BIT(a, i) (((a)[(i) >> 6] >> ((i) & 63)) & 1)
+    for (int64_t k = 0; k < ntips; ++k) {
+        int64_t i = tips[k];
+        ts[k] = (uint8_t)((BIT(gbits, i) ? 0 : 2) + (BIT(tbits, i) ? 0 : 1));
+    }
+    if (orc_tree_dp(ops, nops, ts, out_obs)) { free(ts); free(lab); return -1; }
+    int key = out_obs[1] >= out_obs[2] ? 1 : 2;
+    double est = (double)out_obs[key] / (double)out_obs[0];
+    for (int64_t pi = 0; pi < P; ++pi) {
+        orc_perm_labels(seed, t, (uint32_t)pi, mbits, npos, N, lab);
+        for (int64_t k = 0; k < ntips; ++k) {
+            int64_t i = tips[k];
+            ts[k] = (uint8_t)((BIT(gbits, i) ? 0 : 2) + (BIT(lab, i) ? 0 : 1));
+        }
+        int32_t o[3];
+        orc_tree_dp(ops, nops, ts, o);
+        exceed[pi] = (o[0] > 0 && (double)o[key] / (double)o[0] >= est) ? 1 : 0;
+    }
+#undef BIT
+    free(ts);
+    free(lab);
+    return 0;
+}

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,6 +35,7 @@ constexpr uint32_t kPermDomain = 0x53434F41u;  // "SCOA", spec S4
 // entirely in VGPRs by k_permute_reg.
 constexpr int kRegQuads[] = {1, 2, 4, 6, 8, 12, 16, 20, 24, 32, 40, 48};
 constexpr int kMaxRegQuads = 48;
+constexpr int kAutoRegQuads = 24;  // longer rows: the chunked kernel wins (measured 1.39x at N=5000)
 constexpr int kChunkQuads = 8;  // k_permute_chunked: quads per register chunk
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -375,10 +377,12 @@ __global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict_
   const int nchunks = Qp / CQ;
   uint32_t cnt = 0;
   const uint4* pbase = reinterpret_cast<const uint4*>(perms + ((int64_t)t * P + p0) * ((int64_t)Qp * 4));
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
   for (int i0 = 0; i0 < np; i0 += PB) {
     uint32_t acc[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) acc[j] = 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (int c = 0; c < nchunks; ++c) {
       uint4 gw[CQ];
 #pragma unroll
@@ -388,7 +392,13 @@ __global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict_
         const int i = min(i0 + j, np - 1);
         const uint4* pr = pbase + (int64_t)i * Qp + c * CQ;
 #pragma unroll
-        for (int q = 0; q < CQ; ++q) acc[j] += popc4(gw[q], pr[q]);
+        for (int q = 0; q < CQ; ++q) {
+          const uint4 s = pr[q];  // wave-uniform -> s_load
+          bcnt_acc(acc[j], gw[q].x & s.x);
+          bcnt_acc(acc[j], gw[q].y & s.y);
+          bcnt_acc(acc[j], gw[q].z & s.z);
+          bcnt_acc(acc[j], gw[q].w & s.w);
+        }
       }
     }
 #pragma unroll
@@ -625,8 +635,12 @@ int scoary_permute(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_p
   nch = (P + pchunk - 1) / pchunk;
   dim3 grid((unsigned)gene_waves, (unsigned)nch, (unsigned)T);
 
-  if (Qp <= kMaxRegQuads) {
-    KernelTimer kt(h, s, "k_permute");
+  // Tuning knob (experiments only): SCOARY_PERMUTE_VARIANT=reg|c8x8|c8x16|c4x16|c8x4
+  const char* variant = std::getenv("SCOARY_PERMUTE_VARIANT");
+  const bool force_chunk = variant && variant[0] == 'c';
+  const bool use_reg = Qp <= kMaxRegQuads && !force_chunk && (Qp <= kAutoRegQuads || (variant && variant[0] == 'r'));
+  KernelTimer kt(h, s, "k_permute");
+  if (use_reg) {
     switch (Qp) {
 #define CASE_RQ(RQ)                                                                          \
   case RQ:                                                                                   \
@@ -639,11 +653,20 @@ int scoary_permute(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_p
         return fail(h, SCOARY_ERR_SIZE, "scoary_permute: unsupported tiled row size");
     }
   } else {
-    KernelTimer kt(h, s, "k_permute");
-    hipLaunchKernelGGL((k_permute_chunked<kChunkQuads, 8>), grid, dim3(kWave), 0, s,
-                       reinterpret_cast<const uint4*>(d_tiled), d_perms,
-                       reinterpret_cast<const uint2*>(d_crit), (int)G, (int)Gp, (int)Qp, P, pchunk,
-                       d_r);
+    const uint4* t4 = reinterpret_cast<const uint4*>(d_tiled);
+    const uint2* c2 = reinterpret_cast<const uint2*>(d_crit);
+    const std::string v = variant ? variant : "";
+#define LAUNCH_CHUNK(CQ, PB)                                                                  \
+  hipLaunchKernelGGL((k_permute_chunked<CQ, PB>), grid, dim3(kWave), 0, s, t4, d_perms, c2, (int)G, \
+                     (int)Gp, (int)Qp, P, pchunk, d_r)
+    if (v == "c8x16" && Qp % 8 == 0) LAUNCH_CHUNK(8, 16);
+    else if (v == "c4x16" && Qp % 4 == 0) LAUNCH_CHUNK(4, 16);
+    else if (v == "c8x4" && Qp % 8 == 0) LAUNCH_CHUNK(8, 4);
+    else if (Qp % 8 == 0) LAUNCH_CHUNK(8, 8);
+    else if (Qp % 4 == 0) LAUNCH_CHUNK(4, 16);
+    else if (Qp % 2 == 0) LAUNCH_CHUNK(2, 16);
+    else LAUNCH_CHUNK(1, 16);
+#undef LAUNCH_CHUNK
   }
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
