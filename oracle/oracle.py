@@ -216,3 +216,187 @@ def setup_results(genes, trait):
         "BH_p": np.array(BH),
         "number_of_tests": number_of_tests,
     }
+
+
+# ---------------------------------------------------------------------------
+# Population-structure stage: tree restatements
+# ---------------------------------------------------------------------------
+_lib_tree_ready = False
+
+
+def _tree_lib():
+    global _lib_tree_ready
+    L = lib()
+    if not _lib_tree_ready:
+        i64, u64, u32, vp = ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p
+        L.orc_tree_dp.argtypes = [vp, i64, vp, vp]
+        L.orc_tree_dp.restype = ctypes.c_int
+        L.orc_tree_permute.argtypes = [vp, i64, vp, i64, vp, vp, vp, i64, u32, i64, u64, vp, vp]
+        L.orc_tree_permute.restype = ctypes.c_int
+        _lib_tree_ready = True
+    return L
+
+
+def prune_for_missing(tree, prune):
+    """PruneForMissing (methods.py:709-739): drop tips listed in ``prune`` (the
+    list carries a trailing None so a fully pruned subtree, returned as None,
+    is dropped by its parent too); unary nodes collapse into their child."""
+    left, right = tree[0], tree[1]
+    if isinstance(left, list):
+        left = prune_for_missing(left, prune)
+    if isinstance(right, list):
+        right = prune_for_missing(right, prune)
+    if left in prune and right in prune:
+        return None
+    if left in prune:
+        return right
+    if right in prune:
+        return left
+    return [left, right]
+
+
+def tree_program(tree, index_of):
+    """Nested-list tree -> (ops int32, tips int32): post-order stack program,
+    ops[k] >= 0 = push tip number ops[k] (tips[ops[k]] = isolate index),
+    -1 = merge the two top entries."""
+    ops, tips = [], []
+
+    def walk(node):
+        if isinstance(node, (list, tuple)):
+            walk(node[0])
+            walk(node[1])
+            ops.append(-1)
+        else:
+            ops.append(len(tips))
+            tips.append(index_of[node])
+    import sys as _sys
+    old = _sys.getrecursionlimit()
+    _sys.setrecursionlimit(max(old, 100000))
+    try:
+        walk(tree)
+    finally:
+        _sys.setrecursionlimit(old)
+    return np.array(ops, dtype=np.int32), np.array(tips, dtype=np.int32)
+
+
+TIP_STATE = {"AB": 0, "Ab": 1, "aB": 2, "ab": 3}
+
+
+def tree_dp(ops, tipstate):
+    """(max_contrasting_pairs, propairs, antipairs) -- classes.py:199-592."""
+    ops = np.ascontiguousarray(ops, dtype=np.int32)
+    tipstate = np.ascontiguousarray(tipstate, dtype=np.uint8)
+    out = np.zeros(3, dtype=np.int32)
+    rc = _tree_lib().orc_tree_dp(_p(ops), len(ops), _p(tipstate), _p(out))
+    if rc != 0:
+        raise ValueError("malformed tree program")
+    return tuple(int(x) for x in out)
+
+
+def tree_permute(ops, tips, gbits, tbits, mbits, N, t, P, seed):
+    """Observed (Total, Pro, Anti) and the per-permutation exceedance flags of
+    Permute (methods.py:1314-1369) for one gene, labels by spec S4."""
+    ops = np.ascontiguousarray(ops, dtype=np.int32)
+    tips = np.ascontiguousarray(tips, dtype=np.int32)
+    obs = np.zeros(3, dtype=np.int32)
+    ex = np.zeros(P, dtype=np.uint8)
+    rc = _tree_lib().orc_tree_permute(
+        _p(ops), len(ops), _p(tips), len(tips),
+        _p(np.ascontiguousarray(gbits, dtype=np.uint64)),
+        _p(np.ascontiguousarray(tbits, dtype=np.uint64)),
+        _p(np.ascontiguousarray(mbits, dtype=np.uint64)), int(N), int(t), int(P), int(seed),
+        _p(obs), _p(ex))
+    if rc != 0:
+        raise ValueError("malformed tree program")
+    return tuple(int(x) for x in obs), ex
+
+
+def empirical_p_with_abort(exceed):
+    """The sequential estimator of methods.py:1348-1365: r counts exceedances;
+    after each permutation i >= 30, if 1 - binom.cdf(r, i, 0.1) < 0.05 return
+    (r+1)/(i+2); otherwise (r+1)/(P+1)."""
+    import scipy.stats as ss
+    r = 0
+    P = len(exceed)
+    for i in range(P):
+        r += int(exceed[i])
+        if i >= 30 and (1 - ss.binom.cdf(r, i, 0.1)) < 0.05:
+            return (r + 1.0) / (i + 2.0)
+    return (r + 1.0) / (P + 1.0)
+
+
+def binom_two_sided_half(x, n):
+    """scipy binom_test(x, n, 0.5) (methods.py:1267-1275), exact: the p = 0.5
+    binomial is symmetric, so the two-sided p is 2*P(X <= min(x, n-x)), 1 when
+    x == n/2, capped at 1."""
+    from fractions import Fraction
+    from math import comb
+    x, n = int(x), int(n)
+    if 2 * x == n:
+        return 1.0
+    k = min(x, n - x)
+    tail = sum(comb(n, j) for j in range(k + 1))
+    return float(min(Fraction(1), Fraction(2 * tail, 2 ** n)))
+
+
+def _morton(i, j, levels):
+    key = 0
+    for b in range(levels - 1, -1, -1):
+        key = (key << 2) | (((i >> b) & 1) << 1) | ((j >> b) & 1)
+    return key
+
+
+def upgma(zero_ones_strain_major, names):
+    """UPGMA tree of methods.py:619-707 + classes.py:68-196, restated without
+    the quad tree: Hamming distances (fraction of differing variable genes,
+    d(i,i) = 1), repeated merge of the closest pair, size-weighted average
+    (d_ik*size_i + d_jk*size_j)/new_size, dead clusters at distance 1 for the
+    averaging and maxsize in the matrix.  The reference finds the minimum by
+    descending a quad tree of (value, i, j) minima; among equal values that is
+    the cell with the smallest bit-interleaved (i-major Morton) index."""
+    import sys as _sys
+    X = np.asarray(zero_ones_strain_major, dtype=np.uint8)
+    n = X.shape[0]
+    big = float(_sys.maxsize)
+    D = [[big] * n for _ in range(n)]
+    ngenes = X.shape[1]
+    for i in range(n):
+        D[i][i] = 1
+        for j in range(i + 1, n):
+            D[i][j] = D[j][i] = float(int((X[i] != X[j]).sum())) / ngenes
+    levels = max(1, int(np.ceil(np.log2(max(n, 2)))) + 1)
+    cluster = list(names)
+    size = [1] * n
+    alive = n
+    new_cluster = None
+    while alive > 1:
+        best = None
+        for i in range(n):
+            for j in range(n):
+                v = D[i][j]
+                key = (v, _morton(i, j, levels))
+                if best is None or key < best[0]:
+                    best = (key, i, j)
+        _, i, j = best
+        new_cluster = [cluster[i], cluster[j]]
+        new_size = size[i] + size[j]
+        nd = []
+        for k in range(n):
+            if cluster[k] is None:
+                nd.append(1)
+            else:
+                nd.append((D[i][k] * size[i] + D[j][k] * size[j]) / new_size)
+        nd[i] = big
+        for k in range(n):
+            D[i][k] = D[k][i] = nd[k]
+        for k in range(n):
+            D[j][k] = D[k][j] = big
+        cluster[i], cluster[j] = new_cluster, None
+        size[i], size[j] = new_size, 0
+        alive -= 1
+    return new_cluster
+
+
+def newick(tree):
+    """StoreUPGMAtreeToFile's text form (methods.py:741-751)."""
+    return str(tree).replace("[", "(").replace("]", ")") + ";"

@@ -186,6 +186,121 @@ def fisher_grid(path):
     return len(tabs)
 
 
+def tree_goldens(gd, td, prune, res, manifest):
+    """Population-structure stage: UPGMA trees, PhyloTree
+    maxima, the default-mode (pairwise) CSVs, and Permute() driven by OUR
+    counter-based label permutations (random.shuffle patched so the reference
+    consumes exactly the labels spec S4 generates)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import oracle as orc
+    rng = np.random.default_rng(20260927)
+    gpa = os.path.join(EX, "Gene_presence_absence.csv")
+    tr = os.path.join(EX, "Tetracycline_resistance.csv")
+
+    # -- UPGMA: exampledata + random matrices with many tied distances --------
+    def ref_upgma(zom, names):
+        TDM = rm.CreateTriangularDistanceMatrix(zom, names)
+        return rm.upgma(rm.PopulateQuadTreeWithDistances(TDM))
+    cases = []
+    for n, g in [(2, 5), (3, 4), (4, 6), (5, 8), (7, 10), (8, 16), (9, 7), (12, 20), (16, 12),
+                 (17, 30), (23, 40), (31, 25), (33, 64), (40, 90)]:
+        for rep in range(3):
+            X = (rng.random((n, g)) < rng.uniform(0.2, 0.8)).astype(int)
+            if rep == 2 and n > 4:               # duplicate strains => zero distances / ties
+                X[1] = X[0]
+                X[n - 1] = X[n // 2]
+            keep = (X.sum(0) > 0) & (X.sum(0) < n)
+            if keep.sum() == 0:
+                continue
+            X = X[:, keep]
+            names = ["s%d" % i for i in range(n)]
+            cases.append({"matrix": X.tolist(), "names": names,
+                          "newick": str(ref_upgma(X.tolist(), names))})
+    tree = ref_upgma(gd["Zero_ones_matrix"], gd["Strains"])
+    with open(os.path.join(EX, "ExampleTree.nwk")) as f:
+        shipped = f.read().strip()
+    ours = str(tree).replace("[", "(").replace("]", ")") + ";"
+    manifest["upgma_example_equals_shipped_tree"] = (ours == shipped)
+    with open(os.path.join(HERE, "upgma_cases.json"), "w") as f:
+        json.dump({"cases": cases, "exampledata_tree": str(tree)}, f)
+
+    # -- PhyloTree maxima on random trees / tip states -----------------------
+    def rand_tree(tips):
+        if len(tips) == 1:
+            return tips[0]
+        k = int(rng.integers(1, len(tips)))
+        if rng.random() < 0.3:
+            k = 1                                  # caterpillar-ish
+        return [rand_tree(tips[:k]), rand_tree(tips[k:])]
+    pcases = []
+    for n in [2, 2, 3, 3, 4, 5, 6, 8, 11, 16, 25, 40, 64, 100]:
+        for rep in range(6):
+            tips = ["t%d" % i for i in range(n)]
+            t = rand_tree(tips)
+            states = rng.choice(["AB", "Ab", "aB", "ab"], size=n,
+                                p=rng.dirichlet([1, 1, 1, 1])).tolist()
+            gtc = dict(zip(tips, states))
+            pcases.append({"tree": t, "gtc": gtc,
+                           "result": rm.ConvertUPGMAtoPhyloTree(t, gtc)})
+    with open(os.path.join(HERE, "phylotree_cases.json"), "w") as f:
+        json.dump(pcases, f)
+
+    # -- default (pairwise) mode CSVs + tree file -----------------------------
+    for sub, extra in (("csv_pairwise_default", ["-u"]),
+                       ("csv_pairwise_epw", ["-c", "I", "EPW", "-p", "0.05", "0.05"]),
+                       ("csv_pairwise_bh_pw", ["-c", "BH", "PW", "-p", "0.9", "0.05", "-m", "300"])):
+        od = tempfile.mkdtemp()
+        files = run_cli(["-g", gpa, "-t", tr] + extra, od)
+        for fn, text in files.items():
+            gz_write(text, os.path.join(HERE, sub, fn + ".gz"))
+        if "-u" in extra:
+            with open(os.path.join(od, "Tree.nwk")) as f:
+                manifest["tree_nwk_equals_shipped"] = (f.read().strip() == shipped)
+
+    # -- Permute() fed with spec-S4 permutations -------------------------------
+    strains = gd["Strains"]
+    col = {s: j for j, s in enumerate(strains)}
+    out = {}
+    for ti, trait in enumerate(td):
+        valid = np.array([1 if s in td[trait] else 0 for s in strains], dtype=np.uint8)
+        lab = np.array([1 if td[trait].get(s) == "1" else 0 for s in strains], dtype=np.uint8)
+        mb = orc.pack_rows(valid[None])[0]
+        npos = int(lab.sum())
+        ptree = tree if not [x for x in prune[trait] if x is not None] else \
+            rm.PruneForMissing(tree, prune[trait])
+        gtcs = res["Gene_trait_combinations"][trait]
+        R = res["Results"][trait]
+        ranked = sorted(R, key=lambda g: R[g]["p_v"])
+        picks = ranked[:6] + ranked[40:43] + ranked[300:302] + ranked[-2:]
+        for P, seed in ((100, 7), (600, 12345)):
+            for gene in picks:
+                state = {"pi": 0}
+
+                def fake_shuffle(lst, _state=state, _gene=gene):
+                    bits = orc.perm_labels(seed, ti, _state["pi"], mb, npos, len(strains))
+                    b = np.unpackbits(bits.view(np.uint8), bitorder="little")
+                    order = list(gtcs[_gene].keys())        # isolates in GTC order
+                    want = ["B" if b[col[s]] else "b" for s in order]
+                    lst[:] = want[::-1]                     # PermuteGTC pops from the end
+                    _state["pi"] += 1
+                real = rm.random.shuffle
+                rm.random.shuffle = fake_shuffle
+                try:
+                    with quiet():
+                        emp = rm.Permute(tree=ptree, GTC=gtcs[gene], permutations=P,
+                                         cutoffs={"I": 0.05})
+                except ZeroDivisionError:
+                    emp = None
+                finally:
+                    rm.random.shuffle = real
+                obs = rm.ConvertUPGMAtoPhyloTree(ptree, gtcs[gene])
+                out.setdefault(trait, []).append(
+                    {"gene": gene, "P": P, "seed": seed, "empirical_p": emp,
+                     "perms_consumed": state["pi"], "observed": obs})
+    with open(os.path.join(HERE, "permute_tree_s4.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
 def main():
     os.makedirs(HERE, exist_ok=True)
     manifest = {}
@@ -284,6 +399,8 @@ def main():
     with open(os.path.join(HERE, "permute_tree_seeded.json"), "w") as f:
         json.dump({"gene": "TetRCG", "observed": obs, "seed": 0,
                    "permutations": 100, "empirical_p": emp}, f, indent=1)
+
+    tree_goldens(gd, td, prune, res, manifest)
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
