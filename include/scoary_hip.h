@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SCOARY_ABI_VERSION 1
+#define SCOARY_ABI_VERSION 2
 
 /* error codes */
 #define SCOARY_OK 0
@@ -106,7 +106,9 @@ int scoary_fisher(scoary_handle h, const int32_t *d_tables, int64_t M,
                   scoary_stream_t stream);
 
 /* ---- a8: PermuteGTC (scoary/methods.py:1371-1384) ----------------------
- * Label permutations pi = perm_base .. perm_base+P-1 of every trait: the
+ * Label permutations pi = perm_base .. perm_base+P-1 of the T traits whose
+ * rows are given (their global trait numbers are trait_base .. trait_base+T-1,
+ * the number that enters the Philox counter): the
  * trait's npos positive labels placed on a uniformly random subset of its
  * valid isolates (counter-based: Philox4x32-10 keyed by `seed`, counter
  * (isolate>>1, pi, trait, "SCOA"), sequential selection sampling -- DESIGN.md
@@ -114,8 +116,8 @@ int scoary_fisher(scoary_handle h, const int32_t *d_tables, int64_t M,
  *   d_perms : vecrows [T][P][Wp] */
 int scoary_perm_generate(scoary_handle h, const uint32_t *d_masks,
                          const int32_t *d_margins, int64_t T, int64_t N,
-                         int64_t P, int64_t perm_base, uint64_t seed,
-                         uint32_t *d_perms, scoary_stream_t stream);
+                         int64_t P, int64_t perm_base, int64_t trait_base,
+                         uint64_t seed, uint32_t *d_perms, scoary_stream_t stream);
 
 /* ---- a7: Permute (scoary/methods.py:1314-1369), Fisher statistic --------
  * d_r[t][g] += #{ pi < P : popcount(gene_g & perm_{t,pi}) lies in the
@@ -126,6 +128,57 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
                    const uint32_t *d_perms, const uint32_t *d_crit, int64_t G,
                    int64_t T, int64_t N, int64_t P, uint32_t *d_r,
                    scoary_stream_t stream);
+
+/* ======================================================================
+ * Population-structure stage
+ * ====================================================================== */
+
+/* ---- pdist(zeroonesmatrix, 'hamming') at scoary/methods.py:627-628 -------
+ * Pairwise Hamming COUNTS between the R rows of a tiled bit matrix (here the
+ * rows are isolates and the N columns are the variable genes; build it with
+ * scoary_tile_rows from the transposed presence matrix):
+ *   d_out[i][j] = popcount(row_i XOR row_j)        int32 [R][R]
+ * d_vecrows is the same matrix as vecrows [R][Wp] (the wave-uniform operand).
+ * The caller divides by the number of columns to get the reference's
+ * fractions. */
+int scoary_hamming(scoary_handle h, const uint32_t *d_tiled, const uint32_t *d_vecrows,
+                   int64_t R, int64_t N, int32_t *d_out, scoary_stream_t stream);
+
+/* ---- bit gather: reorder the columns of bit rows --------------------------
+ * d_out[r] bit k = d_rows[r] bit d_index[k]   (k < K; output rows are
+ * uint32 [R][Wout], Wout = (K+31)/32, pad bits zero).  Used to bring gene rows
+ * and permuted label rows into the tip order of a (pruned) tree. */
+int scoary_gather_bits(scoary_handle h, const uint32_t *d_rows, int64_t R, int64_t Wsrc,
+                       const int32_t *d_index, int64_t K, uint32_t *d_out,
+                       scoary_stream_t stream);
+
+/* ---- PhyloTree maxima: ConvertUPGMAtoPhyloTree, scoary/methods.py:1386-1402
+ *      + PhyloTree/Tip, scoary/classes.py:199-592 ---------------------------
+ * The binary tree is a stack program over its K tips (children order is
+ * irrelevant to the result):  op >= 0: push tip `op`;  op == -1: merge the two
+ * top entries;  op <= -2: merge the top entry with tip (-2 - op).
+ * `stack_depth` = the deepest the stack gets (host computes it; <= 32).
+ * Tip k of evaluation (g, l) is in state  (gene bit k of row g ? A : a) +
+ * (label bit k of row l ? B : b); d_gene_bits uint32 [G][Wt], d_label_bits
+ * uint32 [L][Wt], Wt = (K+31)/32.
+ *   d_out : int32 [G][L][3] = max contrasting pairs, max supporting pairs,
+ *           max opposing pairs (classes.py:246-249). */
+int scoary_tree_pairs(scoary_handle h, const int32_t *d_ops, int64_t nops, int64_t stack_depth,
+                      const uint32_t *d_gene_bits, const uint32_t *d_label_bits, int64_t G,
+                      int64_t L, int64_t K, int32_t *d_out, scoary_stream_t stream);
+
+/* ---- Permute with the reference's tree statistic, methods.py:1314-1369 ----
+ * Same evaluation for L permuted label rows, reduced to the exceedance flag
+ *   d_exceed[g][l] = Total_l > 0  &&  double(X_l)/double(Total_l) >= est_g,
+ * X = supporting pairs if the OBSERVED tree has Pro >= Anti else opposing pairs
+ * (methods.py:1333-1355); d_obs int32 [G][3] = observed (Total, Pro, Anti).
+ * A permuted tree with Total == 0 (ZeroDivisionError in the reference) is 0.
+ * The host applies the sequential estimator / early abort (methods.py:1360-1365)
+ * to the flags. */
+int scoary_tree_permute(scoary_handle h, const int32_t *d_ops, int64_t nops,
+                        int64_t stack_depth, const uint32_t *d_gene_bits,
+                        const uint32_t *d_label_bits, int64_t G, int64_t L, int64_t K,
+                        const int32_t *d_obs, uint8_t *d_exceed, scoary_stream_t stream);
 
 /* Name + average device time (ms, hipEvent on `stream`) of the kernels the
  * last scoary_permute call launched; for bench.py's roofline line.  Costs a

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libscoary_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "scoary_hip.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i64, _u64, _i32, _vp, _cp = (ctypes.c_int64, ctypes.c_uint64, ctypes.c_int,
                               ctypes.c_void_p, ctypes.c_char_p)
@@ -29,8 +29,13 @@ SIGNATURES = {
     "scoary_tile_rows": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "scoary_counts": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "scoary_fisher": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "scoary_perm_generate": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _u64, _vp, _vp]),
+    "scoary_perm_generate": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp, _vp]),
     "scoary_permute": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "scoary_hamming": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "scoary_gather_bits": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "scoary_tree_pairs": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "scoary_tree_permute": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
+                                   _vp]),
     "scoary_set_timing": (_i32, [_vp, _i32]),
     "scoary_last_kernel_ms": (_i32, [_vp, _cp, ctypes.POINTER(ctypes.c_double)]),
 }

@@ -260,7 +260,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 __global__ __launch_bounds__(64) void k_perm_generate(const uint32_t* __restrict__ masks,
                                                       const int32_t* __restrict__ margins, int N,
                                                       int Wp, int64_t P, int64_t perm_base,
-                                                      uint32_t k0, uint32_t k1,
+                                                      int trait_base, uint32_t k0, uint32_t k1,
                                                       uint32_t* __restrict__ perms) {
   const int t = blockIdx.y;
   const int64_t pl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void k_perm_generate(const uint32_t* __restrict
 #pragma unroll 4
     for (int jj = 0; jj < 16; ++jj) {
       uint32_t r[4];
-      philox4x32_10((uint32_t)(k * 16 + jj), pi, (uint32_t)t, kPermDomain, k0, k1, r);
+      philox4x32_10((uint32_t)(k * 16 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
       if ((mw >> (2 * jj)) & 1u) {
         const uint64_t u = ((uint64_t)r[1] << 32) | r[0];
         if (__umul64hi(u, remaining) < needed) {
@@ -406,6 +406,207 @@ __global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict_
       if (i0 + j < np) cnt += ((acc[j] - cr.x) >= cr.y) ? 1u : 0u;
   }
   if (g < G && cnt) atomicAdd(&r[(int64_t)t * G + g], cnt);
+}
+
+
+// ----------------------------------------------------------------------------
+// f-2: pairwise Hamming counts between rows (isolates x variable genes)
+// ----------------------------------------------------------------------------
+// Same shape as k_counts: lane = row i (coalesced 16 B loads of the tiled
+// matrix), blockIdx.y = a group of TB rows j whose words are wave-uniform
+// (scalar loads).  out is symmetric, so lane i stores out[j][i]: coalesced.
+template <int TB>
+__global__ __launch_bounds__(256) void k_hamming(const uint4* __restrict__ tiled,
+                                                 const uint32_t* __restrict__ vec, int R, int Rp,
+                                                 int Qp, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int j0 = blockIdx.y * TB;
+  const int Wp = Qp * 4;
+  uint32_t acc[TB];
+  const uint4* rowj[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    acc[j] = 0;
+    rowj[j] = reinterpret_cast<const uint4*>(vec + (int64_t)min(j0 + j, R - 1) * Wp);
+  }
+  for (int q = 0; q < Qp; ++q) {
+    const uint4 gw = tiled[(int64_t)q * Rp + i];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const uint4 s = rowj[j][q];
+      bcnt_acc(acc[j], gw.x ^ s.x);
+      bcnt_acc(acc[j], gw.y ^ s.y);
+      bcnt_acc(acc[j], gw.z ^ s.z);
+      bcnt_acc(acc[j], gw.w ^ s.w);
+    }
+  }
+  if (i >= R) return;
+#pragma unroll
+  for (int j = 0; j < TB; ++j)
+    if (j0 + j < R) out[(int64_t)(j0 + j) * R + i] = (int32_t)acc[j];
+}
+
+// out[r] bit k = rows[r] bit index[k]
+__global__ __launch_bounds__(256) void k_gather_bits(const uint32_t* __restrict__ rows, int64_t R,
+                                                     int64_t Wsrc, const int32_t* __restrict__ index,
+                                                     int64_t K, int64_t Wout,
+                                                     uint32_t* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t w = blockIdx.y;
+  if (r >= R) return;
+  const uint32_t* row = rows + r * Wsrc;
+  uint32_t word = 0;
+  for (int b = 0; b < 32; ++b) {
+    const int64_t k = w * 32 + b;
+    if (k < K) {
+      const int src = index[k];
+      word |= ((row[src >> 5] >> (src & 31)) & 1u) << b;
+    }
+  }
+  out[r * Wout + w] = word;
+}
+
+// ----------------------------------------------------------------------------
+// f-1: maximum contrasting pairs on a tree (PhyloTree, scoary/classes.py:199-592)
+// ----------------------------------------------------------------------------
+// State index 0 = AB, 1 = Ab, 2 = aB, 3 = ab, 4 = "0" (no free path); per state
+// (total, supporting, opposing) pairs, -1 = unreachable.
+struct TreeNode {
+  int tot[5], pro[5], anti[5];
+};
+
+// One candidate pairing of a left state with a right state
+// (classes.py:320-405 / :492-539).  Keeps the best total and, among the
+// candidates that reach it, the best supporting and best opposing counts
+// independently (classes.py:407-453).
+__device__ __forceinline__ void tree_candidate(const TreeNode& L, int ls, const TreeNode& R, int rs,
+                                               int dt, int dp, int da, int& bt, int& bp, int& ba) {
+  if (L.tot[ls] > -1 && R.tot[rs] > -1) {
+    const int t = L.tot[ls] + R.tot[rs] + dt;
+    const int p = L.pro[ls] + R.pro[rs] + dp;
+    const int a = L.anti[ls] + R.anti[rs] + da;
+    if (t > bt) {
+      bt = t;
+      bp = p;
+      ba = a;
+    } else if (t == bt) {
+      bp = max(bp, p);
+      ba = max(ba, a);
+    }
+  }
+}
+
+__device__ __forceinline__ void tree_merge(const TreeNode& L, const TreeNode& R, TreeNode& out) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {  // a free path to state c survives on one side
+    int bt = -1, bp = -1, ba = -1;
+#pragma unroll
+    for (int x = 0; x < 5; ++x) tree_candidate(L, c, R, x, 0, 0, 0, bt, bp, ba);
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+      if (x != c) tree_candidate(L, x, R, c, 0, 0, 0, bt, bp, ba);
+    out.tot[c] = bt;
+    out.pro[c] = bp;
+    out.anti[c] = ba;
+  }
+  int bt = -1, bp = -1, ba = -1;  // no free path: both closed, or one new pair across the root
+  tree_candidate(L, 4, R, 4, 0, 0, 0, bt, bp, ba);
+  tree_candidate(L, 0, R, 3, 1, 1, 0, bt, bp, ba);
+  tree_candidate(L, 3, R, 0, 1, 1, 0, bt, bp, ba);
+  tree_candidate(L, 1, R, 2, 1, 0, 1, bt, bp, ba);
+  tree_candidate(L, 2, R, 1, 1, 0, 1, bt, bp, ba);
+  out.tot[4] = bt;
+  out.pro[4] = bp;
+  out.anti[4] = ba;
+}
+
+__device__ __forceinline__ void tree_tip(TreeNode& n, int state) {
+#pragma unroll
+  for (int c = 0; c < 5; ++c) n.tot[c] = n.pro[c] = n.anti[c] = (c == state) ? 0 : -1;
+}
+
+// One thread per (gene row g, label row l).  The stack program is wave-uniform
+// (scalar loads, uniform branches); the top of the stack lives in registers,
+// deeper entries in LDS as int16 [depth][15][64 lanes].
+template <bool EXCEED>
+__global__ __launch_bounds__(64) void k_tree_dp(const int32_t* __restrict__ ops, int nops,
+                                                const uint32_t* __restrict__ gene_bits,
+                                                const uint32_t* __restrict__ label_bits, int64_t G,
+                                                int64_t L, int Wt, const int32_t* __restrict__ obs,
+                                                int32_t* __restrict__ out3,
+                                                uint8_t* __restrict__ exceed) {
+  extern __shared__ __attribute__((aligned(16))) short stack_lds[];
+  const int lane = threadIdx.x;
+  const int64_t id = (int64_t)blockIdx.x * kWave + lane;
+  const bool live = id < G * L;
+  const int64_t g = live ? id / L : 0, l = live ? id % L : 0;
+  const uint32_t* grow = gene_bits + g * Wt;
+  const uint32_t* lrow = label_bits + l * Wt;
+  TreeNode top;
+  tree_tip(top, 4);
+  int sp = 0;  // entries below `top`
+  int curw = -1;
+  uint32_t gw = 0, lw = 0;
+  for (int k = 0; k < nops; ++k) {
+    const int op = ops[k];
+    if (op == -1) {  // merge the two top entries
+      TreeNode left;
+      --sp;
+#pragma unroll
+      for (int f = 0; f < 5; ++f) {
+        left.tot[f] = stack_lds[((sp * 15) + f) * kWave + lane];
+        left.pro[f] = stack_lds[((sp * 15) + 5 + f) * kWave + lane];
+        left.anti[f] = stack_lds[((sp * 15) + 10 + f) * kWave + lane];
+      }
+      TreeNode m;
+      tree_merge(left, top, m);
+      top = m;
+    } else {
+      const int tip = op >= 0 ? op : -2 - op;
+      if ((tip >> 5) != curw) {
+        curw = tip >> 5;
+        gw = grow[curw];
+        lw = lrow[curw];
+      }
+      const int state = (((gw >> (tip & 31)) & 1u) ? 0 : 2) + (((lw >> (tip & 31)) & 1u) ? 0 : 1);
+      if (op >= 0) {  // push
+        if (k > 0) {
+#pragma unroll
+          for (int f = 0; f < 5; ++f) {
+            stack_lds[((sp * 15) + f) * kWave + lane] = (short)top.tot[f];
+            stack_lds[((sp * 15) + 5 + f) * kWave + lane] = (short)top.pro[f];
+            stack_lds[((sp * 15) + 10 + f) * kWave + lane] = (short)top.anti[f];
+          }
+          ++sp;
+        }
+        tree_tip(top, state);
+      } else {  // merge the top entry with a tip
+        TreeNode t, m;
+        tree_tip(t, state);
+        tree_merge(top, t, m);
+        top = m;
+      }
+    }
+  }
+  if (!live) return;
+  int bt = -1, bp = -1, ba = -1;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    bt = max(bt, top.tot[c]);
+    bp = max(bp, top.pro[c]);
+    ba = max(ba, top.anti[c]);
+  }
+  if (!EXCEED) {
+    out3[id * 3 + 0] = bt;
+    out3[id * 3 + 1] = bp;
+    out3[id * 3 + 2] = ba;
+  } else {
+    const int ot = obs[g * 3], op_ = obs[g * 3 + 1], oa = obs[g * 3 + 2];
+    const bool use_pro = op_ >= oa;
+    const double est = (double)(use_pro ? op_ : oa) / (double)ot;
+    const int x = use_pro ? bp : ba;
+    exceed[id] = (bt > 0 && (double)x / (double)bt >= est) ? 1 : 0;
+  }
 }
 
 }  // namespace
@@ -593,19 +794,21 @@ int scoary_fisher(scoary_handle h, const int32_t* d_tables, int64_t M, double* d
 }
 
 int scoary_perm_generate(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
-                         int64_t T, int64_t N, int64_t P, int64_t perm_base, uint64_t seed,
+                         int64_t T, int64_t N, int64_t P, int64_t perm_base, int64_t trait_base,
+                         uint64_t seed,
                          uint32_t* d_perms, scoary_stream_t stream) {
   if (!h) return SCOARY_ERR_ARG;
-  if (!d_masks || !d_margins || !d_perms || T < 1 || N < 1 || P < 1 || perm_base < 0)
+  if (!d_masks || !d_margins || !d_perms || T < 1 || N < 1 || P < 1 || perm_base < 0 ||
+      trait_base < 0)
     return fail(h, SCOARY_ERR_ARG, "scoary_perm_generate: bad argument");
-  if (T > 65535 || perm_base + P > 0xffffffffLL)
+  if (T > 65535 || trait_base + T > 0x7fffffffLL || perm_base + P > 0xffffffffLL)
     return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate: T > 65535 or permutation index >= 2^32");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   KernelTimer kt(h, s, "k_perm_generate");
   hipLaunchKernelGGL(k_perm_generate, dim3((unsigned)((P + kWave - 1) / kWave), (unsigned)T),
                      dim3(kWave), 0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P,
-                     perm_base, (uint32_t)seed, (uint32_t)(seed >> 32), d_perms);
+                     perm_base, (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), d_perms);
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }
@@ -670,6 +873,86 @@ int scoary_permute(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_p
   }
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
+}
+
+int scoary_hamming(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_vecrows, int64_t R,
+                   int64_t N, int32_t* d_out, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_vecrows || !d_out || R < 1 || N < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_hamming: bad argument");
+  if (R > (int64_t)1 << 20) return fail(h, SCOARY_ERR_SIZE, "scoary_hamming: more than 2^20 rows");
+  DeviceGuard guard(h->device);
+  const int64_t Rp = scoary_tiled_genes(R), Qp = scoary_tiled_quads(N);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr int TB = 8;
+  KernelTimer kt(h, s, "k_hamming");
+  hipLaunchKernelGGL((k_hamming<TB>), dim3((unsigned)(Rp / 256), (unsigned)((R + TB - 1) / TB)),
+                     dim3(256), 0, s, reinterpret_cast<const uint4*>(d_tiled), d_vecrows, (int)R,
+                     (int)Rp, (int)Qp, d_out);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_gather_bits(scoary_handle h, const uint32_t* d_rows, int64_t R, int64_t Wsrc,
+                       const int32_t* d_index, int64_t K, uint32_t* d_out,
+                       scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_rows || !d_index || !d_out || R < 1 || Wsrc < 1 || K < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_gather_bits: bad argument");
+  const int64_t Wout = (K + 31) / 32;
+  if (Wout > 65535) return fail(h, SCOARY_ERR_SIZE, "scoary_gather_bits: K too large");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_gather_bits");
+  hipLaunchKernelGGL(k_gather_bits, dim3((unsigned)((R + 255) / 256), (unsigned)Wout), dim3(256), 0,
+                     s, d_rows, R, Wsrc, d_index, K, Wout, d_out);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+static int launch_tree(scoary_handle h, const char* what, bool exceed_mode, const int32_t* d_ops,
+                       int64_t nops, int64_t stack_depth, const uint32_t* d_gene_bits,
+                       const uint32_t* d_label_bits, int64_t G, int64_t L, int64_t K,
+                       const int32_t* d_obs, int32_t* d_out3, uint8_t* d_exceed,
+                       scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_ops || !d_gene_bits || !d_label_bits || nops < 1 || G < 1 || L < 1 || K < 1 ||
+      stack_depth < 1 || (exceed_mode ? (!d_obs || !d_exceed) : !d_out3))
+    return fail(h, SCOARY_ERR_ARG, std::string(what) + ": bad argument");
+  if (stack_depth > 32) return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": stack_depth > 32");
+  if (K > 32767 * 2) return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": more than 65534 tips");
+  const int64_t threads = G * L;
+  if ((threads + kWave - 1) / kWave > 0x7fffffffLL)
+    return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": G*L too large for one launch");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t lds = (size_t)stack_depth * 15 * kWave * sizeof(short);
+  const int Wt = (int)((K + 31) / 32);
+  dim3 grid((unsigned)((threads + kWave - 1) / kWave));
+  KernelTimer kt(h, s, "k_tree_dp");
+  if (exceed_mode)
+    hipLaunchKernelGGL((k_tree_dp<true>), grid, dim3(kWave), lds, s, d_ops, (int)nops, d_gene_bits,
+                       d_label_bits, G, L, Wt, d_obs, (int32_t*)nullptr, d_exceed);
+  else
+    hipLaunchKernelGGL((k_tree_dp<false>), grid, dim3(kWave), lds, s, d_ops, (int)nops, d_gene_bits,
+                       d_label_bits, G, L, Wt, (const int32_t*)nullptr, d_out3, (uint8_t*)nullptr);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_tree_pairs(scoary_handle h, const int32_t* d_ops, int64_t nops, int64_t stack_depth,
+                      const uint32_t* d_gene_bits, const uint32_t* d_label_bits, int64_t G,
+                      int64_t L, int64_t K, int32_t* d_out, scoary_stream_t stream) {
+  return launch_tree(h, "scoary_tree_pairs", false, d_ops, nops, stack_depth, d_gene_bits,
+                     d_label_bits, G, L, K, nullptr, d_out, nullptr, stream);
+}
+
+int scoary_tree_permute(scoary_handle h, const int32_t* d_ops, int64_t nops, int64_t stack_depth,
+                        const uint32_t* d_gene_bits, const uint32_t* d_label_bits, int64_t G,
+                        int64_t L, int64_t K, const int32_t* d_obs, uint8_t* d_exceed,
+                        scoary_stream_t stream) {
+  return launch_tree(h, "scoary_tree_permute", true, d_ops, nops, stack_depth, d_gene_bits,
+                     d_label_bits, G, L, K, d_obs, nullptr, d_exceed, stream);
 }
 
 int scoary_set_timing(scoary_handle h, int enabled) {

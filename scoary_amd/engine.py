@@ -156,14 +156,15 @@ class AssociationEngine:
         return p, odds, crit
 
     # -- a8 / a7: permutations -------------------------------------------------
-    def perm_generate(self, masks, margins, N, P, perm_base, seed, out=None):
+    def perm_generate(self, masks, margins, N, P, perm_base, seed, out=None, trait_base=0):
         torch = _torch()
         T = masks.shape[0]
         Wp = self.row_words(N)
         if out is None:
             out = self._empty((T, P, Wp), torch.int32)
         self._check(self.lib.scoary_perm_generate(self.h, self._ptr(masks), self._ptr(margins), T,
-                                                  N, P, perm_base, ctypes.c_uint64(seed),
+                                                  N, P, perm_base, trait_base,
+                                                  ctypes.c_uint64(seed),
                                                   self._ptr(out), self._stream()),
                     "scoary_perm_generate")
         return out
@@ -207,6 +208,56 @@ class AssociationEngine:
                 self.permute(genes, perms, crit, r)
                 done += nb
         return {"counts": counts, "margins": margins, "p": p, "odds": odds, "crit": crit, "r": r}
+
+    # -- population-structure stage ----------------------------------
+    def hamming(self, rows01):
+        """rows01: (R, N) 0/1 numpy (rows = isolates, columns = variable genes)
+        -> (R, R) int32 numpy of pairwise Hamming counts."""
+        torch = _torch()
+        rows01 = np.ascontiguousarray(rows01, dtype=np.uint8)
+        R, N = rows01.shape
+        bits = pack_bits_rows(rows01)
+        gm = self.tile_rows(bits, N)
+        vec = self.vecrows(bits, N)
+        out = self._empty((R, R), torch.int32)
+        self._check(self.lib.scoary_hamming(self.h, self._ptr(gm.tiled), self._ptr(vec), R, N,
+                                            self._ptr(out), self._stream()), "scoary_hamming")
+        return out.cpu().numpy()
+
+    def gather_bits(self, rows, index):
+        """rows: int32 device tensor [R, Wsrc] of bit rows; index: int32 device
+        tensor [K] -> int32 [R, ceil(K/32)] with bit k = source bit index[k]."""
+        torch = _torch()
+        rows = rows.contiguous()
+        R, Wsrc = rows.shape
+        K = int(index.shape[0])
+        out = self._empty((R, (K + 31) // 32), torch.int32)
+        self._check(self.lib.scoary_gather_bits(self.h, self._ptr(rows), R, Wsrc,
+                                                self._ptr(index), K, self._ptr(out),
+                                                self._stream()), "scoary_gather_bits")
+        return out
+
+    def tree_pairs(self, ops, depth, gene_bits, label_bits, K):
+        torch = _torch()
+        G, L = gene_bits.shape[0], label_bits.shape[0]
+        out = self._empty((G, L, 3), torch.int32)
+        self._check(self.lib.scoary_tree_pairs(self.h, self._ptr(ops), int(ops.shape[0]),
+                                               int(depth), self._ptr(gene_bits),
+                                               self._ptr(label_bits), G, L, int(K),
+                                               self._ptr(out), self._stream()),
+                    "scoary_tree_pairs")
+        return out
+
+    def tree_permute(self, ops, depth, gene_bits, label_bits, K, obs):
+        torch = _torch()
+        G, L = gene_bits.shape[0], label_bits.shape[0]
+        out = self._empty((G, L), torch.uint8)
+        self._check(self.lib.scoary_tree_permute(self.h, self._ptr(ops), int(ops.shape[0]),
+                                                 int(depth), self._ptr(gene_bits),
+                                                 self._ptr(label_bits), G, L, int(K),
+                                                 self._ptr(obs.contiguous()), self._ptr(out),
+                                                 self._stream()), "scoary_tree_permute")
+        return out
 
     # -- timing (bench.py) ------------------------------------------------------
     def set_timing(self, on):

@@ -177,8 +177,9 @@ class GeneTraitCombinations(Mapping):
     over the trait's valid isolates (methods.py:953-965), computed lazily --
     only the tree stage of the reference consumes it."""
 
-    def __init__(self, table, genes, members, trait_row):
+    def __init__(self, table, genes, members, trait_row, trait_index=0):
         self.table, self.genes, self.members, self.trait_row = table, list(genes), members, trait_row
+        self.trait_index = trait_index           # enters the permutation counters (spec S4)
         self._index = {g: i for i, g in enumerate(self.genes)}
 
     def __len__(self):
@@ -537,25 +538,85 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
         if emp is not None:
             cols["Empirical_p"] = emp[rows_idx]
         all_traits[trait] = TraitResults(names_out, nugn, ann, cols, number_of_tests, members)
-        combos[trait] = GeneTraitCombinations(table, names_out, members, tarr[t])
+        combos[trait] = GeneTraitCombinations(table, names_out, members, tarr[t], t)
     return {"Results": all_traits, "Gene_trait_combinations": combos}
 
 
-def Permute(tree, GTC, permutations, cutoffs, seed=DEFAULT_SEED):
-    """Empirical p of ONE gene by label permutation (methods.py:1314-1369),
-    with the Fisher statistic: the fraction (r+1)/(P+1) of label
-    shuffles whose 2x2 table is as or more extreme than the observed one.
-    ``tree`` is accepted for signature compatibility and ignored; ``GTC`` is
-    the gene's {strain: "AB"|"Ab"|"aB"|"ab"} map."""
+def Permute(tree, GTC, permutations, cutoffs, seed=DEFAULT_SEED, trait_index=0):
+    """Empirical p of ONE gene by label permutation (methods.py:1314-1369).
+
+    With a ``tree`` (nested lists of the GTC's strains): the reference's
+    statistic -- supporting (or opposing) pairs / max contrasting pairs of the
+    PhyloTree, r = #permutations reaching the observed value, sequential early
+    abort after 30 permutations, (r+1)/(P+1) otherwise.  With ``tree=None``: the
+    Fisher statistic the north_star prescribes for the ``--no_pairwise`` path,
+    (r+1)/(P+1) with r = #label shuffles whose 2x2 table is as or less probable
+    than the observed one.  ``GTC`` is {strain: "AB"|"Ab"|"aB"|"ab"}."""
     if permutations < 10:
         sys.stdout.write("Number of permutations too few. The absolute minimum is 10.")
         return None
     strains = list(GTC.keys())
     g = np.array([[1 if GTC[s][0] == "A" else 0 for s in strains]], dtype=np.uint8)
     t = np.array([[1 if GTC[s][-1] == "B" else 0 for s in strains]], dtype=np.uint8)
-    table = GeneTable(["gene"], [""], [""], strains, pack_bits_rows(g))
-    dev = _associate(table, t, permutations, seed)
-    return (float(dev["r"][0, 0]) + 1.0) / (permutations + 1.0)
+    if tree is None:
+        table = GeneTable(["gene"], [""], [""], strains, pack_bits_rows(g))
+        dev = _associate(table, t, permutations, seed)
+        return (float(dev["r"][0, 0]) + 1.0) / (permutations + 1.0)
+    stage = _TreeStage(get_engine(), tree, strains, t[0], trait_index, seed)
+    obs = stage.observed(pack_bits_rows(g))
+    exceed = stage.permute(pack_bits_rows(g), obs, permutations)
+    from .tree import empirical_p_sequential
+    return empirical_p_sequential(exceed[0])
+
+
+class _TreeStage:
+    """Device state of the pairwise-comparison stage for ONE trait: the pruned
+    tree as a stack program, label bits in tip order, and the kernels that
+    evaluate genes (observed) and gene x permutation (scoary_tree_permute)."""
+
+    def __init__(self, engine, tree, strains, trait_row, trait_index, seed):
+        import torch
+        from .tree import TreeProgram
+        self.eng, self.N = engine, len(strains)
+        self.trait_index, self.seed = int(trait_index), seed
+        index_of = {s: i for i, s in enumerate(strains)}
+        self.prog = TreeProgram(tree, index_of)
+        dev = engine.device
+        self.ops = torch.from_numpy(self.prog.ops).to(dev)
+        self.tips = torch.from_numpy(self.prog.tips).to(dev)
+        trait_row = np.asarray(trait_row, dtype=np.uint8)
+        self.label_rows = engine.vecrows(pack_bits_rows((trait_row == 1)[None]), self.N)
+        self.mask_rows = engine.vecrows(pack_bits_rows((trait_row != 2)[None]), self.N)
+        self.labels_tip = engine.gather_bits(self.label_rows, self.tips)
+        self.margins = torch.tensor([[int((trait_row == 1).sum()), int((trait_row != 2).sum())]],
+                                    dtype=torch.int32, device=dev)
+
+    def _gene_tip_bits(self, rows64):
+        return self.eng.gather_bits(self.eng.vecrows(rows64, self.N), self.tips)
+
+    def observed(self, rows64):
+        """(G, 3) int32 numpy: max contrasting / supporting / opposing pairs."""
+        gt = self._gene_tip_bits(rows64)
+        out = self.eng.tree_pairs(self.ops, self.prog.depth, gt, self.labels_tip, self.prog.ntips)
+        return out[:, 0, :].cpu().numpy()
+
+    def permute(self, rows64, obs, permutations, batch_threads=1 << 26):
+        """(G, P) uint8 numpy exceedance flags (methods.py:1353-1355) under the
+        spec-S4 label permutations 0..P-1 of this trait."""
+        import torch
+        gt = self._gene_tip_bits(rows64)
+        obs_d = torch.from_numpy(np.ascontiguousarray(obs, dtype=np.int32)).to(self.eng.device)
+        G = gt.shape[0]
+        out = np.empty((G, permutations), dtype=np.uint8)
+        pb = max(1, min(permutations, batch_threads // max(G, 1)))
+        for p0 in range(0, permutations, pb):
+            nb = min(pb, permutations - p0)
+            perms = self.eng.perm_generate(self.mask_rows, self.margins, self.N, nb, p0, self.seed,
+                                           trait_base=self.trait_index)
+            ptip = self.eng.gather_bits(perms[0], self.tips)
+            ex = self.eng.tree_permute(self.ops, self.prog.depth, gt, ptip, self.prog.ntips, obs_d)
+            out[:, p0:p0 + nb] = ex.cpu().numpy()
+        return out
 
 
 # ---------------------------------------------------------------------------
@@ -583,79 +644,174 @@ CUT_FIELD = {"I": "p_v", "B": "B_p", "BH": "BH_p", "PW": "Plowest", "EPW": "Pbot
 
 def StoreResults(Results, max_hits, cutoffs, upgmatree, GTC, Prunedic, outdir, permutations,
                  num_threads, no_pairwise, genedic, extracolstoprint, firstcolnames, time="",
-                 delimiter=","):
+                 delimiter=",", seed=DEFAULT_SEED):
     for Trait in Results:
         sys.stdout.write("\n")
         log.info("Storing results: " + Trait)
         StoreTraitResult(Results[Trait], Trait, max_hits, cutoffs, upgmatree, GTC, Prunedic,
                          outdir, permutations, num_threads, no_pairwise, genedic,
-                         extracolstoprint, firstcolnames, time, delimiter)
+                         extracolstoprint, firstcolnames, time, delimiter, seed=seed)
+
+
+def decideifbreak(cutoffs, currentgene):
+    """True when a gene violates a naive / Bonferroni / BH cutoff, which ends
+    the pairwise stage for everything less significant (methods.py:1489-1508)."""
+    for m in ("I", "B", "BH"):
+        if m in cutoffs and currentgene[CUT_FIELD[m]] > cutoffs[m]:
+            return True
+    return False
+
+
+def _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC, Prunedic, permutations,
+                    genedic, seed):
+    """PairWiseComparisons (methods.py:1208-1312) for the genes ``order`` (row
+    indices, ascending naive p) of one trait, on the GPU: the prefix that passes
+    the I/B/BH cutoffs gets max contrasting / supporting / opposing pairs, the
+    two binomial p-values and, with permutations, the tree-statistic empirical p.
+    Returns (row indices kept, dict of extra columns over those rows)."""
+    from . import tree as T
+    cols = {k: np.asarray(Trait.column(k)) for k in ("p_v", "B_p", "BH_p")}
+    keep = []
+    for i in order:
+        if any(m in cutoffs and cols[CUT_FIELD[m]][i] > cutoffs[m] for m in ("I", "B", "BH")):
+            break
+        keep.append(int(i))
+    keep = np.array(keep, dtype=np.int64)
+    extra = {k: np.zeros(len(keep)) for k in ("Pbest", "Pworst", "Plowest", "Pboth")}
+    for k in ("max_total_pairs", "max_propairs", "max_antipairs"):
+        extra[k] = np.zeros(len(keep), dtype=np.int64)
+    if permutations >= 10:
+        extra["Empirical_p"] = np.zeros(len(keep))
+    if len(keep) == 0:
+        return keep, extra
+    gtc = GTC[Traitname]
+    table = gtc.table
+    tree = upgmatree
+    if len(Prunedic[Traitname]) > 0:
+        tree = T.prune_missing(upgmatree, Prunedic[Traitname])
+    stage = _TreeStage(get_engine(), tree, table.strains, gtc.trait_row, gtc.trait_index, seed)
+    src = [table.index(Trait.members[i][-1] if Trait.members is not None else Trait.genes[i])
+           for i in keep]
+    rows64 = table.rows64[src]
+    obs = stage.observed(rows64)
+    extra["max_total_pairs"] = obs[:, 0].astype(np.int64)
+    extra["max_propairs"] = obs[:, 1].astype(np.int64)
+    extra["max_antipairs"] = obs[:, 2].astype(np.int64)
+    memo = {}
+
+    def bt(x, n):
+        if (x, n) not in memo:
+            memo[(x, n)] = T.binom_two_sided(x, n)
+        return memo[(x, n)]
+    for k in range(len(keep)):
+        tot, pro, anti = (int(v) for v in obs[k])
+        a, b = bt(pro, tot), bt(tot - anti, tot)
+        if pro >= anti:                     # methods.py:1259-1275
+            extra["Pbest"][k], extra["Pworst"][k] = a, b
+        else:
+            extra["Pworst"][k], extra["Pbest"][k] = a, b
+    extra["Plowest"] = np.minimum(extra["Pbest"], extra["Pworst"])
+    extra["Pboth"] = np.maximum(extra["Pbest"], extra["Pworst"])
+    if permutations >= 10:
+        log.info("Performing %d label permutations of the pairwise-comparison statistic for "
+                 "%d genes on the GPU" % (permutations, len(keep)))
+        exceed = stage.permute(rows64, obs, permutations)
+        for k in range(len(keep)):
+            extra["Empirical_p"][k] = T.empirical_p_sequential(exceed[k])
+    return keep, extra
 
 
 def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Prunedic, outdir,
                      permutations, num_threads, no_pairwise, genedic, extracolstoprint,
-                     firstcolnames, time="", delimiter=","):
+                     firstcolnames, time="", delimiter=",", seed=DEFAULT_SEED):
     """Write ``<outdir><Trait><time>.results.csv`` (methods.py:1003-1197):
-    header, rows sorted by naive p (stable), every active cutoff applied, every
-    cell double-quoted."""
-    if not no_pairwise:
-        sys.exit("Pairwise comparisons (the tree-based population-structure stage, "
-                 "scoary/methods.py:1208-1312) are not part of this build yet; run with "
-                 "--no_pairwise.")
+    header, rows sorted (stable) by the reference's key, every active cutoff
+    applied, every cell double-quoted.  Without ``no_pairwise`` the
+    pairwise-comparison stage runs first (see _pairwise_stage)."""
     permutations = int(permutations)
     fname = outdir + Traitname + time + ".results.csv"
     columns = list(firstcolnames) + [
         "Number_pos_present_in", "Number_neg_present_in", "Number_pos_not_present_in",
         "Number_neg_not_present_in", "Sensitivity", "Specificity", "Odds_ratio", "Naive_p",
         "Bonferroni_p", "Benjamini_H_p"]
+    if not no_pairwise:
+        columns += ["Max_Pairwise_comparisons", "Max_supporting_pairs", "Max_opposing_pairs",
+                    "Best_pairwise_comp_p", "Worst_pairwise_comp_p"]
     with_emp = permutations >= 10
     if with_emp:
         columns.append("Empirical_p")
     columns += list(extracolstoprint)
     table = _as_table(genedic) if extracolstoprint else None
+    if not isinstance(Trait, TraitResults):
+        Trait = _trait_results_from_dict(Trait)
 
     n = len(Trait)
     num_results = n if max_hits is None else min(max_hits, n)
-    if isinstance(Trait, TraitResults):
-        order = np.argsort(np.asarray(Trait.column("p_v"), dtype=np.float64), kind="stable")
-        order = order[:num_results]
-        keep = np.ones(order.shape[0], dtype=bool)
-        for method, cut in cutoffs.items():
-            keep &= np.asarray(Trait.column(CUT_FIELD[method]))[order] <= cut
-        rows = order[keep]
-        get = lambda k: Trait.column(k)          # noqa: E731
-        names, nugn, ann = Trait.genes, Trait.nugn, Trait.annotation
-        members = Trait.members
-    else:                                        # plain dict of row dicts
-        names = list(Trait.keys())
-        order = sorted(range(n), key=lambda i: Trait[names[i]]["p_v"])[:num_results]
-        rows = [i for i in order
-                if all(Trait[names[i]][CUT_FIELD[m]] <= c for m, c in cutoffs.items())]
-        cache = {}
-
-        def get(k):
-            if k not in cache:
-                cache[k] = [Trait[g][k] for g in names]
-            return cache[k]
-        nugn, ann, members = get("NUGN"), get("Annotation"), None
-
-    log.info("Skipping population structure-aware analyses." if not with_emp else
-             "Performing %s label permutations per gene on the GPU (Fisher statistic)"
-             % permutations)
-    log.info("Storing results to file")
+    order = np.argsort(np.asarray(Trait.column("p_v"), dtype=np.float64), kind="stable")
+    order = order[:num_results]
     fields = ["tpgp", "tngp", "tpgn", "tngn", "sens", "spes", "OR", "p_v", "B_p", "BH_p"]
-    if with_emp:
-        fields.append("Empirical_p")
-    data = [get(k) for k in fields]
+    if no_pairwise:
+        log.info("Skipping population structure-aware analyses." if not with_emp else
+                 "Performing %s label permutations per gene on the GPU (Fisher statistic)"
+                 % permutations)
+        cand = order
+        colget = {k: np.asarray(Trait.column(k)) for k in fields}
+        if with_emp:
+            colget["Empirical_p"] = np.asarray(Trait.column("Empirical_p"))
+            fields.append("Empirical_p")
+        keyed = {CUT_FIELD[m]: colget[CUT_FIELD[m]] for m in cutoffs}
+        sel = cand[np.all([keyed[CUT_FIELD[m]][cand] <= c for m, c in cutoffs.items()], axis=0)] \
+            if cutoffs else cand
+        rows = [(int(i), None) for i in sel]
+        extra = None
+    else:
+        log.info("Calculating max number of contrasting pairs for each %s gene%s"
+                 % ("significant" if with_emp else "nominally significant",
+                    " and performing %d permutations" % permutations if with_emp else ""))
+        keep, extra = _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC, Prunedic,
+                                      permutations, genedic, seed)
+        colget = {k: np.asarray(Trait.column(k)) for k in fields}
+        # sort key of the filtered set (methods.py:1124-1135); ``keep`` is already
+        # in ascending-p order, and every sort is stable
+        pos = np.arange(len(keep))
+        if any(m in cutoffs for m in ("I", "B", "BH")):
+            pos = pos[np.argsort(colget["p_v"][keep], kind="stable")]
+        elif "EPW" in cutoffs:
+            pos = pos[np.argsort(extra["Pboth"], kind="stable")]
+        elif "PW" in cutoffs:
+            pos = pos[np.argsort(extra["Plowest"], kind="stable")]
+        elif "P" in cutoffs:
+            pos = pos[np.argsort(extra["Empirical_p"], kind="stable")]
+        else:
+            log.info("No filtration applied")
+        pos = pos[:min(num_results, len(keep))]
+        rows = []
+        for k in pos:
+            i = int(keep[k])
+            ok = True
+            for m, c in cutoffs.items():
+                f = CUT_FIELD[m]
+                v = extra[f][k] if f in extra else colget[f][i]
+                ok = ok and (v <= c)
+            if ok:
+                rows.append((i, int(k)))
+    log.info("Storing results to file")
+    names, nugn, ann, members = Trait.genes, Trait.nugn, Trait.annotation, Trait.members
     with open(fname, "w") as out:
         out.write(delimiter.join('"' + c + '"' for c in columns) + "\n")
-        for i in rows:
+        for i, k in rows:
             gene = names[i]
             if "_|_" in gene:
                 cells = gene.split("_|_")
             else:
                 cells = [gene, str(nugn[i]), str(ann[i])]
-            cells += [_fmt(col[i]) for col in data]
+            cells += [_fmt(colget[f][i]) for f in fields]
+            if extra is not None:
+                cells += [_fmt(extra["max_total_pairs"][k]), _fmt(extra["max_propairs"][k]),
+                          _fmt(extra["max_antipairs"][k]), _fmt(extra["Pbest"][k]),
+                          _fmt(extra["Pworst"][k])]
+                if with_emp:
+                    cells.append(_fmt(extra["Empirical_p"][k]))
             for colname in extracolstoprint:
                 key = colname + "_name"
                 if "--" in gene:
@@ -665,6 +821,27 @@ def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Pruned
                     cells.append(str(table.extra[key][table.index(gene)]))
             out.write(delimiter.join('"' + c + '"' for c in cells) + "\n")
     return fname
+
+
+def _trait_results_from_dict(rows):
+    """Plain {gene: row dict} (the reference's Results[trait]) -> TraitResults."""
+    genes = list(rows.keys())
+    cols = {}
+    for k in TraitResults.FIELDS + ("Empirical_p",):
+        if genes and k in rows[genes[0]]:
+            cols[k] = np.array([rows[g][k] for g in genes])
+    return TraitResults(genes, [rows[g]["NUGN"] for g in genes],
+                        [rows[g]["Annotation"] for g in genes], cols, len(genes))
+
+
+def StoreUPGMAtreeToFile(upgmatree, outdir, time=""):
+    """Write the tree as ``Tree<time>.nwk`` (methods.py:741-752)."""
+    from .tree import newick_text
+    name = str(outdir + ("Tree%s.nwk" % time))
+    with open(name, "w") as f:
+        f.write(newick_text(upgmatree))
+    log.info("Wrote the UPGMA tree to file: %s" % name)
+    return name
 
 
 def filtrationoptions(cutoffs, collapse):
@@ -835,12 +1012,29 @@ def main(**kwargs):
                                   allowed_isolates=allowed, writereducedset=args.write_reduced,
                                   time=stamp, outdir=args.outdir)
             genedic, strains = gd["Roarydic"], gd["Strains"]
-            if not args.no_pairwise:
-                sys.exit("Pairwise comparisons (UPGMA tree + the tree-based population-"
-                         "structure stage, scoary/methods.py:619-707 and :1208-1312) are not "
-                         "part of this build yet; run with --no_pairwise.")
-            log.info("Ignoring relatedness among input sample and performing only population "
-                     "structure-naive analysis.")
+            upgmatree = None
+            if args.newicktree is None and not args.no_pairwise:
+                log.info("Creating Hamming distance matrix based on gene presence/absence")
+                from . import tree as T
+                log.info("Building UPGMA tree from distance matrix")
+                upgmatree = T.upgma(get_engine(), genedic.dense(), strains)
+            elif args.no_pairwise:
+                log.info("Ignoring relatedness among input sample and performing only "
+                         "population structure-naive analysis.")
+            else:
+                log.info("Reading custom tree file")
+                from . import tree as T
+                upgmatree, members = T.read_newick(args.newicktree)
+                if sorted(strains) != sorted(members):
+                    if args.restrict_to is None:
+                        sys.exit("CRITICAL: Please make sure that isolates in your custom tree "
+                                 "match those in your gene presence absence file.")
+                    if not all(i in members for i in strains):
+                        sys.exit("CRITICAL: Your provided tree file did not contain all the "
+                                 "isolates in your gene presence absence file.")
+                    log.info("Pruning phylogenetic tree to correspond to set of included isolates")
+                    keepset = set(strains)
+                    upgmatree = T.prune_missing(upgmatree, [i for i in members if i not in keepset])
             log.info("Reading traits file")
             traitsdic, prunedic = Csv_to_dic(traits, args.delimiter, allowed, strains)
         log.info("Finished loading files into memory.\n\n")
@@ -848,13 +1042,18 @@ def main(**kwargs):
         for line in filtrationoptions(cutoffs, args.collapse):
             log.info(line)
         log.info("Tallying genes and performing statistical analyses")
-        res = Setup_results(genedic, traitsdic, args.collapse, permutations=args.permute,
-                            seed=seed)
+        # --no_pairwise: Fisher-statistic permutations for every gene (north_star);
+        # default mode: tree-statistic permutations of the surviving genes, done
+        # in the pairwise stage like the reference does.
+        res = Setup_results(genedic, traitsdic, args.collapse,
+                            permutations=args.permute if args.no_pairwise else 0, seed=seed)
+        if args.upgma_tree and upgmatree is not None and rank == 0:
+            StoreUPGMAtreeToFile(upgmatree, args.outdir, time=stamp)
         if rank == 0:           # every rank holds the gathered results; one writes
-            StoreResults(res["Results"], args.max_hits, cutoffs, None,
+            StoreResults(res["Results"], args.max_hits, cutoffs, upgmatree,
                          res["Gene_trait_combinations"], prunedic, args.outdir, args.permute,
                          args.threads, args.no_pairwise, genedic, gd["Extracols"],
-                         gd["Firstcolnames"], time=stamp, delimiter=args.delimiter)
+                         gd["Firstcolnames"], time=stamp, delimiter=args.delimiter, seed=seed)
         log.info("\n")
         log.info("==== Finished ====")
         log.info("Checked a total of %d genes for associations to %d trait(s). Total time "

@@ -1,0 +1,379 @@
+"""Population-structure stage, host side.
+
+  upgma()              scoary/methods.py:619-707 + scoary/classes.py:68-196
+                       (Hamming counts on the GPU, the O(N^2) merge loop on the
+                       host with a vectorised min-quad-tree)
+  prune_missing()      scoary/methods.py:709-739   PruneForMissing
+  TreeProgram          the stack program scoary_tree_pairs / scoary_tree_permute
+                       evaluate (replaces the recursive PhyloTree construction,
+                       scoary/methods.py:1386-1402, scoary/classes.py:210-249)
+  binom_two_sided()    ss.binom_test(x, n, 0.5), scoary/methods.py:1267-1275
+  newick_text() / read_newick()   scoary/methods.py:741-752, scoary/nwkhandler.py
+
+Trees are the reference's nested two-element lists of strain names.  All
+traversals are iterative: UPGMA trees can be caterpillars thousands deep.
+"""
+import sys
+from fractions import Fraction
+from math import comb
+
+import numpy as np
+
+BIG = float(sys.maxsize)
+
+
+# ---------------------------------------------------------------------------
+# UPGMA
+# ---------------------------------------------------------------------------
+class _MinQuadTree:
+    """Levels of 2x2 block minima over a square matrix (the reference's
+    QuadTree).  Level 0 is the matrix padded to even size with BIG; level l+1
+    holds the minima of level l's 2x2 blocks, padded to even size again."""
+
+    def __init__(self, D):
+        n = D.shape[0]
+        m = n + n % 2
+        cur = np.full((m, m), BIG, dtype=np.float64)
+        cur[:n, :n] = D
+        self.levels = [cur]
+        while cur.shape[0] > 2:
+            h = cur.shape[0] // 2
+            nxt = cur.reshape(h, 2, h, 2).min(axis=(1, 3))
+            if h % 2:
+                pad = np.full((h + 1, h + 1), BIG, dtype=np.float64)
+                pad[:h, :h] = nxt
+                nxt = pad
+            self.levels.append(nxt)
+            cur = nxt
+
+    def _set(self, idx, vec, row):
+        v = np.asarray(vec, dtype=np.float64)
+        for lv, cur in enumerate(self.levels):
+            m = cur.shape[0]
+            if v.shape[0] < m:
+                v = np.concatenate([v, np.full(m - v.shape[0], BIG)])
+            if row:
+                cur[idx, :] = v
+                pair = np.minimum(cur[idx & ~1, :], cur[idx | 1, :])
+            else:
+                cur[:, idx] = v
+                pair = np.minimum(cur[:, idx & ~1], cur[:, idx | 1])
+            v = pair.reshape(-1, 2).min(axis=1)
+            idx //= 2
+
+    def set_row(self, i, vec):
+        self._set(i, vec, True)
+
+    def set_col(self, j, vec):
+        self._set(j, vec, False)
+
+    def argmin(self):
+        """Descend from the top: in each 2x2 block take the smallest
+        (value, i, j) -- the reference's tie-break (classes.py:172-196)."""
+        i = j = 0
+        for cur in reversed(self.levels):
+            i, j = 2 * i, 2 * j
+            best = None
+            for di in (0, 1):
+                for dj in (0, 1):
+                    key = (cur[i + di, j + dj], i + di, j + dj)
+                    if best is None or key < best:
+                        best = key
+            i, j = best[1], best[2]
+        return i, j
+
+
+def upgma_from_counts(counts, ncols, names):
+    """counts: (n, n) integer Hamming counts over ``ncols`` variable genes."""
+    n = len(names)
+    D = counts.astype(np.float64) / float(ncols)      # pdist 'hamming' fractions
+    np.fill_diagonal(D, 1.0)                          # methods.py:636-638
+    qt = _MinQuadTree(D)
+    d0 = qt.levels[0]
+    cluster = list(names)
+    alive = np.ones(n, dtype=bool)
+    size = np.ones(n, dtype=np.float64)
+    new_cluster = cluster[0] if n == 1 else None
+    for _ in range(n - 1):
+        i, j = qt.argmin()
+        new_cluster = [cluster[i], cluster[j]]
+        new_size = size[i] + size[j]
+        nd = (d0[i, :n] * size[i] + d0[j, :n] * size[j]) / new_size
+        nd[~alive] = 1.0
+        nd[i] = BIG
+        qt.set_row(i, nd)
+        qt.set_col(i, nd)
+        dead = np.full(n, BIG)
+        qt.set_row(j, dead)
+        qt.set_col(j, dead)
+        cluster[i], cluster[j] = new_cluster, None
+        alive[j] = False
+        size[i], size[j] = new_size, 0.0
+    return new_cluster
+
+
+def upgma(engine, dense_genes_by_strain, names):
+    """dense (G, N) 0/1 presence matrix -> UPGMA tree over the N strains, from
+    Hamming distances over the variable genes (methods.py:496-502, 619-707).
+    The N x N Hamming counts are computed on the GPU (scoary_hamming)."""
+    dense = np.asarray(dense_genes_by_strain, dtype=np.uint8)
+    tot = dense.sum(axis=1)
+    var = dense[(tot > 0) & (tot < dense.shape[1])]
+    if var.shape[0] == 0:
+        raise ValueError("no variable genes: cannot build a tree")
+    counts = engine.hamming(np.ascontiguousarray(var.T))
+    return upgma_from_counts(counts, var.shape[0], names)
+
+
+# ---------------------------------------------------------------------------
+# Tree utilities (iterative)
+# ---------------------------------------------------------------------------
+def _flatten(tree):
+    """Nested lists -> (left[], right[], name[]) arrays; node 0 is the root.
+    Tips have left = right = -1."""
+    left, right, name = [], [], []
+    stack = [(tree, -1, 0)]
+    while stack:
+        node, parent, side = stack.pop()
+        me = len(left)
+        left.append(-1)
+        right.append(-1)
+        name.append(None)
+        if parent >= 0:
+            (left if side == 0 else right)[parent] = me
+        if isinstance(node, (list, tuple)):
+            if len(node) != 2:
+                raise ValueError("tree nodes must be binary")
+            stack.append((node[1], me, 1))
+            stack.append((node[0], me, 0))
+        else:
+            name[me] = node
+    return left, right, name
+
+
+def prune_missing(tree, prune):
+    """PruneForMissing (methods.py:709-739): remove the tips in ``prune``;
+    a node left with one child is replaced by that child, with none it
+    disappears.  Returns None if nothing remains."""
+    drop = set(x for x in prune if x is not None)
+    if not drop:
+        return tree
+    left, right, name = _flatten(tree)
+    n = len(left)
+    result = [None] * n
+    for v in range(n - 1, -1, -1):          # children have larger indices than parents
+        if left[v] < 0:
+            result[v] = None if name[v] in drop else name[v]
+        else:
+            a, b = result[left[v]], result[right[v]]
+            if a is None and b is None:
+                result[v] = None
+            elif a is None:
+                result[v] = b
+            elif b is None:
+                result[v] = a
+            else:
+                result[v] = [a, b]
+    return result[0]
+
+
+def tips_of(tree):
+    return [x for x in _flatten(tree)[2] if x is not None]
+
+
+class TreeProgram:
+    """Stack program of a binary tree for scoary_tree_pairs / _permute:
+    op >= 0 push tip op; -1 merge the two top entries; <= -2 merge the top entry
+    with tip (-2 - op).  Tips are numbered in program order; ``tips[k]`` is the
+    isolate index of tip k.  The larger subtree is always evaluated first, so
+    the stack never gets deeper than log2(#tips) + 1."""
+
+    def __init__(self, tree, index_of):
+        left, right, name = _flatten(tree)
+        n = len(left)
+        if n < 3:
+            raise ValueError("a tree needs at least two tips")
+        size = [1] * n
+        for v in range(n - 1, -1, -1):
+            if left[v] >= 0:
+                size[v] = size[left[v]] + size[right[v]]
+        ops, tips = [], []
+        depth = maxdepth = 0          # entries below the top of the stack
+        started = False
+        work = [("visit", 0)]
+        while work:
+            kind, v = work.pop()
+            if kind == "merge":
+                ops.append(-1)
+                depth -= 1
+            elif kind == "mergetip":
+                ops.append(-2 - len(tips))
+                tips.append(index_of[name[v]])
+            elif left[v] < 0:
+                ops.append(len(tips))
+                tips.append(index_of[name[v]])
+                if started:
+                    depth += 1
+                    maxdepth = max(maxdepth, depth)
+                started = True
+            else:
+                a, b = left[v], right[v]
+                if size[a] < size[b]:
+                    a, b = b, a                         # heavy child first
+                if left[b] < 0:
+                    work.append(("mergetip", b))
+                else:
+                    work.append(("merge", v))
+                    work.append(("visit", b))
+                work.append(("visit", a))
+        self.ops = np.array(ops, dtype=np.int32)
+        self.tips = np.array(tips, dtype=np.int32)
+        self.depth = max(1, maxdepth)
+        self.ntips = len(tips)
+
+
+# ---------------------------------------------------------------------------
+# Newick in / out
+# ---------------------------------------------------------------------------
+def newick_text(tree):
+    """str(nested lists) with [] -> () plus ';' (methods.py:741-751), written
+    iteratively so deep trees do not hit the recursion limit."""
+    out = []
+    work = [(False, tree)]
+    while work:
+        literal, x = work.pop()
+        if literal:
+            out.append(x)
+        elif isinstance(x, (list, tuple)):
+            work.append((True, ")"))
+            work.append((False, x[1]))
+            work.append((True, ", "))
+            work.append((False, x[0]))
+            work.append((True, "("))
+        else:
+            out.append(repr(x))
+    return "".join(out) + ";"
+
+
+def read_newick(path):
+    """Read a Newick file into nested two-element lists of tip names + the
+    list of tip names (scoary/nwkhandler.py:10-40).  Branch lengths, support
+    values and internal names are ignored; quotes around names are stripped; a
+    node with more than two children is resolved left to right
+    ((a, b), c) ...  -- ete3's own polytomy resolution is not available here
+    (documented divergence for non-binary input trees)."""
+    with open(path) as f:
+        text = f.read().strip()
+    text = text[:text.index(";")] if ";" in text else text
+    pos = 0
+    stack = [[]]
+    members = []
+    n = len(text)
+    while pos < n:
+        ch = text[pos]
+        if ch == "(":
+            stack.append([])
+            pos += 1
+        elif ch == ")":
+            kids = stack.pop()
+            pos += 1
+            # skip internal label / support / branch length
+            while pos < n and text[pos] not in ",()":
+                pos += 1
+            if not kids:
+                raise SystemExit("Corrupted or non-existing custom tree file? empty group")
+            node = kids[0]
+            for k in kids[1:]:
+                node = [node, k]
+            if len(kids) == 1:
+                node = kids[0]
+            stack[-1].append(node)
+        elif ch == ",":
+            pos += 1
+        elif ch.isspace():
+            pos += 1
+        else:
+            if ch in "'\"":
+                end = text.index(ch, pos + 1)
+                label = text[pos + 1:end]
+                pos = end + 1
+                while pos < n and text[pos] not in ",()":
+                    pos += 1
+            else:
+                end = pos
+                while end < n and text[end] not in ",():":
+                    end += 1
+                label = text[pos:end].strip().lstrip("'\"").rstrip("'\"")
+                pos = end
+                while pos < n and text[pos] not in ",()":
+                    pos += 1
+            stack[-1].append(label)
+            members.append(label)
+    top = stack[0]
+    if len(top) != 1:
+        node = top[0]
+        for k in top[1:]:
+            node = [node, k]
+        top = [node]
+    return top[0], members
+
+
+# ---------------------------------------------------------------------------
+# Binomial test and the sequential permutation estimator
+# ---------------------------------------------------------------------------
+def binom_two_sided(x, n):
+    """binom_test(x, n, 0.5): the p = 0.5 binomial is symmetric, so the
+    two-sided p is 2 P(X <= min(x, n-x)) (1 when x == n/2), capped at 1; exact
+    rational arithmetic, rounded once."""
+    x, n = int(x), int(n)
+    if 2 * x == n:
+        return 1.0
+    k = min(x, n - x)
+    tail = sum(comb(n, j) for j in range(k + 1))
+    return float(min(Fraction(1), Fraction(2 * tail, 2 ** n)))
+
+
+_ABORT_CACHE = {}
+
+
+def _abort_thresholds(P):
+    """For i in [30, P): smallest r with 1 - binom.cdf(r, i, 0.1) < 0.05
+    (methods.py:1360-1361), evaluated with SciPy's binom.cdf exactly as the
+    reference evaluates it (candidates bracketed by the 0.95 quantile)."""
+    if P not in _ABORT_CACHE:
+        import scipy.stats as ss
+        thr = np.full(P, np.iinfo(np.int64).max, dtype=np.int64)
+        if P > 30:
+            i = np.arange(30, P)
+            r0 = ss.binom.ppf(0.95, i, 0.1).astype(np.int64)
+            best = np.full(i.shape, np.iinfo(np.int64).max, dtype=np.int64)
+            for d in (3, 2, 1, 0, -1, -2, -3):          # descending: smallest r wins last
+                r = np.maximum(r0 + d, 0)
+                ok = (1 - ss.binom.cdf(r, i, 0.1)) < 0.05
+                best = np.where(ok, r, best)
+            # guard the bracketing assumption: below `best` the test must fail
+            below = np.maximum(best - 1, 0)
+            bad = (best > 0) & ((1 - ss.binom.cdf(below, i, 0.1)) < 0.05)
+            if bad.any() or (best == np.iinfo(np.int64).max).any():
+                for k in np.nonzero(bad | (best == np.iinfo(np.int64).max))[0]:
+                    rr = np.arange(0, i[k] + 1)
+                    hit = np.nonzero((1 - ss.binom.cdf(rr, i[k], 0.1)) < 0.05)[0]
+                    best[k] = hit[0] if hit.size else np.iinfo(np.int64).max
+            thr[30:] = best
+        _ABORT_CACHE[P] = thr
+    return _ABORT_CACHE[P]
+
+
+def empirical_p_sequential(exceed):
+    """The reference's estimator (methods.py:1348-1365) over the exceedance
+    flags of permutations 0..P-1: r accumulates; from i >= 30 on, the first i
+    with 1 - binom.cdf(r, i, 0.1) < 0.05 returns (r+1)/(i+2); else (r+1)/(P+1)."""
+    ex = np.asarray(exceed, dtype=np.int64)
+    P = ex.shape[0]
+    r = np.cumsum(ex)
+    thr = _abort_thresholds(P)
+    hit = np.nonzero(r >= thr)[0]
+    if hit.size:
+        i = int(hit[0])
+        return (float(r[i]) + 1.0) / (i + 2.0)
+    return (float(r[-1]) + 1.0) / (P + 1.0)

@@ -1,0 +1,251 @@
+"""Population-structure stage on the GPU: Hamming counts,
+bit gather, PhyloTree maxima, tree-statistic permutations and the default-mode
+command line, against the oracle and files captured from the real reference."""
+import csv
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_text, read_dense
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    from scoary_amd.engine import AssociationEngine
+    e = AssociationEngine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("R,N", [(2, 1), (3, 31), (17, 64), (100, 5940), (257, 1000), (40, 20001)])
+def test_hamming_counts_bit_exact(eng, R, N):
+    rng = np.random.default_rng(R * 31 + N)
+    X = (rng.random((R, N)) < rng.uniform(0.1, 0.9)).astype(np.uint8)
+    got = eng.hamming(X)
+    want = (X[:, None, :] != X[None, :, :]).sum(axis=2) if R * R * N < 5e7 else \
+        np.array([[int((X[i] != X[j]).sum()) for j in range(R)] for i in range(R)])
+    assert np.array_equal(got, want)
+
+
+def test_upgma_random_cases_and_exampledata(eng):
+    from scoary_amd import tree as T
+    d = _json("upgma_cases.json")
+    for c in d["cases"]:
+        X = np.array(c["matrix"], dtype=np.uint8)          # strains x genes
+        t = T.upgma(eng, X.T, c["names"])
+        assert str(t) == c["newick"]
+    ids, strains, genes, names, traits = read_dense(
+        golden_text("exampledata/Gene_presence_absence.csv.gz"),
+        golden_text("exampledata/Tetracycline_resistance.csv.gz"))
+    t = T.upgma(eng, genes, strains)
+    assert T.newick_text(t) == golden_text("exampledata/ExampleTree.nwk.gz").strip()
+
+
+@pytest.mark.parametrize("R,N,K", [(1, 1, 1), (5, 40, 40), (70, 100, 97), (300, 2000, 1980), (3, 5000, 4999)])
+def test_gather_bits_bit_exact(eng, R, N, K):
+    import torch
+    from scoary_amd.engine import pack_bits_rows
+    rng = np.random.default_rng(R + N + K)
+    X = (rng.random((R, N)) < 0.5).astype(np.uint8)
+    idx = rng.permutation(N)[:K].astype(np.int32)
+    rows = eng.vecrows(pack_bits_rows(X), N)
+    got = eng.gather_bits(rows, torch.from_numpy(idx).cuda()).cpu().numpy().view(np.uint32)
+    bits = np.unpackbits(got.view(np.uint8), axis=1, bitorder="little")
+    assert np.array_equal(bits[:, :K], X[:, idx])
+    assert not bits[:, K:].any()
+
+
+def _dp_via_gpu(eng, tree, tips_names, states_by_name):
+    import torch
+    from scoary_amd import tree as T
+    from scoary_amd.engine import pack_bits_rows
+    index_of = {t: i for i, t in enumerate(tips_names)}
+    prog = T.TreeProgram(tree, index_of)
+    K = prog.ntips
+    g = np.array([[1 if states_by_name[tips_names[i]][0] == "A" else 0 for i in prog.tips]], np.uint8)
+    l = np.array([[1 if states_by_name[tips_names[i]][1] == "B" else 0 for i in prog.tips]], np.uint8)
+    gb = torch.from_numpy(pack_bits_rows(g).view(np.int32)).cuda()
+    lb = torch.from_numpy(pack_bits_rows(l).view(np.int32)).cuda()
+    out = eng.tree_pairs(torch.from_numpy(prog.ops).cuda(), prog.depth, gb, lb, K)
+    return tuple(int(x) for x in out.cpu().numpy()[0, 0])
+
+
+def test_phylotree_maxima_golden_cases(eng):
+    for c in _json("phylotree_cases.json"):
+        tips = list(c["gtc"].keys())
+        got = _dp_via_gpu(eng, c["tree"], tips, c["gtc"])
+        w = c["result"]
+        assert got == (w["Total"], w["Pro"], w["Anti"]), c["tree"]
+
+
+def test_tree_pairs_many_genes_vs_oracle(eng, orc):
+    """G genes x L label rows on random deep / bushy trees."""
+    import torch
+    from scoary_amd import tree as T
+    from scoary_amd.engine import pack_bits_rows
+    rng = np.random.default_rng(5)
+
+    def rand_tree(tips, cat):
+        if len(tips) == 1:
+            return tips[0]
+        k = 1 if rng.random() < cat else int(rng.integers(1, len(tips)))
+        return [rand_tree(tips[:k], cat), rand_tree(tips[k:], cat)]
+    sys.setrecursionlimit(10000)
+    for K, cat in [(2, 0), (9, 0.2), (64, 0.5), (333, 0.9), (700, 0.1), (1500, 0.97)]:
+        names = ["t%d" % i for i in range(K)]
+        tree = rand_tree(names, cat)
+        prog = T.TreeProgram(tree, {t: i for i, t in enumerate(names)})
+        assert prog.depth <= int(np.log2(K)) + 2
+        G, L = 37, 11
+        gm = (rng.random((G, K)) < rng.uniform(0.05, 0.95, (G, 1))).astype(np.uint8)
+        lm = (rng.random((L, K)) < rng.uniform(0.2, 0.8, (L, 1))).astype(np.uint8)
+        gb = torch.from_numpy(pack_bits_rows(gm[:, prog.tips]).view(np.int32)).cuda()
+        lb = torch.from_numpy(pack_bits_rows(lm[:, prog.tips]).view(np.int32)).cuda()
+        out = eng.tree_pairs(torch.from_numpy(prog.ops).cuda(), prog.depth, gb, lb, K).cpu().numpy()
+        ops, tips = orc.tree_program(tree, {t: i for i, t in enumerate(names)})
+        for g in range(0, G, 5):
+            for l in range(0, L, 3):
+                st = np.array([(0 if gm[g, i] else 2) + (0 if lm[l, i] else 1) for i in tips],
+                              dtype=np.uint8)
+                assert tuple(out[g, l]) == orc.tree_dp(ops, st), (K, g, l)
+
+
+def test_tree_permute_call_site_vs_reference_permute(eng, manifest):
+    """methods.Permute(tree=...) == the reference's Permute() fed the same
+    spec-S4 label permutations (golden, incl. its early abort)."""
+    from scoary_amd import methods as m
+    from scoary_amd import tree as T
+    gold = _json("permute_tree_s4.json")
+    tree = eval(_json("upgma_cases.json")["exampledata_tree"])
+    ids, strains, genes, names, traits = read_dense(
+        golden_text("exampledata/Gene_presence_absence.csv.gz"),
+        golden_text("exampledata/Tetracycline_resistance.csv.gz"))
+    for ti, trait in enumerate(names):
+        ptree = T.prune_missing(tree, manifest["prune"][trait] + [None])
+        for rec in gold[trait]:
+            if rec["empirical_p"] is None:
+                continue
+            g = ids.index(rec["gene"])
+            # the Permute() call site works on the trait's valid isolates only, so its
+            # permutation counters see a different isolate numbering than the batched
+            # CLI path: compare through the batched stage instead (same numbering as
+            # the golden run), then the call-site signature separately below.
+            stage = m._TreeStage(eng, ptree, strains, traits[ti], ti, rec["seed"])
+            from scoary_amd.engine import pack_bits_rows
+            rows = pack_bits_rows(genes[g:g + 1])
+            obs = stage.observed(rows)
+            w = rec["observed"]
+            assert tuple(int(x) for x in obs[0]) == (w["Total"], w["Pro"], w["Anti"])
+            ex = stage.permute(rows, obs, rec["P"])
+            assert T.empirical_p_sequential(ex[0]) == rec["empirical_p"], rec
+    # call-site signature: GTC dict in, float out, tree statistic when a tree is given
+    gtc = {s: ("A" if genes[ids.index("TetRCG"), j] else "a") + ("B" if traits[0, j] == 1 else "b")
+           for j, s in enumerate(strains)}
+    emp = m.Permute(tree=tree, GTC=gtc, permutations=100, cutoffs={"I": 0.05}, seed=7,
+                    trait_index=0)
+    assert emp == [r for r in gold["Tetracycline_resistance"]
+                   if r["gene"] == "TetRCG" and r["P"] == 100][0]["empirical_p"]
+
+
+def run_cli(argv, outdir):
+    from scoary_amd import methods as m
+    old = sys.argv
+    sys.argv = ["scoary"] + argv + ["-o", str(outdir), "--no-time"]
+    try:
+        with pytest.raises(SystemExit) as e:
+            m.main()
+        assert e.value.code in (0, None), e.value.code
+    finally:
+        sys.argv = old
+    out = {}
+    for fn in sorted(os.listdir(outdir)):
+        if fn.endswith(".results.csv") or fn.endswith(".nwk"):
+            with open(os.path.join(outdir, fn), newline="") as f:
+                out[fn] = f.read()
+    return out
+
+
+@pytest.mark.parametrize("sub,extra", [
+    ("csv_pairwise_default", ["-u"]),
+    ("csv_pairwise_epw", ["-c", "I", "EPW", "-p", "0.05", "0.05"]),
+    ("csv_pairwise_bh_pw", ["-c", "BH", "PW", "-p", "0.9", "0.05", "-m", "300"]),
+])
+def test_cli_default_pairwise_mode_vs_reference(exampledir, tmp_path, sub, extra):
+    """The reference's Travis "Test1"-style runs (pairwise comparisons on)."""
+    files = run_cli(["-g", os.path.join(exampledir, "Gene_presence_absence.csv"),
+                     "-t", os.path.join(exampledir, "Tetracycline_resistance.csv")] + extra,
+                    tmp_path)
+    if "-u" in extra:
+        assert files["Tree.nwk"].strip() == golden_text("exampledata/ExampleTree.nwk.gz").strip()
+    for trait in ("Tetracycline_resistance", "Bogus_trait"):
+        got = list(csv.reader(io.StringIO(files[trait + ".results.csv"])))
+        want = list(csv.reader(io.StringIO(golden_text("%s/%s.results.csv.gz" % (sub, trait)))))
+        assert got[0] == want[0]
+        assert len(got) == len(want), (trait, len(got), len(want))
+        wi = {r[0]: r for r in want[1:]}
+        for r in got[1:]:
+            w = wi[r[0]]
+            assert r[:7] == w[:7]                                  # names + counts
+            assert r[13:16] == w[13:16], r[0]                      # pair counts: exact
+            for k in (7, 8, 9, 10, 11, 12, 16, 17):
+                a, b = float(r[k]), float(w[k])
+                assert abs(a - b) <= 1e-9 * abs(b) + 1e-12 * 6000, (r[0], got[0][k], r[k], w[k])
+    # the reference's own pinned row (tests/test_scoary_output.py:12-14), pairwise part
+    top = list(csv.reader(io.StringIO(files["Tetracycline_resistance.results.csv"])))[1]
+    assert top[0] == "TetRCG" and [int(x) for x in top[13:16]] == [25, 25, 1]
+    assert abs(float(top[16]) - 5.96046447754E-008) < 1e-9
+    assert abs(float(top[17]) - 1.54972076416E-006) < 1e-7
+
+
+def test_cli_pairwise_with_tree_permutations(exampledir, tmp_path):
+    """--permute in default mode = tree-statistic permutations of the surviving
+    genes (closes SURVEY D1): column present, values are the sequential
+    estimator of the oracle's exceedance flags."""
+    from oracle import oracle as orc
+    P, seed = 120, 99
+    files = run_cli(["-g", os.path.join(exampledir, "Gene_presence_absence.csv"),
+                     "-t", os.path.join(exampledir, "Tetracycline_resistance.csv"),
+                     "-e", str(P), "--seed", str(seed), "-p", "0.001"], tmp_path)
+    ids, strains, genes, names, traits = read_dense(
+        golden_text("exampledata/Gene_presence_absence.csv.gz"),
+        golden_text("exampledata/Tetracycline_resistance.csv.gz"))
+    tree = eval(_json("upgma_cases.json")["exampledata_tree"])
+    index_of = {s: i for i, s in enumerate(strains)}
+    gb = orc.pack_rows(genes)
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        manifest = json.load(f)
+    checked = 0
+    for ti, trait in enumerate(names):
+        rows = list(csv.reader(io.StringIO(files[trait + ".results.csv"])))
+        assert rows[0][18] == "Empirical_p"
+        miss = manifest["prune"][trait]
+        ptree = orc.prune_for_missing(tree, miss + [None]) if miss else tree
+        ops, tips = orc.tree_program(ptree, index_of)
+        tb = orc.pack_rows((traits[ti] == 1)[None].astype(np.uint8))[0]
+        mb = orc.pack_rows((traits[ti] != 2)[None].astype(np.uint8))[0]
+        for d in rows[1:8]:
+            g = ids.index(d[0])
+            obs, ex = orc.tree_permute(ops, tips, gb[g], tb, mb, len(strains), ti, P, seed)
+            assert d[18] == repr(orc.empirical_p_with_abort(ex)), (trait, d[0])
+            checked += 1
+    assert checked >= 5
