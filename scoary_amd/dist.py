@@ -44,9 +44,9 @@ def pack_records(counts, p, odds, r):
     T, Gs = p.shape
     if r is None:
         r = torch.zeros((T, Gs), dtype=torch.int32, device=p.device)
-    return torch.cat([counts.reshape(T, Gs, 4),
-                      p.contiguous().view(torch.int32).view(T, Gs, 2),
-                      odds.contiguous().view(torch.int32).view(T, Gs, 2),
+    def i32(x):
+        return x.reshape(-1).clone().view(torch.int32).view(T, Gs, 2)
+    return torch.cat([counts.reshape(T, Gs, 4), i32(p), i32(odds),
                       r.reshape(T, Gs, 1)], dim=2).contiguous()
 
 
@@ -54,10 +54,11 @@ def unpack_records(rec):
     torch = _torch()
     T, G, _ = rec.shape
     rec = rec.contiguous()
-    return {"counts": rec[:, :, 0:4].contiguous(),
-            "p": rec[:, :, 4:6].contiguous().view(torch.float64).view(T, G),
-            "odds": rec[:, :, 6:8].contiguous().view(torch.float64).view(T, G),
-            "r": rec[:, :, 8].contiguous()}
+    def f64(lo):        # flat copy first: a (1, 1, 2) slice keeps the parent's odd strides
+        return rec[:, :, lo:lo + 2].reshape(-1).clone().view(torch.float64).view(T, G)
+    return {"counts": rec[:, :, 0:4].reshape(-1).clone().view(T, G, 4),
+            "p": f64(4), "odds": f64(6),
+            "r": rec[:, :, 8].reshape(-1).clone().view(T, G)}
 
 
 def is_distributed():

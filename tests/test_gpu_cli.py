@@ -218,15 +218,3 @@ def test_permute_call_site_matches_oracle(exampledir):
                       len(strains), 150, 9)
     assert emp == (float(r[0, 0]) + 1.0) / 151.0
     assert m.Permute(None, gtc, 5, {}) is None
-
-
-def test_pairwise_mode_fails_loudly(exampledir, tmp_path):
-    from scoary_amd import methods as m
-    old = sys.argv
-    sys.argv = ["scoary"] + _inputs(exampledir) + ["-o", str(tmp_path), "--no-time"]
-    try:
-        with pytest.raises(SystemExit) as e:
-            m.main()
-        assert "no_pairwise" in str(e.value.code)
-    finally:
-        sys.argv = old
