@@ -520,6 +520,47 @@ __device__ __forceinline__ void tree_merge(const TreeNode& L, const TreeNode& R,
   out.anti[4] = ba;
 }
 
+// Merge with a Tip of state s (one-hot node, classes.py:575-592): the generic
+// candidate list collapses to
+//   out[c] = L[c]                          for the free states c != s,
+//   out[s] = best of ALL five states of L  (the tip supplies the free path),
+//   out[4] = L[3 - s] + one new pair       (AB|ab supporting, Ab|aB opposing),
+// ~20x fewer VALU ops than tree_merge; about half the merges of a tree are these.
+__device__ __forceinline__ void tree_merge_tip(const TreeNode& L, int s, TreeNode& out) {
+  int bt = -1, bp = -1, ba = -1;
+#pragma unroll
+  for (int x = 0; x < 5; ++x) {
+    if (L.tot[x] > bt) {
+      bt = L.tot[x];
+      bp = L.pro[x];
+      ba = L.anti[x];
+    } else if (L.tot[x] == bt) {
+      bp = max(bp, L.pro[x]);
+      ba = max(ba, L.anti[x]);
+    }
+  }
+  const int cs = 3 - s;
+  int ct = -1, cp = -1, ca = -1;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+    if (x == cs) {
+      ct = L.tot[x];
+      cp = L.pro[x];
+      ca = L.anti[x];
+    }
+  const bool pair = ct > -1;
+  const bool supporting = (s == 0) || (s == 3);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    out.tot[c] = (c == s) ? bt : L.tot[c];
+    out.pro[c] = (c == s) ? bp : L.pro[c];
+    out.anti[c] = (c == s) ? ba : L.anti[c];
+  }
+  out.tot[4] = pair ? ct + 1 : -1;
+  out.pro[4] = pair ? cp + (supporting ? 1 : 0) : -1;
+  out.anti[4] = pair ? ca + (supporting ? 0 : 1) : -1;
+}
+
 __device__ __forceinline__ void tree_tip(TreeNode& n, int state) {
 #pragma unroll
   for (int c = 0; c < 5; ++c) n.tot[c] = n.pro[c] = n.anti[c] = (c == state) ? 0 : -1;
@@ -581,9 +622,8 @@ __global__ __launch_bounds__(64) void k_tree_dp(const int32_t* __restrict__ ops,
         }
         tree_tip(top, state);
       } else {  // merge the top entry with a tip
-        TreeNode t, m;
-        tree_tip(t, state);
-        tree_merge(top, t, m);
+        TreeNode m;
+        tree_merge_tip(top, state, m);
         top = m;
       }
     }
