@@ -1,0 +1,131 @@
+"""VCF (4.x, haploid) -> Roary/Scoary-style presence/absence table.
+
+Mirror of scoary/vcf2scoary.py (reference lines 50-218), the converter that
+produces the input format of BASELINE config 4 ("VCF-derived variants"): one
+output row per ALT allele, the nine fixed VCF columns, a DUMMY column (True for
+rows split out of a multi-allelic site), then one 0/1 genotype cell per sample.
+
+    python -m scoary_amd.vcf2scoary [--out mutations_presence_absence.csv]
+                                    [--types snp,ins,del] [--force] input.vcf
+
+Kept from the reference, on purpose: a missing genotype "." at a bi-allelic
+site is written through unchanged (and therefore reads as *present* in Scoary,
+whose absence markers are "", "0", "-"), while at multi-allelic sites it
+becomes "0" (reference lines 186-189, 204-214).
+"""
+import argparse
+import csv
+import os
+import re
+import sys
+
+__version__ = "0.1b"
+
+STRUCTURED = ("##INFO", "##FILTER", "##FORMAT", "##ALT", "##contig", "##META", "##SAMPLE",
+              "##PEDIGREE")
+_SPLIT_OUTSIDE_QUOTES = re.compile(r',(?=(?:[^"]*"[^"]*")*[^"]*$)')
+
+
+def _quote_row(cells):
+    return ",".join('"' + c + '"' for c in cells) + "\n"
+
+
+def parse_meta(line, meta):
+    key, _, value = line.partition("=")
+    if key in STRUCTURED:
+        ident = re.search(r"ID=(\w+)", value).group(1)
+        entry = {}
+        for item in _SPLIT_OUTSIDE_QUOTES.split(value.strip("<>")):
+            parts = item.split("=")
+            entry[parts[0]] = parts[1]
+        meta.setdefault(key, {})[ident] = entry
+    else:
+        meta[key] = value
+
+
+def allele_row(fields, genotypes, allele):
+    """Genotype cells of one ALT allele of a multi-allelic site."""
+    out = []
+    for g in genotypes:
+        if g == ".":
+            out.append("0")
+        else:
+            try:
+                out.append("1" if int(g) == allele else "0")
+            except ValueError:
+                print(genotypes, allele)
+                sys.exit(-1)
+    return fields + ["True"] + out
+
+
+def convert(vcf_handle, out_handle, types="ALL", log=print):
+    rows = csv.reader(vcf_handle, delimiter="\t", quotechar='"')
+    meta = {k: {} for k in STRUCTURED}
+    header = None
+    for line in rows:
+        if line and line[0][:2] == "##":
+            parse_meta(line[0], meta)
+        else:
+            header = line
+            break
+    if header is None:
+        sys.exit("ERROR: There appears to be only metainformation (lines starting with ##) "
+                 "in your VCF file.")
+    try:
+        version = meta["##fileformat"].split("v")[1]
+        if int(version[0]) != 4:
+            log("WARNING: A VCF format other than 4.x detected. File parsing may proceed "
+                "with errors.")
+        else:
+            log("VCF version %s detected" % version)
+    except (KeyError, IndexError, ValueError, AttributeError):
+        log("WARNING: Could not detect VCF format. Expected v4.x. File parsing may proceed "
+            "with errors.")
+    if meta["##FORMAT"]["GT"]["Number"] != "1":
+        sys.exit("ERROR: Expected a single allele per genotype. Scoary only works for "
+                 "haploid organisms.")
+    out_handle.write(_quote_row(header[:9] + ["DUMMY"] + header[9:]))
+    n = 0
+    for line in rows:
+        if types != "ALL":
+            if re.search(r"TYPE=(\w+)", line[7]).group(1) not in types:
+                continue
+        gts = [cell.split(":")[0] for cell in line[9:]]
+        if "," in line[4]:
+            for k, alt in enumerate(line[4].split(","), start=1):
+                fixed = line[:4] + [alt] + line[5:9]
+                out_handle.write(_quote_row(allele_row(fixed, gts, k)))
+                n += 1
+        else:
+            out_handle.write(_quote_row(line[:9] + ["False"] + gts))
+            n += 1
+    log("Reached the end of the file")
+    return n
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(
+        description="Convert a VCF file into a presence/absence matrix of mutations in the "
+                    "Roary/Scoary format")
+    ap.add_argument("--out", default="./mutations_presence_absence.csv",
+                    help="Output file path")
+    ap.add_argument("--types", default="ALL",
+                    help="Comma-separated variant types to keep (needs TYPE=.. in INFO); "
+                         "ALL keeps everything")
+    ap.add_argument("--version", action="version", version=__version__)
+    ap.add_argument("--force", action="store_true", default=False,
+                    help="Overwrite an existing output file")
+    ap.add_argument("vcf", metavar="<VCF_file>", help="The VCF file to convert")
+    args = ap.parse_args(argv)
+    types = args.types if args.types == "ALL" else args.types.split(",")
+    if os.path.isfile(args.out) and not args.force:
+        sys.exit("Outfile already exists. Change name of outfile or run with --force")
+    if not os.path.isfile(args.vcf):
+        sys.exit("Unable to locate input file %s" % args.vcf)
+    with open(args.vcf, "r", newline=None) as vcf, open(args.out, "w") as out:
+        convert(vcf, out, types)
+    sys.exit(0)
+
+
+if __name__ == "__main__":
+    main()

@@ -214,3 +214,25 @@ def test_cell_formatting_is_shortest_roundtrip():
     assert _fmt(np.float64(1.0862106610751687e-14)) == "1.0862106610751687e-14"
     assert _fmt(float("inf")) == "inf" and _fmt(float("nan")) == "nan" and _fmt(0.0) == "0.0"
     assert _fmt(np.float64(1.0)) == "1.0"
+
+
+# -------------------------------------------------------------- vcf2scoary ---
+def test_vcf2scoary_matches_reference_output(exampledir, tmp_path):
+    """tests/test_scoary_output.py:16-17,123-136 of the reference pins the first
+    row; the whole converted file is compared here (captured from the reference)."""
+    from scoary_amd import vcf2scoary as v
+    out = tmp_path / "mpa.csv"
+    with pytest.raises(SystemExit) as e:
+        v.main(["--force", "--out", str(out), os.path.join(exampledir, "Example.vcf")])
+    assert e.value.code == 0
+    got = out.read_text()
+    assert got == golden_text("exampledata/mutations_presence_absence.csv.gz")
+    first = got.splitlines()[1].replace('"', "").split(",")
+    assert first == ["NC_000962", "4013", "0", "T", "C", "9999", "0", "TYPE=snp", "GT", "False",
+                     "0", "1", "1", "1"]
+    with pytest.raises(SystemExit):                       # refuses to overwrite
+        v.main(["--out", str(out), os.path.join(exampledir, "Example.vcf")])
+    io_out = io.StringIO()
+    with open(os.path.join(exampledir, "Example.vcf")) as f:
+        n = v.convert(f, io_out, types=["ins"], log=lambda *a: None)
+    assert n == 0 and io_out.getvalue().count("\n") == 1
