@@ -1,0 +1,51 @@
+/*
+ * scoary_io.h -- native input codec: gene presence/absence CSV -> bit rows.
+ *
+ * Replaces the per-cell Python loop of Csv_to_dic_Roary
+ * (scoary/methods.py:335-508) for files too large for it:
+ * one streaming pass over the memory-mapped file, Python-csv-compatible
+ * tokenisation (excel dialect + skipinitialspace, as at scoary/methods.py:
+ * 350-351), presence rule "cell not in {'', '0', '-'}" (:476-485), output
+ * directly as rows64 (bit i of word w = kept strain column 64*w+i).
+ * Host-only (no GPU); plain C ABI, bound with ctypes by scoary_amd/io_native.py.
+ */
+#ifndef SCOARY_IO_H
+#define SCOARY_IO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct scoary_gpa *scoary_gpa_t;
+
+/* Parse `path`.  Columns [0, startcol) are kept as text, columns >= startcol
+ * are strains.  keep: NULL, or one byte per strain column (in file order,
+ * length = header cells - startcol) -- non-zero = include that strain.
+ * Because the header must be read before `keep` can be built, parsing is two
+ * calls: scoary_gpa_open reads the header only; scoary_gpa_parse the body.
+ * Return 0 or a negative error; message via scoary_gpa_error. */
+int scoary_gpa_open(const char *path, char delimiter, int64_t startcol, scoary_gpa_t *out);
+int scoary_gpa_parse(scoary_gpa_t g, const uint8_t *keep);
+void scoary_gpa_close(scoary_gpa_t g);
+const char *scoary_gpa_error(scoary_gpa_t g);
+
+/* Header cells: count, total bytes; copy-out as lengths[] + concatenated bytes. */
+int64_t scoary_gpa_header_cells(scoary_gpa_t g);
+int64_t scoary_gpa_header_bytes(scoary_gpa_t g);
+void scoary_gpa_header_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
+
+/* After scoary_gpa_parse: rows, kept strains, words per row. */
+int64_t scoary_gpa_rows(scoary_gpa_t g);
+int64_t scoary_gpa_strains(scoary_gpa_t g);
+int64_t scoary_gpa_words(scoary_gpa_t g);
+/* rows64 [rows][words] */
+void scoary_gpa_bits_copy(scoary_gpa_t g, uint64_t *out);
+/* the text cells of columns [0, startcol) of every row, row-major:
+ * lengths [rows*startcol], bytes concatenated in the same order */
+int64_t scoary_gpa_meta_bytes(scoary_gpa_t g);
+void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

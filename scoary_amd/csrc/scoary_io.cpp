@@ -1,0 +1,271 @@
+// scoary_io.cpp -- streaming gene presence/absence CSV reader (see
+// include/scoary_io.h).  Tokeniser = Python's csv "excel" dialect with
+// skipinitialspace: quote char '"' opens a quoted field only at field start,
+// "" inside quotes is a literal quote, text after a closing quote is appended,
+// line ends \n, \r, \r\n outside quotes, newlines kept inside quotes.
+#include "scoary_io.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct scoary_gpa {
+  int fd = -1;
+  const char* data = nullptr;
+  size_t size = 0, pos = 0;
+  char delim = ',';
+  int64_t startcol = 14;
+  std::string err;
+  std::vector<std::string> header;
+  // body
+  int64_t rows = 0, strains = 0, words = 0;
+  std::vector<uint64_t> bits;
+  std::vector<int32_t> meta_len;
+  std::string meta;
+};
+
+namespace {
+
+// Reads one record starting at g->pos; calls sink(col, ptr, len) with the
+// unquoted content of every cell.  Returns false at end of input.  A state
+// machine equivalent to CPython's _csv reader for the excel dialect with
+// skipinitialspace (text mode: \r\n and \r read as \n, also inside quotes).
+template <class Sink>
+bool read_record(scoary_gpa* g, std::string& scratch, Sink&& sink) {
+  const char* d = g->data;
+  const size_t n = g->size;
+  size_t p = g->pos;
+  if (p >= n) return false;
+  enum { START_RECORD, START_FIELD, IN_FIELD, IN_QUOTED, QUOTE_IN_QUOTED } st = START_RECORD;
+  int64_t col = 0;
+  size_t fstart = 0;      // unquoted field: [fstart, p) is the content
+  bool in_scratch = false;
+  auto is_eol = [&](size_t q) { return d[q] == '\n' || d[q] == '\r'; };
+  auto eat_eol = [&](size_t q) { return (d[q] == '\r' && q + 1 < n && d[q + 1] == '\n') ? q + 2 : q + 1; };
+  auto save = [&](size_t end) {
+    if (in_scratch) sink(col, scratch.data(), scratch.size());
+    else sink(col, d + fstart, end - fstart);
+    ++col;
+    in_scratch = false;
+  };
+  for (;;) {
+    if (p >= n) {                        // end of input acts as an end of line
+      if (st == START_FIELD) { fstart = p; save(p); }
+      else if (st == IN_FIELD || st == QUOTE_IN_QUOTED || st == IN_QUOTED) save(p);
+      g->pos = p;
+      return true;
+    }
+    const char c = d[p];
+    switch (st) {
+      case START_RECORD:
+        if (is_eol(p)) {                 // empty line: a record with no cells
+          g->pos = eat_eol(p);
+          return true;
+        }
+        st = START_FIELD;
+        continue;                        // re-dispatch the same character
+      case START_FIELD:
+        if (is_eol(p)) {
+          fstart = p;
+          save(p);
+          g->pos = eat_eol(p);
+          return true;
+        } else if (c == '"') {
+          scratch.clear();
+          in_scratch = true;
+          st = IN_QUOTED;
+        } else if (c == ' ') {
+          // skipinitialspace
+        } else if (c == g->delim) {
+          fstart = p;
+          save(p);
+        } else {
+          fstart = p;
+          st = IN_FIELD;
+        }
+        ++p;
+        break;
+      case IN_FIELD:
+        if (is_eol(p)) {
+          save(p);
+          g->pos = eat_eol(p);
+          return true;
+        } else if (c == g->delim) {
+          save(p);
+          st = START_FIELD;
+        } else if (in_scratch) {
+          scratch.push_back(c);
+        }
+        ++p;
+        break;
+      case IN_QUOTED:
+        if (c == '"') {
+          st = QUOTE_IN_QUOTED;
+          ++p;
+        } else if (c == '\r') {
+          scratch.push_back('\n');
+          p = eat_eol(p);
+        } else {
+          scratch.push_back(c);
+          ++p;
+        }
+        break;
+      case QUOTE_IN_QUOTED:
+        if (c == '"') {
+          scratch.push_back('"');
+          st = IN_QUOTED;
+          ++p;
+        } else if (c == g->delim) {
+          save(p);
+          st = START_FIELD;
+          ++p;
+        } else if (is_eol(p)) {
+          save(p);
+          g->pos = eat_eol(p);
+          return true;
+        } else {                         // non-strict: keep going as a plain field
+          scratch.push_back(c);
+          st = IN_FIELD;
+          ++p;
+        }
+        break;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int scoary_gpa_open(const char* path, char delimiter, int64_t startcol, scoary_gpa_t* out) {
+  if (!path || !out || startcol < 0) return -1;
+  scoary_gpa* g = new scoary_gpa();
+  *out = g;
+  g->delim = delimiter;
+  g->startcol = startcol;
+  g->fd = ::open(path, O_RDONLY);
+  if (g->fd < 0) {
+    g->err = std::string("cannot open ") + path;
+    return -2;
+  }
+  struct stat st;
+  if (fstat(g->fd, &st) != 0) {
+    g->err = "fstat failed";
+    return -2;
+  }
+  g->size = (size_t)st.st_size;
+  if (g->size == 0) {
+    g->err = "empty file";
+    return -3;
+  }
+  void* m = mmap(nullptr, g->size, PROT_READ, MAP_PRIVATE, g->fd, 0);
+  if (m == MAP_FAILED) {
+    g->err = "mmap failed";
+    return -2;
+  }
+  madvise(m, g->size, MADV_SEQUENTIAL);
+  g->data = static_cast<const char*>(m);
+  std::string scratch;
+  if (!read_record(g, scratch, [&](int64_t, const char* p, size_t n) { g->header.emplace_back(p, n); })) {
+    g->err = "no header";
+    return -3;
+  }
+  if ((int64_t)g->header.size() <= startcol) {
+    g->err = "startcol beyond the header";
+    return -4;
+  }
+  return 0;
+}
+
+int scoary_gpa_parse(scoary_gpa_t g, const uint8_t* keep) {
+  if (!g || !g->data) return -1;
+  const int64_t ncols = (int64_t)g->header.size();
+  const int64_t nstr = ncols - g->startcol;
+  std::vector<int32_t> slot(nstr, -1);  // strain column -> bit index
+  int64_t kept = 0;
+  for (int64_t c = 0; c < nstr; ++c)
+    if (!keep || keep[c]) slot[c] = (int32_t)kept++;
+  g->strains = kept;
+  g->words = (kept + 63) / 64;
+  g->rows = 0;
+  g->bits.clear();
+  g->meta_len.clear();
+  g->meta.clear();
+  std::string scratch;
+  const int64_t sc = g->startcol;
+  for (;;) {
+    const size_t base = g->bits.size();
+    g->bits.resize(base + (size_t)g->words, 0);
+    const size_t meta_base = g->meta_len.size();
+    g->meta_len.resize(meta_base + (size_t)sc, -1);
+    int64_t cells = 0;
+    uint64_t* row = g->bits.data() + base;
+    const bool got = read_record(g, scratch, [&](int64_t col, const char* p, size_t n) {
+      ++cells;
+      if (col < sc) {
+        g->meta_len[meta_base + (size_t)col] = (int32_t)n;
+        g->meta.append(p, n);
+      } else if (col - sc < nstr) {
+        const int32_t b = slot[col - sc];
+        if (b >= 0) {
+          const bool absent = n == 0 || (n == 1 && (p[0] == '0' || p[0] == '-'));
+          if (!absent) row[b >> 6] |= (uint64_t)1 << (b & 63);
+        }
+      }
+    });
+    if (!got) {
+      g->bits.resize(base);
+      g->meta_len.resize(meta_base);
+      break;
+    }
+    if (cells < ncols) {  // the reference indexes q[startcol + strain]: IndexError -> exit
+      g->err = "row " + std::to_string(g->rows + 2) + " has " + std::to_string(cells) +
+               " cells, header has " + std::to_string(ncols);
+      return -5;
+    }
+    ++g->rows;
+  }
+  return 0;
+}
+
+void scoary_gpa_close(scoary_gpa_t g) {
+  if (!g) return;
+  if (g->data) munmap(const_cast<char*>(g->data), g->size);
+  if (g->fd >= 0) ::close(g->fd);
+  delete g;
+}
+
+const char* scoary_gpa_error(scoary_gpa_t g) { return g ? g->err.c_str() : "null handle"; }
+
+int64_t scoary_gpa_header_cells(scoary_gpa_t g) { return (int64_t)g->header.size(); }
+int64_t scoary_gpa_header_bytes(scoary_gpa_t g) {
+  int64_t n = 0;
+  for (auto& s : g->header) n += (int64_t)s.size();
+  return n;
+}
+void scoary_gpa_header_copy(scoary_gpa_t g, int32_t* lengths, char* bytes) {
+  size_t off = 0;
+  for (size_t i = 0; i < g->header.size(); ++i) {
+    lengths[i] = (int32_t)g->header[i].size();
+    std::memcpy(bytes + off, g->header[i].data(), g->header[i].size());
+    off += g->header[i].size();
+  }
+}
+int64_t scoary_gpa_rows(scoary_gpa_t g) { return g->rows; }
+int64_t scoary_gpa_strains(scoary_gpa_t g) { return g->strains; }
+int64_t scoary_gpa_words(scoary_gpa_t g) { return g->words; }
+void scoary_gpa_bits_copy(scoary_gpa_t g, uint64_t* out) {
+  std::memcpy(out, g->bits.data(), g->bits.size() * sizeof(uint64_t));
+}
+int64_t scoary_gpa_meta_bytes(scoary_gpa_t g) { return (int64_t)g->meta.size(); }
+void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t* lengths, char* bytes) {
+  std::memcpy(lengths, g->meta_len.data(), g->meta_len.size() * sizeof(int32_t));
+  std::memcpy(bytes, g->meta.data(), g->meta.size());
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+"""ctypes binding of the native gene presence/absence reader (include/scoary_io.h,
+scoary_amd/csrc/scoary_io.cpp).  Host-only input codec; the Python
+csv path in methods.Csv_to_dic_Roary stays as the reference-shaped fallback for
+handles that are not plain files."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libscoary_io.so")
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        L.scoary_gpa_open.argtypes = [ctypes.c_char_p, ctypes.c_char, i64, ctypes.POINTER(vp)]
+        L.scoary_gpa_parse.argtypes = [vp, vp]
+        L.scoary_gpa_close.argtypes = [vp]
+        L.scoary_gpa_close.restype = None
+        L.scoary_gpa_error.argtypes = [vp]
+        L.scoary_gpa_error.restype = ctypes.c_char_p
+        for name in ("header_cells", "header_bytes", "rows", "strains", "words", "meta_bytes"):
+            f = getattr(L, "scoary_gpa_" + name)
+            f.argtypes = [vp]
+            f.restype = i64
+        for name in ("header_copy", "meta_copy"):
+            f = getattr(L, "scoary_gpa_" + name)
+            f.argtypes = [vp, vp, vp]
+            f.restype = None
+        L.scoary_gpa_bits_copy.argtypes = [vp, vp]
+        L.scoary_gpa_bits_copy.restype = None
+        _lib = L
+    return _lib
+
+
+def _cells(lengths, blob):
+    out, off = [], 0
+    for n in lengths:
+        out.append(blob[off:off + n].decode("utf-8", errors="surrogateescape"))
+        off += n
+    return out
+
+
+class GpaError(Exception):
+    pass
+
+
+def read_gpa(path, delimiter, startcol, allowed=None):
+    """-> (header, meta_rows, rows64, kept_strains): the file's header cells,
+    for every data row the text of columns [0, startcol), the presence bits of
+    the kept strain columns as rows64, and the kept strain names.  ``allowed``:
+    None or a container of isolate names (methods.py:416-420, 473-475)."""
+    L = _load()
+    h = ctypes.c_void_p()
+    rc = L.scoary_gpa_open(os.fsencode(path), delimiter.encode()[0:1], int(startcol),
+                           ctypes.byref(h))
+    try:
+        if rc != 0:
+            raise GpaError((L.scoary_gpa_error(h) or b"open failed").decode())
+        nh = L.scoary_gpa_header_cells(h)
+        lens = np.zeros(nh, dtype=np.int32)
+        blob = ctypes.create_string_buffer(max(1, L.scoary_gpa_header_bytes(h)))
+        L.scoary_gpa_header_copy(h, lens.ctypes.data_as(ctypes.c_void_p), blob)
+        header = _cells(lens, blob.raw)
+        strains = header[startcol:]
+        keep = None
+        if allowed is not None:
+            keep = np.array([1 if s in allowed else 0 for s in strains], dtype=np.uint8)
+        rc = L.scoary_gpa_parse(h, keep.ctypes.data_as(ctypes.c_void_p) if keep is not None
+                                else None)
+        if rc != 0:
+            raise GpaError(L.scoary_gpa_error(h).decode())
+        R, W = L.scoary_gpa_rows(h), L.scoary_gpa_words(h)
+        bits = np.zeros((R, max(W, 0)), dtype=np.uint64)
+        if R and W:
+            L.scoary_gpa_bits_copy(h, bits.ctypes.data_as(ctypes.c_void_p))
+        mlen = np.zeros(R * startcol, dtype=np.int32)
+        mblob = ctypes.create_string_buffer(max(1, L.scoary_gpa_meta_bytes(h)))
+        if R and startcol:
+            L.scoary_gpa_meta_copy(h, mlen.ctypes.data_as(ctypes.c_void_p), mblob)
+        flat = _cells(mlen, mblob.raw)
+        meta = [flat[r * startcol:(r + 1) * startcol] for r in range(R)]
+        kept = [s for k, s in enumerate(strains) if keep is None or keep[k]]
+        return header, meta, bits, kept
+    finally:
+        L.scoary_gpa_close(h)

@@ -224,14 +224,37 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
 
     Returns the reference's dict: "Roarydic" (a GeneTable), "Zero_ones_matrix"
     (strain-major 0/1 lists of the variable genes, for tree building),
-    "Strains", "Extracols", "Firstcolnames"."""
+    "Strains", "Extracols", "Firstcolnames".  Plain files are tokenised by the
+    native streaming reader (scoary_amd/csrc/scoary_io.cpp, same csv dialect);
+    other handles, or --include_input_columns reaching into strain columns, go
+    through Python's csv module."""
     opened = None
     if writereducedset:
         opened = open(ReduceSet(genefile, delimiter, grabcols, startcol, allowed_isolates,
                                 time, outdir), "r", newline=None)
         genefile = opened
-    reader = csv.reader(genefile, skipinitialspace=True, delimiter=delimiter)
-    header = next(reader)
+    from . import io_native
+    path = getattr(genefile, "name", None)
+    native = (io_native.available() and isinstance(path, str) and os.path.isfile(path)
+              and len(delimiter) == 1 and delimiter not in ' "\r\n'
+              and os.environ.get("SCOARY_PY_CSV") != "1"
+              and grabcols != [-999] and all(0 <= c < startcol for c in grabcols))
+    rows_iter = None
+    if native:
+        try:
+            header, meta_rows, bits, kept_native = io_native.read_gpa(
+                path, delimiter, startcol, allowed_isolates)
+        except io_native.GpaError as e:
+            if "startcol" in str(e):
+                sys.exit("The startcol (-s) you have specified does not seem to correspond to "
+                         "any column in your gene presence/absence file.")
+            sys.exit("CRITICAL: Could not read gene presence absence file. Verify that this "
+                     "file is a proper Roary file using the specified delimiter (default is "
+                     "','). [%s]" % e)
+    else:
+        reader = csv.reader(genefile, skipinitialspace=True, delimiter=delimiter)
+        header = next(reader)
+        rows_iter = reader
     if grabcols == [-999]:
         grabcols = list(range(3, len(header)))
     if startcol >= len(header):
@@ -276,40 +299,85 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
         genecol, nugcol, anncol = 0, 1, 2
         firstcolnames = header[0:3]
 
-    index, ids, nugn, ann, rows = {}, [], [], [], []
+    # a repeated identifier replaces the earlier row but keeps its position
+    # (dict overwrite in the reference)
+    index, ids, nugn, ann, source = {}, [], [], [], []
     extra = {header[c] + "_name": [] for c in grabcols}
-    for q in reader:
+    dense_rows = []
+
+    def take(q, r, present):
         try:
             ident = q[genecol] if roary else "_|_".join((q[genecol], q[nugcol], q[anncol]))
-            present = [q[startcol + c] not in ABSENT_CELLS for c in keep]
             meta = (q[nugcol], q[anncol])
+            grabbed = [q[c] for c in grabcols]
         except IndexError:
             sys.exit("CRITICAL: Could not read gene presence absence file. Verify that this "
                      "file is a proper Roary file using the specified delimiter (default is ',').")
-        # a repeated identifier replaces the earlier row but keeps its position
-        # (dict overwrite in the reference)
         if ident in index:
             i = index[ident]
-            nugn[i], ann[i], rows[i] = meta[0], meta[1], present
-            for c in grabcols:
-                extra[header[c] + "_name"][i] = q[c]
+            nugn[i], ann[i], source[i] = meta[0], meta[1], r
+            if present is not None:
+                dense_rows[i] = present
+            for c, v in zip(grabcols, grabbed):
+                extra[header[c] + "_name"][i] = v
         else:
             index[ident] = len(ids)
             ids.append(ident)
             nugn.append(meta[0])
             ann.append(meta[1])
-            rows.append(present)
-            for c in grabcols:
-                extra[header[c] + "_name"].append(q[c])
+            source.append(r)
+            if present is not None:
+                dense_rows.append(present)
+            for c, v in zip(grabcols, grabbed):
+                extra[header[c] + "_name"].append(v)
+
+    if native:
+        for r, q in enumerate(meta_rows):
+            take(q, r, None)
+        rows64 = bits[np.array(source, dtype=np.int64)] if ids else bits[:0]
+        table = GeneTable(ids, nugn, ann, kept_strains, rows64, extra)
+        dense = table.dense()
+    else:
+        for r, q in enumerate(rows_iter):
+            try:
+                present = [q[startcol + c] not in ABSENT_CELLS for c in keep]
+            except IndexError:
+                sys.exit("CRITICAL: Could not read gene presence absence file. Verify that "
+                         "this file is a proper Roary file using the specified delimiter "
+                         "(default is ',').")
+            take(q, r, present)
+        dense = np.array(dense_rows, dtype=np.uint8).reshape(len(ids), len(keep))
+        table = GeneTable(ids, nugn, ann, kept_strains, pack_bits_rows(dense), extra)
     if opened is not None:
         opened.close()
-    dense = np.array(rows, dtype=np.uint8).reshape(len(ids), len(keep))
-    table = GeneTable(ids, nugn, ann, kept_strains, pack_bits_rows(dense), extra)
-    tot = dense.sum(axis=1)
-    variable = (tot > 0) & (tot < dense.shape[1])
-    zero_ones = dense[variable].T.tolist() if len(keep) else []
-    return {"Roarydic": table, "Zero_ones_matrix": zero_ones, "Strains": kept_strains,
+    return {"Roarydic": table, "Zero_ones_matrix": _LazyZeroOnes(dense), "Strains": kept_strains,
             "Extracols": extracols, "Firstcolnames": firstcolnames}
+
+
+class _LazyZeroOnes:
+    """``Zero_ones_matrix`` (methods.py:493-502): strain-major 0/1 lists of the
+    variable genes.  Only the tree builder wants it, so the list-of-lists is
+    built on first use."""
+
+    def __init__(self, dense):
+        self._dense, self._lists = dense, None
+
+    def _get(self):
+        if self._lists is None:
+            d = self._dense
+            tot = d.sum(axis=1) if d.size else np.zeros(0)
+            var = (tot > 0) & (tot < d.shape[1])
+            self._lists = d[var].T.tolist() if d.shape[1] else []
+        return self._lists
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __len__(self):
+        return len(self._get())
+
+    def __getitem__(self, k):
+        return self._get()[k]
 
 
 def ReduceSet(genefile, delimiter, grabcols, startcol=14, allowed_isolates=None, time="",

@@ -236,3 +236,94 @@ def test_vcf2scoary_matches_reference_output(exampledir, tmp_path):
     with open(os.path.join(exampledir, "Example.vcf")) as f:
         n = v.convert(f, io_out, types=["ins"], log=lambda *a: None)
     assert n == 0 and io_out.getvalue().count("\n") == 1
+
+
+# ------------------------------------------------------- native GPA reader ---
+def _py_cells(text, delimiter=","):
+    import csv
+    return list(csv.reader(io.StringIO(text, newline=None) if False else io.StringIO(text),
+                           skipinitialspace=True, delimiter=delimiter))
+
+
+TRICKY = [
+    'Gene,x,y,S1,S2,S3\ng1,a,b,1,0,\ng2,"q,1","say ""hi""",, - ,2\n',
+    'Gene,x,y,S1,S2\r\ng1,a,b,grp_1,\r\n"g 2", a ,b,"0","-"\r\n',
+    'Gene,x,y,S1,S2\ng1,"multi\nline",b,1,1\ng2,a,"b"tail,0,1',          # no trailing newline
+    'Gene;x;y;S1;S2\ng1;a;b;1;0\ng2;;;;\n',
+    'Gene,x,y,S1,S2\ng1,a,b,   1,   0\ng2,a,b,"",  "-"\n',
+    'Gene,x,y,S1,S2\ng1,a,b,00,--\ng2,a,b,0 ,-x\n',
+]
+
+
+@pytest.mark.parametrize("k", range(len(TRICKY)))
+def test_native_reader_tokenises_like_python_csv(tmp_path, k):
+    from scoary_amd import io_native
+    if not io_native.available():
+        import __graft_entry__
+        __graft_entry__.build()
+    text = TRICKY[k]
+    delim = ";" if k == 3 else ","
+    path = tmp_path / "g.csv"
+    path.write_bytes(text.encode())
+    with open(path, "r", newline=None) as f:                 # universal newlines like "rU"
+        import csv
+        rows = list(csv.reader(f, skipinitialspace=True, delimiter=delim))
+    header, meta, bits, kept = io_native.read_gpa(str(path), delim, 3)
+    assert header == rows[0]
+    assert meta == [r[:3] for r in rows[1:]]
+    want = np.array([[c not in ("", "0", "-") for c in r[3:]] for r in rows[1:]], dtype=np.uint8)
+    got = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :want.shape[1]]
+    assert np.array_equal(got, want)
+    assert kept == rows[0][3:]
+
+
+def test_native_reader_errors_and_restriction(tmp_path):
+    from scoary_amd import io_native
+    p = tmp_path / "g.csv"
+    p.write_text("Gene,x,y,S1,S2,S3\ng1,a,b,1,0,1\ng2,a,b,1\n")
+    with pytest.raises(io_native.GpaError):
+        io_native.read_gpa(str(p), ",", 3)                   # short row
+    p.write_text("Gene,x,y,S1,S2,S3\ng1,a,b,1,0,1\n\ng2,a,b,1,1,1\n")
+    with pytest.raises(io_native.GpaError):
+        io_native.read_gpa(str(p), ",", 3)                   # blank line = empty record
+    with pytest.raises(io_native.GpaError):
+        io_native.read_gpa(str(p), ",", 6)                   # startcol beyond header
+    p.write_text("Gene,x,y,S1,S2,S3\ng1,a,b,1,0,1\ng2,a,b,0,1,1\n")
+    header, meta, bits, kept = io_native.read_gpa(str(p), ",", 3, allowed={"S3", "S1"})
+    assert kept == ["S1", "S3"] and bits[:, 0].tolist() == [3, 2]
+
+
+def test_native_and_python_readers_build_the_same_table(exampledir, monkeypatch):
+    from scoary_amd import methods as m
+    path = os.path.join(exampledir, "Gene_presence_absence.csv")
+    with open(path) as f:
+        a = m.Csv_to_dic_Roary(f, ",", [3, 5], startcol=14)
+    monkeypatch.setenv("SCOARY_PY_CSV", "1")
+    with open(path) as f:
+        b = m.Csv_to_dic_Roary(f, ",", [3, 5], startcol=14)
+    ta, tb = a["Roarydic"], b["Roarydic"]
+    assert ta.ids == tb.ids and ta.nugn == tb.nugn and ta.annotation == tb.annotation
+    assert np.array_equal(ta.rows64, tb.rows64) and ta.extra == tb.extra
+    assert a["Extracols"] == b["Extracols"] == ["No. isolates", "Avg sequences per isolate"]
+    assert list(a["Zero_ones_matrix"]) == list(b["Zero_ones_matrix"])
+    # duplicate identifiers (non-Roary files): later row wins, earlier position kept
+    vcf = os.path.join(exampledir, "mutations_presence_absence.csv")
+    monkeypatch.delenv("SCOARY_PY_CSV")
+    with open(vcf) as f:
+        c = m.Csv_to_dic_Roary(f, ",", [], startcol=10)
+    monkeypatch.setenv("SCOARY_PY_CSV", "1")
+    with open(vcf) as f:
+        d = m.Csv_to_dic_Roary(f, ",", [], startcol=10)
+    assert c["Roarydic"].ids == d["Roarydic"].ids
+    assert np.array_equal(c["Roarydic"].rows64, d["Roarydic"].rows64)
+
+
+def test_io_library_exports_every_declared_symbol():
+    from scoary_amd import io_native
+    with open(os.path.join(ROOT, "include", "scoary_io.h")) as f:
+        src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(scoary_gpa_[a-z_]+)\s*\(", src)))
+    lib = ctypes.CDLL(io_native.LIB_PATH)
+    assert len(names) == 13
+    for n in names:
+        assert hasattr(lib, n), n
