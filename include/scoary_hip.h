@@ -180,6 +180,14 @@ int scoary_tree_permute(scoary_handle h, const int32_t *d_ops, int64_t nops,
                         const uint32_t *d_label_bits, int64_t G, int64_t L, int64_t K,
                         const int32_t *d_obs, uint8_t *d_exceed, scoary_stream_t stream);
 
+/* ---- --collapse: presence-pattern identity, scoary/methods.py:816-840, :981
+ * 128-bit hash of every gene's presence pattern restricted to each trait's
+ * valid isolates (row AND mask):  d_out uint64 [T][G][2].  Equal patterns give
+ * equal hashes; the host groups by hash and confirms equality on the bit rows,
+ * so a collision can cost time but never correctness. */
+int scoary_row_hash(scoary_handle h, const uint32_t *d_tiled, const uint32_t *d_masks,
+                    int64_t G, int64_t T, int64_t N, uint64_t *d_out, scoary_stream_t stream);
+
 /* Name + average device time (ms, hipEvent on `stream`) of the kernels the
  * last scoary_permute call launched; for bench.py's roofline line.  Costs a
  * stream sync; timing is recorded only after scoary_set_timing(h, 1). */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "scoary_tree_pairs": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "scoary_tree_permute": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
                                    _vp]),
+    "scoary_row_hash": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "scoary_set_timing": (_i32, [_vp, _i32]),
     "scoary_last_kernel_ms": (_i32, [_vp, _cp, ctypes.POINTER(ctypes.c_double)]),
 }

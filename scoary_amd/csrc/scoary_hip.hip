@@ -467,6 +467,40 @@ __global__ __launch_bounds__(256) void k_gather_bits(const uint32_t* __restrict_
 }
 
 // ----------------------------------------------------------------------------
+// f-4: presence-pattern hash for --collapse
+// ----------------------------------------------------------------------------
+// Two independent 64-bit multiply-xorshift chains over the masked words of a
+// gene row (lane = gene, mask words wave-uniform).
+__device__ __forceinline__ uint64_t mix64(uint64_t h, uint32_t w, uint64_t k) {
+  h ^= (uint64_t)w + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+  h *= k;
+  return h ^ (h >> 29);
+}
+
+__global__ __launch_bounds__(256) void k_row_hash(const uint4* __restrict__ tiled,
+                                                  const uint32_t* __restrict__ masks, int G, int Gp,
+                                                  int Qp, uint64_t* __restrict__ out) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.y;
+  const uint4* mrow = reinterpret_cast<const uint4*>(masks + (int64_t)t * Qp * 4);
+  uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull;
+  for (int q = 0; q < Qp; ++q) {
+    const uint4 gw = tiled[(int64_t)q * Gp + g];
+    const uint4 m = mrow[q];
+    const uint32_t w[4] = {gw.x & m.x, gw.y & m.y, gw.z & m.z, gw.w & m.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h0 = mix64(h0, w[j], 0xBF58476D1CE4E5B9ull);
+      h1 = mix64(h1, w[j] ^ 0x5bd1e995u, 0x94D049BB133111EBull);
+    }
+  }
+  if (g < G) {
+    out[((int64_t)t * G + g) * 2] = h0;
+    out[((int64_t)t * G + g) * 2 + 1] = h1;
+  }
+}
+
+// ----------------------------------------------------------------------------
 // f-1: maximum contrasting pairs on a tree (PhyloTree, scoary/classes.py:199-592)
 // ----------------------------------------------------------------------------
 // State index 0 = AB, 1 = Ab, 2 = aB, 3 = ab, 4 = "0" (no free path); per state
@@ -993,6 +1027,23 @@ int scoary_tree_permute(scoary_handle h, const int32_t* d_ops, int64_t nops, int
                         scoary_stream_t stream) {
   return launch_tree(h, "scoary_tree_permute", true, d_ops, nops, stack_depth, d_gene_bits,
                      d_label_bits, G, L, K, d_obs, nullptr, d_exceed, stream);
+}
+
+int scoary_row_hash(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_masks, int64_t G,
+                    int64_t T, int64_t N, uint64_t* d_out, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_masks || !d_out || G < 1 || T < 1 || N < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_row_hash: bad argument");
+  if (T > 65535) return fail(h, SCOARY_ERR_SIZE, "scoary_row_hash: T > 65535");
+  DeviceGuard guard(h->device);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_row_hash");
+  hipLaunchKernelGGL(k_row_hash, dim3((unsigned)(Gp / 256), (unsigned)T), dim3(256), 0, s,
+                     reinterpret_cast<const uint4*>(d_tiled), d_masks, (int)G, (int)Gp, (int)Qp,
+                     d_out);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
 }
 
 int scoary_set_timing(scoary_handle h, int enabled) {

@@ -209,6 +209,18 @@ class AssociationEngine:
                 done += nb
         return {"counts": counts, "margins": margins, "p": p, "odds": odds, "crit": crit, "r": r}
 
+    # -- --collapse support -----------------------------------------
+    def row_hash(self, genes, masks):
+        """(T, G, 2) uint64 numpy: 128-bit hash of every gene row AND each
+        trait's validity mask."""
+        torch = _torch()
+        T = masks.shape[0]
+        out = self._empty((T, genes.G, 2), torch.int64)
+        self._check(self.lib.scoary_row_hash(self.h, self._ptr(genes.tiled), self._ptr(masks),
+                                             genes.G, T, genes.N, self._ptr(out), self._stream()),
+                    "scoary_row_hash")
+        return out.cpu().numpy().view(np.uint64)
+
     # -- population-structure stage (SURVEY 8f) ----------------------------------
     def hamming(self, rows01):
         """rows01: (R, N) 0/1 numpy (rows = isolates, columns = variable genes)

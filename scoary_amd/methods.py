@@ -499,6 +499,30 @@ def bonferroni_bh(p_sorted_input, number_of_tests):
     return np.minimum(p * number_of_tests, 1.0), np.minimum(bh, 1.0)
 
 
+def _pattern_groups(table, maskrow, idx, hashes):
+    """Group id per tested gene (``idx``): equal ids <=> identical presence
+    pattern over the trait's valid isolates.  ``hashes``: (G, 2) uint64 from the
+    device (scoary_row_hash); candidate groups are confirmed on the bit rows,
+    so a hash collision only costs a second pass."""
+    keyed = None
+    if hashes is not None:
+        h = hashes[idx]
+        _, inv = np.unique(h, axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        # confirm: within a hash group every row must equal the group's first row
+        order = np.argsort(inv, kind="stable")
+        gs = inv[order]
+        first = np.nonzero(np.r_[True, gs[1:] != gs[:-1]])[0]
+        rep = order[np.repeat(first, np.diff(np.r_[first, len(gs)]))]
+        keyed = table.rows64[idx] & maskrow[None, :]
+        if np.array_equal(keyed[order], keyed[rep]):
+            return inv
+    if keyed is None:
+        keyed = table.rows64[idx] & maskrow[None, :]
+    _, inv = np.unique(keyed, axis=0, return_inverse=True)
+    return inv.reshape(-1)
+
+
 def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED):
     """Whole hot path for all traits; under torchrun (world > 1) every rank
     takes a contiguous gene shard and the per-gene records are all-gathered
@@ -531,6 +555,12 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
     table = _as_table(genedic)
     names, tarr = _trait_arrays(traitsdic, table.strains)
     dev = _associate(table, tarr, permutations if permutations >= 10 else 0, seed)
+    collapse_hashes = None
+    if collapse:
+        eng = get_engine()
+        N = len(table.strains)
+        collapse_hashes = eng.row_hash(table.on_device(eng),
+                                       eng.vecrows(pack_bits_rows(tarr != 2), N))
     all_traits, combos = {}, {}
     G = len(table)
     for t, trait in enumerate(names):
@@ -552,36 +582,33 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
             bh_rank_p = plist
         else:
             # identical presence pattern over the trait's valid isolates => one
-            # merged unit (methods.py:816-840); the merged unit moves to the end
-            # of the insertion order and keeps the LAST member's statistics.
+            # merged unit (methods.py:816-840).  In the reference's dict
+            # bookkeeping a unit is re-inserted (at the end) whenever it absorbs a
+            # gene and takes that gene's statistics, so: unit order = ascending
+            # index of its LAST member; name / NUGN / annotation = members joined
+            # by "--" in file order; statistics of the last member.
             maskrow = pack_bits_rows((tarr[t:t + 1] != 2))[0]
-            keyed = (table.rows64 & maskrow[None, :])
-            units, by_hash, appended = {}, {}, []          # name -> (members), hash -> name
-            for i in idx:
-                h = keyed[i].tobytes()
-                g = table.ids[i]
-                if h in by_hash:
-                    old = by_hash[h]
-                    new = old + "--" + g
-                    units[new] = units.pop(old) + [i]
-                    by_hash[h] = new
-                    number_of_tests -= 1
-                    appended.append((new, p_all[i]))
-                else:
-                    by_hash[h] = g
-                    units[g] = [i]
-                    appended.append((g, p_all[i]))
-            names_out = list(units.keys())
-            members_idx = [units[k] for k in names_out]
+            group = _pattern_groups(table, maskrow, idx, collapse_hashes[t] if
+                                    collapse_hashes is not None else None)
+            order_g = np.argsort(group, kind="stable")           # members stay in file order
+            gs = group[order_g]
+            starts = np.nonzero(np.r_[True, gs[1:] != gs[:-1]])[0]
+            ends = np.r_[starts[1:], len(gs)]
+            last_pos = order_g[ends - 1]                         # position (in idx) of last member
+            unit_order = np.argsort(last_pos, kind="stable")
+            members_idx = [idx[order_g[starts[u]:ends[u]]].tolist() for u in unit_order]
+            number_of_tests -= int(len(idx) - len(starts))
             rows_idx = np.array([m[-1] for m in members_idx], dtype=np.int64)
             members = [[table.ids[i] for i in m] for m in members_idx]
+            names_out = ["--".join(m) for m in members]
             nugn = ["--".join(table.nugn[i] for i in m) for m in members_idx]
             ann = ["--".join(table.annotation[i] for i in m) for m in members_idx]
             plist = p_all[rows_idx]
-            # the reference's p_value_list keeps the superseded names
-            # (methods.py:873/892), so BH ranks count them
-            bh_rank_p = np.array([p for _, p in appended], dtype=np.float64)
-            bh_names = [n for n, _ in appended]
+            # the reference's p_value_list keeps one entry per tested gene,
+            # superseded names included (methods.py:873/892), so BH ranks count
+            # them; a unit's BH is that of its last member's entry
+            bh_rank_p = p_all[idx]
+            bh_entry = last_pos[unit_order]
 
         cc = c[rows_idx]
         num_pos = (cc[:, 0] + cc[:, 1]).astype(np.float64)
@@ -595,10 +622,7 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
             B, BH = bonferroni_bh(plist, number_of_tests)
         else:
             _, bh_all = bonferroni_bh(bh_rank_p, number_of_tests)
-            last = {}
-            for k, n in enumerate(bh_names):
-                last[n] = bh_all[k]              # later entries overwrite (dict semantics)
-            BH = np.array([last[n] for n in names_out], dtype=np.float64)
+            BH = bh_all[bh_entry]
             B = np.minimum(plist * number_of_tests, 1.0)
         cols = {"tpgp": cc[:, 0], "tngp": cc[:, 2], "tpgn": cc[:, 1], "tngn": cc[:, 3],
                 "sens": sens, "spes": spes, "OR": or_all[rows_idx], "p_v": plist,

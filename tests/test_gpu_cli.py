@@ -218,3 +218,38 @@ def test_permute_call_site_matches_oracle(exampledir):
                       len(strains), 150, 9)
     assert emp == (float(r[0, 0]) + 1.0) / 151.0
     assert m.Permute(None, gtc, 5, {}) is None
+
+
+def test_collapse_device_hash_equals_exact_grouping(monkeypatch):
+    """--collapse grouping from the device hash (scoary_row_hash) == exact
+    grouping on the bit rows, incl. chains of 3+ identical genes, genes that
+    differ only at missing isolates, and the reference's ordering rules."""
+    from scoary_amd import methods as m
+    rng = np.random.default_rng(3)
+    G, N = 400, 70
+    genes = (rng.random((G, N)) < 0.5).astype(np.uint8)
+    genes[10] = genes[3]; genes[200] = genes[3]; genes[57] = genes[56]
+    genes[300] = genes[299]; genes[300, 5] ^= 1        # differs only at isolate 5
+    strains = ["s%d" % i for i in range(N)]
+    genedic = {"g%d" % i: dict({"Non-unique Gene name": "n%d" % i, "Annotation": "a%d" % i},
+                               **{s: int(genes[i, j]) for j, s in enumerate(strains)})
+               for i in range(G)}
+    t0 = {s: str(int(rng.random() < 0.4)) for s in strains}
+    t1 = {s: v for s, v in t0.items() if s != "s5"}    # isolate 5 missing for trait 1
+    res = m.Setup_results(genedic, {"full": t0, "holes": t1}, True)
+    names0 = list(res["Results"]["full"])
+    assert "g3--g10--g200" in names0 and "g56--g57" in names0 and "g299--g300" not in names0
+    assert names0[-1] == "g3--g10--g200" or names0.index("g3--g10--g200") > names0.index("g199")
+    names1 = list(res["Results"]["holes"])
+    assert "g299--g300" in names1                       # identical once isolate 5 is masked
+    r = res["Results"]["full"]["g3--g10--g200"]
+    assert r["NUGN"] == "n3--n10--n200" and r["Annotation"] == "a3--a10--a200"
+    # exact grouping (no hashes) gives the same thing
+    monkeypatch.setattr(m, "_pattern_groups",
+                        lambda table, maskrow, idx, hashes, _f=m._pattern_groups:
+                        _f(table, maskrow, idx, None))
+    res2 = m.Setup_results(genedic, {"full": t0, "holes": t1}, True)
+    for tr in ("full", "holes"):
+        assert list(res2["Results"][tr]) == list(res["Results"][tr])
+        assert np.array_equal(res2["Results"][tr].column("BH_p"), res["Results"][tr].column("BH_p"))
+        assert res2["Results"][tr].number_of_tests == res["Results"][tr].number_of_tests
