@@ -13,8 +13,8 @@ HBM.  tests per step = G*T*P per GPU.
 Multi-GPU: genes shard across ranks (every rank holds its own G-gene shard of a
 G*N-gene matrix: weak scaling); trait / permutation vectors are regenerated
 identically on every rank from the seed (no broadcast); the one exchange step
-of the path -- gathering per-gene results -- is an RCCL all_gather inside the
-timed region.
+of the path -- gathering per-gene results on rank 0 -- is an RCCL gather inside
+the timed region (asynchronous, overlapped with the next step's kernels).
 
 Prints ONE JSON line (rank 0).
 """
@@ -138,16 +138,35 @@ def main():
     perm_buf = torch.empty((T, pbatch, eng.row_words(N)), dtype=torch.int32, device=eng.device)
     from scoary_amd import dist as sdist
 
+    # The path's one exchange step: the per-gene records of every shard are
+    # gathered on rank 0 over RCCL/xGMI (north_star: "only an RCCL gather of
+    # per-gene results").  It is issued asynchronously and drained before its
+    # buffers are reused, so step i's gather overlaps step i+1's kernels; every
+    # gather has completed before the closing barrier of the timed region.
+    pending = []
+    recv_bufs = [None, None]
+    if world > 1 and rank == 0:
+        recv_bufs = [torch.empty((world, T, G, sdist.REC_WORDS), dtype=torch.int32,
+                                 device=eng.device) for _ in range(2)]
+    step_no = [0]
+
+    def drain(keep=0):
+        while len(pending) > keep:
+            pending.pop(0)()
+
     def step():
         res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, perm_buffer=perm_buf)
         if world > 1:
-            # the path's one exchange step: per-gene records of every shard to
-            # every rank (RCCL all_gather over xGMI), same code as the CLI uses
+            drain(keep=1)
             rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
-            res["gathered"] = sdist.all_gather_genes(rec, G * world)
+            _, finish = sdist.gather_genes(rec, G * world, dst=0, async_op=True,
+                                           recv=recv_bufs[step_no[0] % 2])
+            pending.append(finish)
+            step_no[0] += 1
         return res
 
     def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

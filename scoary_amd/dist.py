@@ -120,9 +120,43 @@ def all_gather_genes(rec_local, G, group=None):
     return torch.cat(parts, dim=1).contiguous()
 
 
+def gather_genes(rec_local, G, dst=0, group=None, async_op=False, recv=None):
+    """The path's one exchange step as a true gather: every rank sends its
+    [T, Gs, W] block to ``dst`` only (1/world of an all_gather's traffic; over
+    xGMI each sender uses its own link to dst).  Returns (work, finish) where
+    finish() -> the full [T, G, W] tensor on dst, None elsewhere."""
+    torch = _torch()
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bounds = shard_bounds(G, world)
+    T, Gs, W = rec_local.shape
+    cap = max_shard(G, world)
+    send = rec_local
+    if Gs != cap:
+        send = torch.zeros((T, cap, W), dtype=rec_local.dtype, device=rec_local.device)
+        send[:, :Gs] = rec_local
+    send = send.contiguous()
+    parts = None
+    if rank == dst:
+        if recv is None:
+            recv = torch.empty((world, T, cap, W), dtype=rec_local.dtype, device=rec_local.device)
+        parts = [recv[r] for r in range(world)]
+    work = dist.gather(send, parts, dst=dst, group=group, async_op=async_op)
+
+    def finish():
+        if work is not None and async_op:
+            work.wait()
+        if rank != dst:
+            return None
+        return torch.cat([recv[r, :, :b - a] for r, (a, b) in enumerate(bounds)],
+                         dim=1).contiguous()
+    return work, finish
+
+
 def associate_sharded(local_compute, G, group=None):
     """Run ``local_compute(start, stop) -> int32 records [T, stop-start, 9]`` on
-    this rank's gene shard and gather the records of all ranks."""
+    this rank's gene shard and gather the records of all ranks (every rank gets
+    the full result: the host-side B/BH needs the globally sorted p)."""
     world, rank = world_rank()
     if world == 1:
         return local_compute(0, G)

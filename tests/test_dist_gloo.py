@@ -113,3 +113,39 @@ def test_record_pack_roundtrip():
     d = sd.unpack_records(sd.pack_records(c, p, o, r))
     assert torch.equal(d["counts"], c) and torch.equal(d["p"], p) and torch.equal(d["r"], r)
     assert torch.equal(d["odds"].view(torch.int64), o.view(torch.int64))   # bit pattern, nan incl.
+
+
+def _gather_worker(rank, world, port, outq):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from scoary_amd import dist as sd
+    sd.init_from_env()
+    G, T = 11, 2
+    a, b = sd.shard_bounds(G, world)[rank]
+    full = torch.arange(T * G * sd.REC_WORDS, dtype=torch.int32).view(T, G, sd.REC_WORDS)
+    outs = []
+    for async_op in (False, True):
+        _, finish = sd.gather_genes(full[:, a:b].contiguous(), G, dst=0, async_op=async_op)
+        outs.append(finish())
+    outq.put((rank, [None if o is None else o.numpy() for o in outs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_to_rank0_gloo():
+    """bench.py's exchange step: a true gather (uneven shards), sync and async."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.arange(2 * 11 * 9, dtype=np.int32).reshape(2, 11, 9)
+    assert all(np.array_equal(o, want) for o in got[0])
+    assert got[1] == [None, None] and got[2] == [None, None]
