@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+LISTS_DEFAULT = False        # flipped once the list-driven kernel wins on the headline config
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (upper bound)
 
@@ -43,6 +44,8 @@ def parse():
     ap.add_argument("--genes", type=int, default=None, help="override G (per GPU)")
     ap.add_argument("--permutations", type=int, default=None, help="override P")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "dense", "lists"],
+                    help="permutation kernel: dense (k_permute_reg/chunked) or list-driven")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -134,6 +137,10 @@ def main():
     gm = eng.pack_dense(genes)                     # bit-packed once into HBM
     trv = eng.vecrows(pack_bits_rows((traits == 1).astype(np.uint8)), N)
     mkv = eng.vecrows(pack_bits_rows((traits != 2).astype(np.uint8)), N)
+    use_lists = args.kernel == "lists" or (args.kernel == "auto" and LISTS_DEFAULT
+                                           and eng.lists_supported(N))
+    if use_lists:
+        eng.build_lists(gm, pack_bits_rows(genes))    # once per dataset, like the packing
     pbatch = eng.perm_batch(T, N, P)
     perm_buf = torch.empty((T, pbatch, eng.row_words(N)), dtype=torch.int32, device=eng.device)
     from scoary_amd import dist as sdist
@@ -155,7 +162,8 @@ def main():
             pending.pop(0)()
 
     def step():
-        res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, perm_buffer=perm_buf)
+        res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, perm_buffer=perm_buf,
+                            use_lists=use_lists)
         if world > 1:
             drain(keep=1)
             rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
@@ -180,9 +188,12 @@ def main():
         res = step()
     barrier()
     dt = time.perf_counter() - t0
-    k3_ms = eng.kernel_ms("k_permute")
-    kernel_ms = {k: eng.kernel_ms(k) for k in
-                 ("k_margins", "k_counts", "k_fisher", "k_perm_generate", "k_permute")}
+    k3_name = "k_permute_lists" if use_lists else "k_permute"
+    k3_ms = eng.kernel_ms(k3_name)
+    names = ("k_margins", "k_counts", "k_fisher") + (
+        ("k_perm_generate_tiles", "k_lists_crit", "k_permute_lists") if use_lists else
+        ("k_perm_generate", "k_permute"))
+    kernel_ms = {k: eng.kernel_ms(k) for k in names}
     eng.set_timing(False)
 
     if world > 1:
@@ -223,7 +234,7 @@ def main():
                        "parallelism": "gene-shard x%d" % world},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_permute",
+                "kernel": k3_name,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -129,6 +129,32 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
                    int64_t T, int64_t N, int64_t P, uint32_t *d_r,
                    scoary_stream_t stream);
 
+/* ---- a7/a8, list-driven variant -------------------------------------------
+ * Same result as scoary_perm_generate + scoary_permute (d_r is bit-identical),
+ * different data flow: genes as ascending lists of the isolates that carry
+ * their minority value (built once per dataset by scoary_lists_build,
+ * include/scoary_io.h), permuted labels as isolate-major tiles of 512
+ * permutations that live in LDS, overlap counts as bit-sliced counters.  Cost
+ * is proportional to the list length, so sparse (or near-core) genes are
+ * cheap.  Available while a tile fits in LDS: N <= scoary_list_max_isolates().
+ *   d_tiles : uint32 [scoary_list_tiles_words(N, P, T)]
+ *   d_lidx / d_lstart / d_lngroups / d_lorder / d_lflipped : scoary_lists_build
+ *             output (row stride = scoary_list_row_stride()), copied to the GPU
+ *   d_lcrit : scratch, uint32 [T][G][2] */
+int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T);
+int64_t scoary_list_row_stride(void);
+int64_t scoary_list_max_isolates(void);
+int scoary_perm_generate_tiles(scoary_handle h, const uint32_t *d_masks,
+                               const int32_t *d_margins, int64_t T, int64_t N, int64_t P,
+                               int64_t perm_base, int64_t trait_base, uint64_t seed,
+                               uint32_t *d_tiles, scoary_stream_t stream);
+int scoary_permute_lists(scoary_handle h, const uint32_t *d_tiles, const uint32_t *d_lidx,
+                         const int32_t *d_lstart, const int32_t *d_lngroups,
+                         const int32_t *d_lorder, const uint8_t *d_lflipped,
+                         const uint32_t *d_crit, const int32_t *d_margins, uint32_t *d_lcrit,
+                         int64_t G, int64_t T, int64_t N, int64_t P, uint32_t *d_r,
+                         scoary_stream_t stream);
+
 /* ======================================================================
  * Population-structure stage
  * ====================================================================== */

@@ -45,6 +45,26 @@ void scoary_gpa_bits_copy(scoary_gpa_t g, uint64_t *out);
 int64_t scoary_gpa_meta_bytes(scoary_gpa_t g);
 void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
 
+/* ---- minority index lists for the list-driven permutation kernel ----------
+ * (scoary_permute_lists, include/scoary_hip.h).  For every gene row of a
+ * rows64 matrix [G][W64] over N isolates: the ascending positions of its
+ * MINORITY value (ones if popcount <= N/2, else zeros; flipped[g] = 1 in the
+ * latter case), padded to a multiple of 8 entries with the value N (an
+ * all-zero row on the device).  Lists are laid out back to back in `order`:
+ * genes sorted by descending list length, so that the four genes a wavefront
+ * processes together have similar lengths.
+ *   first call  : scoary_lists_count -> total number of entries
+ *   second call : scoary_lists_build fills
+ *       idx     uint32 [total]   entry = position * row_stride_dwords
+ *       start   int32  [G]       first entry of gene order[k], in groups of 8
+ *       ngroups int32  [G]       groups of 8 of gene order[k]
+ *       order   int32  [G]       gene id of slot k
+ *       flipped uint8  [G]       per gene id */
+int64_t scoary_lists_count(const uint64_t *rows64, int64_t G, int64_t N);
+void scoary_lists_build(const uint64_t *rows64, int64_t G, int64_t N, int64_t row_stride_dwords,
+                        uint32_t *idx, int32_t *start, int32_t *ngroups, int32_t *order,
+                        uint8_t *flipped);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,12 @@ SIGNATURES = {
     "scoary_fisher": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "scoary_perm_generate": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp, _vp]),
     "scoary_permute": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "scoary_list_tiles_words": (_i64, [_i64, _i64, _i64]),
+    "scoary_list_row_stride": (_i64, []),
+    "scoary_list_max_isolates": (_i64, []),
+    "scoary_perm_generate_tiles": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp,
+                                          _vp]),
+    "scoary_permute_lists": (_i32, [_vp] * 10 + [_i64, _i64, _i64, _i64, _vp, _vp]),
     "scoary_hamming": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "scoary_gather_bits": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "scoary_tree_pairs": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),

@@ -409,6 +409,243 @@ __global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict_
 }
 
 
+
+// ----------------------------------------------------------------------------
+// a7 (list-driven variant): permutation exceedance counts from minority lists
+// ----------------------------------------------------------------------------
+// The dense kernel (k_permute_reg) pays 2 VALU ops per 32 isolates whatever the
+// gene looks like.  Here the roles are swapped: a gene is the ascending list of
+// isolates carrying its MINORITY value (scoary_lists_build), the permuted
+// labels are stored isolate-major in tiles of LG*32 permutations that live in
+// LDS, and a gene's overlap count with 32 permutations at once is a
+// bit-sliced ("vertical") counter: every listed isolate adds one LDS row word
+// into KC counter planes through v_bitop3 full adders (sum = a^b^c,
+// carry = maj(a,b,c)).  Cost ~3.5 VALU ops per listed isolate per 32
+// permutations instead of 2 ops per 32 isolates per permutation, i.e.
+// ~0.11 * |list| ops per test versus 0.0625 * N * 2: a gene present in 26 %
+// of 2000 isolates costs 57 ops per test instead of 137, a rare variant ~20x less.
+// A wavefront = 64/LG lane groups = 64/LG genes of similar list length.
+constexpr int kListLG = 16;           // lanes (32-permutation words) per gene
+constexpr int kListRS = kListLG + 1;  // LDS row stride in dwords (+1: bank spread)
+
+__device__ __forceinline__ uint32_t bit_xor3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t bit_maj(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe8" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// c += x + y at bit-plane weight 1: returns the carry (weight 2)
+__device__ __forceinline__ uint32_t full_add(uint32_t& c, uint32_t x, uint32_t y) {
+  const uint32_t carry = bit_maj(c, x, y);
+  c = bit_xor3(c, x, y);
+  return carry;
+}
+
+// Isolate-major label tiles: tiles[t][tile][row 0..N][kListRS] dwords, row N all
+// zero; dword j of a row = labels of permutations tile*LG*32 + 32j .. +31.
+// One wavefront generates 64 consecutive permutations (spec S4, same draws as
+// k_perm_generate) and transposes them with ballots.
+__global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __restrict__ masks,
+                                                            const int32_t* __restrict__ margins,
+                                                            int N, int Wp, int64_t P,
+                                                            int64_t perm_base, int trait_base,
+                                                            uint32_t k0, uint32_t k1, int ntiles,
+                                                            uint32_t* __restrict__ tiles) {
+  const int t = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int64_t wave = blockIdx.x;                    // 64 permutations each
+  const int64_t pl = wave * kWave + lane;
+  const bool live = pl < P;
+  const uint32_t pi = (uint32_t)(perm_base + pl);
+  const int waves_per_tile = kListLG / 2;
+  const int tile = (int)(wave / waves_per_tile);
+  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
+  uint32_t* base = tiles + ((int64_t)(t * ntiles + tile) * (N + 1)) * kListRS + col;
+  uint64_t needed = (uint64_t)margins[2 * t], remaining = (uint64_t)margins[2 * t + 1];
+  const uint32_t* mrow = masks + (int64_t)t * Wp;
+  const int nw = (N + 31) / 32;
+  uint64_t mine = 0;
+  for (int k = 0; k < nw; ++k) {
+    const uint32_t mw = mrow[k];
+#pragma unroll 2
+    for (int jj = 0; jj < 16; ++jj) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)(k * 16 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int bit = 2 * jj + h;
+        bool sel = false;
+        if ((mw >> bit) & 1u) {
+          const uint64_t u = ((uint64_t)r[2 * h + 1] << 32) | r[2 * h];
+          if (__umul64hi(u, remaining) < needed) {
+            sel = live;
+            --needed;
+          }
+          --remaining;
+        }
+        const uint64_t b = __ballot(sel);
+        const int iso = k * 32 + bit;
+        if ((iso & 63) == lane) mine = b;
+        if ((iso & 63) == 63 || iso == nw * 32 - 1) {  // 64 isolates collected: one row per lane
+          const int row = (iso & ~63) + lane;
+          if (row < N) {
+            base[(int64_t)row * kListRS] = (uint32_t)mine;
+            base[(int64_t)row * kListRS + 1] = (uint32_t)(mine >> 32);
+          }
+          mine = 0;
+        }
+      }
+    }
+  }
+  if (lane == 0) {  // the all-zero row that list padding points at
+    base[(int64_t)N * kListRS] = 0u;
+    base[(int64_t)N * kListRS + 1] = 0u;
+  }
+}
+
+// Per (trait, list slot): the rejection region in terms of the LIST count u
+// (u = a for a ones-list, npos - a for a zeros-list), modulo M = 2^KD:
+//   in region  <=>  always | ((((u - base) mod M) >= span) ^ invert)
+// out[t][slot] = { base, span | invert << 30 | always << 31 }.
+__global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ crit,
+                                                    const int32_t* __restrict__ margins,
+                                                    const int32_t* __restrict__ order,
+                                                    const uint8_t* __restrict__ flipped, int G,
+                                                    int KD, uint2* __restrict__ out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (k >= G) return;
+  const int g = order[k];
+  const uint2 c = crit[(int64_t)t * G + g];
+  const uint32_t M = 1u << KD;
+  uint2 o;
+  if (c.y == 0u) {
+    o = make_uint2(0u, 1u << 31);
+  } else if (!flipped[g]) {
+    o = make_uint2(c.x & (M - 1), c.y);
+  } else {
+    const uint32_t npos = (uint32_t)margins[2 * t];
+    o = make_uint2((npos - c.x + 1u) & (M - 1), (M - c.y) | (1u << 30));
+  }
+  out[(int64_t)t * G + k] = o;
+}
+
+template <int KC, int KD>
+__global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
+                                                        const uint4* __restrict__ lidx,
+                                                        const int32_t* __restrict__ lstart,
+                                                        const int32_t* __restrict__ lngroups,
+                                                        const int32_t* __restrict__ lorder,
+                                                        const uint2* __restrict__ lcrit, int G,
+                                                        int N, int64_t P, int ntiles,
+                                                        int quads_per_block,
+                                                        uint32_t* __restrict__ r) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
+  const int t = blockIdx.z, tile = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int lg = lane / kListLG, col = lane % kListLG;
+  constexpr int GPW = kWave / kListLG;  // genes per wavefront
+
+  // tile -> LDS (contiguous copy)
+  const int tile_dwords = (N + 1) * kListRS;
+  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * tile_dwords;
+  for (int i = tid; i < tile_dwords; i += blockDim.x) tile_lds[i] = src[i];
+  __syncthreads();
+
+  // permutations of this lane's word that exist (the last tile may be ragged)
+  const int64_t p_first = ((int64_t)tile * kListLG + col) * 32;
+  const uint32_t valid = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
+
+  const int nquads = (G + GPW - 1) / GPW;
+  const int q_lo = blockIdx.x * quads_per_block;
+  const int q_hi = min(nquads, q_lo + quads_per_block);
+  for (int q = q_lo + wave; q < q_hi; q += nwaves) {
+    const int slot = q * GPW + lg;
+    const bool have = slot < G;
+    const int my_start = have ? lstart[slot] : 0;
+    const int my_ng = have ? lngroups[slot] : 0;
+    int ngmax = my_ng;  // wave-uniform maximum over the lane groups
+#pragma unroll
+    for (int off = 32; off >= kListLG; off >>= 1) ngmax = max(ngmax, __shfl_xor(ngmax, off));
+    ngmax = __builtin_amdgcn_readfirstlane(ngmax);
+
+    uint32_t c[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) c[k] = 0u;
+    uint32_t pend = 0u;   // a weight-8 carry waiting for a partner
+    bool has_pend = false;
+    const uint32_t zero_row = (uint32_t)N * kListRS;
+    for (int grp = 0; grp < ngmax; ++grp) {
+      uint4 ia, ib;
+      if (grp < my_ng) {
+        ia = lidx[(int64_t)(my_start + grp) * 2];
+        ib = lidx[(int64_t)(my_start + grp) * 2 + 1];
+      } else {
+        ia = ib = make_uint4(zero_row, zero_row, zero_row, zero_row);
+      }
+      const uint32_t x0 = tile_lds[ia.x + col], x1 = tile_lds[ia.y + col];
+      const uint32_t x2 = tile_lds[ia.z + col], x3 = tile_lds[ia.w + col];
+      const uint32_t x4 = tile_lds[ib.x + col], x5 = tile_lds[ib.y + col];
+      const uint32_t x6 = tile_lds[ib.z + col], x7 = tile_lds[ib.w + col];
+      // 8 words -> planes 0..2 + one carry of weight 8
+      const uint32_t a1 = full_add(c[0], x0, x1);
+      const uint32_t a2 = full_add(c[0], x2, x3);
+      const uint32_t b1 = full_add(c[1], a1, a2);
+      const uint32_t a3 = full_add(c[0], x4, x5);
+      const uint32_t a4 = full_add(c[0], x6, x7);
+      const uint32_t b2 = full_add(c[1], a3, a4);
+      uint32_t carry = full_add(c[2], b1, b2);
+      if (!has_pend) {
+        pend = carry;
+        has_pend = true;
+      } else {
+        carry = full_add(c[3], pend, carry);  // weight 16
+        has_pend = false;
+#pragma unroll
+        for (int k = 4; k < KC; ++k) {        // ripple (half adders)
+          const uint32_t nc = c[k] & carry;
+          c[k] ^= carry;
+          carry = nc;
+        }
+      }
+    }
+    if (has_pend) {
+      uint32_t carry = pend;
+#pragma unroll
+      for (int k = 3; k < KC; ++k) {
+        const uint32_t nc = c[k] & carry;
+        c[k] ^= carry;
+        carry = nc;
+      }
+    }
+    // region test, bit-sliced against this lane group's constants
+    const uint2 cr = have ? lcrit[(int64_t)t * G + slot] : make_uint2(0u, 0u);
+    const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
+    const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
+    const uint32_t always = (cr.y >> 31) ? 0xffffffffu : 0u;
+    uint32_t borrow = 0u, lt = 0u;   // d = u - base ; lt = (d < span)
+#pragma unroll
+    for (int k = 0; k < KD; ++k) {
+      const uint32_t ck = k < KC ? c[k] : 0u;
+      const uint32_t bk = (uint32_t)__builtin_amdgcn_sbfe((int)base, k, 1);   // 0 / ~0
+      const uint32_t sk = (uint32_t)__builtin_amdgcn_sbfe((int)span, k, 1);
+      const uint32_t dk = ck ^ bk ^ borrow;
+      borrow = (~ck & (bk | borrow)) | (bk & borrow);
+      lt = (~dk & (sk | lt)) | (sk & lt);
+    }
+    uint32_t ex = ((~lt) ^ inv) | always;
+    ex &= valid;
+    int cnt = have ? __popc(ex) : 0;
+#pragma unroll
+    for (int off = kListLG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (have && col == 0 && cnt) atomicAdd(&r[(int64_t)t * G + lorder[slot]], (uint32_t)cnt);
+  }
+}
+
 // ----------------------------------------------------------------------------
 // f-2: pairwise Hamming counts between rows (isolates x variable genes)
 // ----------------------------------------------------------------------------
@@ -1042,6 +1279,84 @@ int scoary_row_hash(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_
   hipLaunchKernelGGL(k_row_hash, dim3((unsigned)(Gp / 256), (unsigned)T), dim3(256), 0, s,
                      reinterpret_cast<const uint4*>(d_tiled), d_masks, (int)G, (int)Gp, (int)Qp,
                      d_out);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
+  const int64_t tile_perms = kListLG * 32;
+  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
+  return T * ntiles * (N + 1) * kListRS;
+}
+int64_t scoary_list_row_stride(void) { return kListRS; }
+int64_t scoary_list_max_isolates(void) { return (160 * 1024 - 64) / (kListRS * 4) - 1; }
+
+int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
+                               int64_t T, int64_t N, int64_t P, int64_t perm_base,
+                               int64_t trait_base, uint64_t seed, uint32_t* d_tiles,
+                               scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_masks || !d_margins || !d_tiles || T < 1 || N < 1 || P < 1 || perm_base < 0 || trait_base < 0)
+    return fail(h, SCOARY_ERR_ARG, "scoary_perm_generate_tiles: bad argument");
+  if (T > 65535 || perm_base + P > 0xffffffffLL)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: T > 65535 or permutation index >= 2^32");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t tile_perms = kListLG * 32;
+  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
+  KernelTimer kt(h, s, "k_perm_generate_tiles");
+  hipLaunchKernelGGL(k_perm_generate_tiles, dim3((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T),
+                     dim3(kWave), 0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P,
+                     perm_base, (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles,
+                     d_tiles);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_t* d_lidx,
+                         const int32_t* d_lstart, const int32_t* d_lngroups,
+                         const int32_t* d_lorder, const uint8_t* d_lflipped,
+                         const uint32_t* d_crit, const int32_t* d_margins, uint32_t* d_lcrit,
+                         int64_t G, int64_t T, int64_t N, int64_t P, uint32_t* d_r,
+                         scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiles || !d_lidx || !d_lstart || !d_lngroups || !d_lorder || !d_lflipped || !d_crit ||
+      !d_margins || !d_lcrit || !d_r || G < 1 || T < 1 || N < 1 || P < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_permute_lists: bad argument");
+  if (N > scoary_list_max_isolates())
+    return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: label tile does not fit in LDS for this N");
+  if (T > 65535) return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: T > 65535");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr int KC = 11, KD = 13;   // lists <= 2047 entries, 2N+3 <= 8192
+  {
+    KernelTimer kt(h, s, "k_lists_crit");
+    hipLaunchKernelGGL(k_lists_crit, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                       reinterpret_cast<const uint2*>(d_crit), d_margins, d_lorder, d_lflipped,
+                       (int)G, KD, reinterpret_cast<uint2*>(d_lcrit));
+  }
+  const int64_t tile_perms = kListLG * 32;
+  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
+  const int GPW = kWave / kListLG;
+  const int64_t nquads = (G + GPW - 1) / GPW;
+  // enough blocks for ~16 rounds over the CUs, each a multiple of 16 quads
+  int64_t chunks = ((int64_t)h->num_cu * 16 + ntiles * T - 1) / (ntiles * T);
+  if (chunks < 1) chunks = 1;
+  int64_t qpb = (nquads + chunks - 1) / chunks;
+  qpb = (qpb + 15) / 16 * 16;
+  chunks = (nquads + qpb - 1) / qpb;
+  const size_t lds = (size_t)(N + 1) * kListRS * sizeof(uint32_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_permute_lists<KC, KD>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  KernelTimer kt(h, s, "k_permute_lists");
+  hipLaunchKernelGGL((k_permute_lists<KC, KD>), dim3((unsigned)chunks, (unsigned)ntiles, (unsigned)T),
+                     dim3(1024), lds, s, d_tiles, reinterpret_cast<const uint4*>(d_lidx), d_lstart,
+                     d_lngroups, d_lorder, reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P,
+                     (int)ntiles, (int)qpb, d_r);
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }

@@ -268,4 +268,58 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t* lengths, char* bytes) {
   std::memcpy(bytes, g->meta.data(), g->meta.size());
 }
 
+static inline int64_t row_popcount(const uint64_t* r, int64_t W) {
+  int64_t n = 0;
+  for (int64_t w = 0; w < W; ++w) n += __builtin_popcountll(r[w]);
+  return n;
+}
+
+int64_t scoary_lists_count(const uint64_t* rows64, int64_t G, int64_t N) {
+  const int64_t W = (N + 63) / 64;
+  int64_t total = 0;
+  for (int64_t g = 0; g < G; ++g) {
+    int64_t n1 = row_popcount(rows64 + g * W, W);
+    int64_t len = n1 * 2 <= N ? n1 : N - n1;
+    total += (len + 7) / 8 * 8;
+  }
+  return total;
+}
+
+void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t row_stride_dwords,
+                        uint32_t* idx, int32_t* start, int32_t* ngroups, int32_t* order,
+                        uint8_t* flipped) {
+  const int64_t W = (N + 63) / 64;
+  std::vector<int32_t> len(G);
+  for (int64_t g = 0; g < G; ++g) {
+    int64_t n1 = row_popcount(rows64 + g * W, W);
+    flipped[g] = n1 * 2 <= N ? 0 : 1;
+    len[g] = (int32_t)(flipped[g] ? N - n1 : n1);
+  }
+  // counting sort by descending length (stable in gene id)
+  std::vector<int64_t> bucket(N + 2, 0);
+  for (int64_t g = 0; g < G; ++g) ++bucket[N - len[g] + 1];
+  for (int64_t k = 1; k <= N + 1; ++k) bucket[k] += bucket[k - 1];
+  for (int64_t g = 0; g < G; ++g) order[bucket[N - len[g]]++] = (int32_t)g;
+  int64_t pos = 0;
+  for (int64_t k = 0; k < G; ++k) {
+    const int64_t g = order[k];
+    const uint64_t* r = rows64 + g * W;
+    const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
+    start[k] = (int32_t)(pos / 8);
+    int64_t n = 0;
+    for (int64_t w = 0; w < W; ++w) {
+      uint64_t bits = r[w] ^ inv;
+      if (w == W - 1 && (N & 63)) bits &= (((uint64_t)1 << (N & 63)) - 1);
+      while (bits) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        idx[pos + n++] = (uint32_t)((w * 64 + b) * row_stride_dwords);
+      }
+    }
+    while (n % 8) idx[pos + n++] = (uint32_t)(N * row_stride_dwords);
+    ngroups[k] = (int32_t)(n / 8);
+    pos += n;
+  }
+}
+
 }  // extern "C"

@@ -35,6 +35,15 @@ class GeneMatrix:
         self.tiled = tiled      # torch.int32 [Qp, Gp, 4]
         self.G = int(G)
         self.N = int(N)
+        self.lists = None       # GeneLists, for the list-driven permutation kernel
+
+
+class GeneLists:
+    """Minority index lists of a gene matrix on the device (scoary_lists_build)."""
+
+    def __init__(self, idx, start, ngroups, order, flipped, entries):
+        self.idx, self.start, self.ngroups = idx, start, ngroups
+        self.order, self.flipped, self.entries = order, flipped, entries
 
 
 class AssociationEngine:
@@ -127,6 +136,43 @@ class AssociationEngine:
         buf[:, :2 * W] = rows64.view(np.uint32).reshape(R, 2 * W)
         return torch.from_numpy(buf.view(np.int32)).to(self.device)
 
+    def build_lists(self, genes, rows64):
+        """Attach the minority index lists of ``rows64`` (host (G, W64) uint64,
+        the same genes as ``genes``) for the list-driven permutation kernel."""
+        torch = _torch()
+        from . import io_native
+        d = io_native.build_lists(rows64, genes.N, int(self.lib.scoary_list_row_stride()))
+        dev = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(self.device)  # noqa: E731
+        genes.lists = GeneLists(dev(d["idx"]), dev(d["start"]), dev(d["ngroups"]),
+                                dev(d["order"]), dev(d["flipped"]), d["entries"])
+        return genes.lists
+
+    def lists_supported(self, N):
+        return int(N) <= int(self.lib.scoary_list_max_isolates())
+
+    def perm_generate_tiles(self, masks, margins, N, P, perm_base, seed, out=None, trait_base=0):
+        torch = _torch()
+        T = masks.shape[0]
+        if out is None:
+            out = self._empty((int(self.lib.scoary_list_tiles_words(N, P, T)),), torch.int32)
+        self._check(self.lib.scoary_perm_generate_tiles(
+            self.h, self._ptr(masks), self._ptr(margins), T, N, P, perm_base, trait_base,
+            ctypes.c_uint64(seed), self._ptr(out), self._stream()), "scoary_perm_generate_tiles")
+        return out
+
+    def permute_lists(self, genes, tiles, crit, margins, P, r, scratch=None):
+        torch = _torch()
+        L = genes.lists
+        T = crit.shape[0]
+        if scratch is None:
+            scratch = self._empty((T, genes.G, 2), torch.int32)
+        self._check(self.lib.scoary_permute_lists(
+            self.h, self._ptr(tiles), self._ptr(L.idx), self._ptr(L.start), self._ptr(L.ngroups),
+            self._ptr(L.order), self._ptr(L.flipped), self._ptr(crit), self._ptr(margins),
+            self._ptr(scratch), genes.G, T, genes.N, P, self._ptr(r), self._stream()),
+            "scoary_permute_lists")
+        return r
+
     # -- a3: counts -----------------------------------------------------------
     def counts(self, genes, traits, masks):
         torch = _torch()
@@ -183,7 +229,8 @@ class AssociationEngine:
         return int(max(1, min(P, budget_bytes // max(per, 1))))
 
     # -- the whole hot path ----------------------------------------------------
-    def associate(self, genes, traits, masks, permutations=0, seed=0, perm_buffer=None):
+    def associate(self, genes, traits, masks, permutations=0, seed=0, perm_buffer=None,
+                  use_lists=None, tiles_buffer=None):
         """counts -> Fisher -> (optional) permutation exceedance counts.
         Returns dict of device tensors: counts [T,G,4], margins [T,2],
         p / odds [T,G], r [T,G] (uint32 bit pattern in int32) or None."""
@@ -191,7 +238,23 @@ class AssociationEngine:
         counts, margins = self.counts(genes, traits, masks)
         p, odds, crit = self.fisher(counts, want_crit=permutations > 0)
         r = None
-        if permutations > 0:
+        if use_lists is None:
+            use_lists = genes.lists is not None and self.lists_supported(genes.N)
+        if permutations > 0 and use_lists:
+            T = traits.shape[0]
+            r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
+            per = int(self.lib.scoary_list_tiles_words(genes.N, 512, T)) * 4   # bytes / 512 perms
+            batch = int(max(512, min(-(-permutations // 512) * 512, ((8 << 30) // per) * 512)))
+            done = 0
+            while done < permutations:
+                nb = min(batch, permutations - done)
+                need = int(self.lib.scoary_list_tiles_words(genes.N, nb, T))
+                buf = tiles_buffer[:need] if (tiles_buffer is not None and
+                                              tiles_buffer.numel() >= need) else None
+                tiles = self.perm_generate_tiles(masks, margins, genes.N, nb, done, seed, out=buf)
+                self.permute_lists(genes, tiles, crit, margins, nb, r)
+                done += nb
+        elif permutations > 0:
             T = traits.shape[0]
             r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
             if perm_buffer is not None:

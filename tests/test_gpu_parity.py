@@ -306,3 +306,59 @@ def test_headline_config_properties(eng, orc):
     assert np.max(np.abs(p[:, sub].ravel() - want_p)) < P_TOL
     want_r = orc.permute_r(gb, tb, mb, N, P, seed).T
     assert np.array_equal(r[:, sub], want_r)
+
+
+# ------------------------------------------------------ a7, list-driven -----
+@pytest.mark.parametrize("G,N,T,P", [
+    (1, 1, 1, 10), (7, 40, 2, 33), (300, 100, 2, 512), (513, 130, 3, 600), (1000, 500, 1, 1100),
+    (400, 700, 2, 65), (260, 1500, 1, 700), (500, 2000, 3, 1030), (90, 2400, 2, 520),
+])
+def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
+    """The list-driven kernel (minority lists + bit-sliced counters) gives
+    bit-identical exceedance counts to the dense kernel and to the oracle,
+    including genes present everywhere / nowhere, dense genes (zeros-list),
+    missing isolates and ragged last tiles."""
+    rng = np.random.default_rng(G * 3 + N + P)
+    genes, traits = _random_case(rng, G, N, T)
+    if G > 20:
+        genes[5] = (rng.random(N) < 0.97).astype(np.uint8)     # zeros-list, short
+        genes[6] = (rng.random(N) < 0.02).astype(np.uint8)     # ones-list, short
+        genes[7] = genes[8]                                    # duplicates
+    tb, mb = _bits(eng, traits)
+    from scoary_amd.engine import pack_bits_rows
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    seed = 99 + N
+    dense = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=False)["r"].cpu().numpy()
+    eng.build_lists(gm, pack_bits_rows(genes))
+    assert eng.lists_supported(N)
+    lists = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=True)["r"].cpu().numpy()
+    assert np.array_equal(lists, dense)
+    want = orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, seed).T
+    assert np.array_equal(lists.view(np.uint32), want)
+
+
+def test_perm_tiles_are_the_transposed_row_labels(eng):
+    """k_perm_generate_tiles writes the same spec-S4 labels as k_perm_generate,
+    isolate-major in tiles of 512 permutations, zero row + zero ragged tail."""
+    rng = np.random.default_rng(2)
+    N, T, P, base = 333, 2, 700, 40
+    traits = (rng.random((T, N)) < 0.4).astype(np.uint8)
+    traits[1, rng.random(N) < 0.1] = 2
+    tb, mb = _bits(eng, traits)
+    masks, trv = eng.vecrows(mb, N), eng.vecrows(tb, N)
+    _, margins = eng.counts(eng.pack_dense(np.ones((1, N), dtype=np.uint8)), trv, masks)
+    rows = eng.perm_generate(masks, margins, N, P, base, 5).cpu().numpy().view(np.uint32)
+    tiles = eng.perm_generate_tiles(masks, margins, N, P, base, 5).cpu().numpy().view(np.uint32)
+    RS = int(eng.lib.scoary_list_row_stride())
+    ntiles = -(-P // 512)
+    tiles = tiles.reshape(T, ntiles, N + 1, RS)
+    bits = np.unpackbits(rows.view(np.uint8).reshape(T, P, -1), axis=2, bitorder="little")[:, :, :N]
+    for t in range(T):
+        for tile in range(ntiles):
+            tb_ = np.unpackbits(np.ascontiguousarray(tiles[t, tile, :, :RS - 1]).view(np.uint8),
+                                axis=1, bitorder="little")            # (N+1, 512)
+            assert not tb_[N].any()
+            lo, hi = tile * 512, min(P, tile * 512 + 512)
+            assert np.array_equal(tb_[:N, :hi - lo], bits[t, lo:hi].T)
+            assert not tb_[:N, hi - lo:].any()
