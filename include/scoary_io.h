@@ -49,15 +49,17 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
  * (scoary_permute_lists, include/scoary_hip.h).  For every gene row of a
  * rows64 matrix [G][W64] over N isolates: the ascending positions of its
  * MINORITY value (ones if popcount <= N/2, else zeros; flipped[g] = 1 in the
- * latter case), padded to a multiple of 8 entries with the value N (an
- * all-zero row on the device).  Lists are laid out back to back in `order`:
- * genes sorted by descending list length, so that the four genes a wavefront
- * processes together have similar lengths.
+ * latter case), padded with the value N (an all-zero row on the device) to a
+ * multiple of 32 entries and to the longest list of its quad.  Lists are laid
+ * out back to back in `order`: genes sorted by descending list length, so that
+ * the four genes (a "quad": slots 4q..4q+3) a wavefront processes together have
+ * similar lengths and, after padding, the same number of 32-entry groups.
  *   first call  : scoary_lists_count -> total number of entries
  *   second call : scoary_lists_build fills
- *       idx     uint32 [total]   entry = position * row_stride_dwords
- *       start   int32  [G]       first entry of gene order[k], in groups of 8
- *       ngroups int32  [G]       groups of 8 of gene order[k]
+ *       idx     uint32 [total]   entry = position * row_stride (the LDS byte offset of
+ *                                that isolate's label row in the list-driven kernel)
+ *       start   int32  [G]       first entry of gene order[k], in groups of 32
+ *       ngroups int32  [G]       groups of 32 of gene order[k] (equal within a quad)
  *       order   int32  [G]       gene id of slot k
  *       flipped uint8  [G]       per gene id */
 int64_t scoary_lists_count(const uint64_t *rows64, int64_t G, int64_t N);

@@ -426,7 +426,16 @@ __global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict_
 // of 2000 isolates costs 57 ops per test instead of 137, a rare variant ~20x less.
 // A wavefront = 64/LG lane groups = 64/LG genes of similar list length.
 constexpr int kListLG = 16;           // lanes (32-permutation words) per gene
-constexpr int kListRS = kListLG + 1;  // LDS row stride in dwords (+1: bank spread)
+// LDS row stride in dwords.  No padding: with a 16-dword stride a row starts at
+// bank 0 or 16 by the PARITY of its isolate index, and the list builder orders
+// the two genes that share a 32-lane half so that one walks its even rows while
+// the other walks its odd rows (scoary_lists_build) -- conflict-free except where
+// their even/odd counts differ.
+constexpr int kListRS = kListLG;
+// dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
+__host__ __device__ constexpr int64_t list_tile_dwords(int64_t N) {
+  return ((N + 1) * kListRS + 3) / 4 * 4;
+}
 
 __device__ __forceinline__ uint32_t bit_xor3(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t d;
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
   const int waves_per_tile = kListLG / 2;
   const int tile = (int)(wave / waves_per_tile);
   const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
-  uint32_t* base = tiles + ((int64_t)(t * ntiles + tile) * (N + 1)) * kListRS + col;
+  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N) + col;
   uint64_t needed = (uint64_t)margins[2 * t], remaining = (uint64_t)margins[2 * t + 1];
   const uint32_t* mrow = masks + (int64_t)t * Wp;
   const int nw = (N + 31) / 32;
@@ -534,9 +543,41 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
   out[(int64_t)t * G + k] = o;
 }
 
+// Entry K of a 16-lane group's index vector (held one per lane) -> every lane of
+// the group, fused into the address add:  v_add_u32_dpp ... row_newbcast:K
+template <int K>
+__device__ __forceinline__ uint32_t bcast_add(uint32_t v, uint32_t add) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + K, 0xf, 0xf, false) + add;
+}
+__device__ __forceinline__ uint32_t lds_at(const uint32_t* lds, uint32_t byte_off) {
+  return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + byte_off);
+}
+
+// 8 listed rows (entries 8J..8J+7 of the 32 held as (x, y) of lanes 0..15 of the
+// group) -> counter planes 0..2, returns the carry of weight 8
+template <int J>
+__device__ __forceinline__ uint32_t add8(uint32_t (&c)[16], const uint32_t* __restrict__ lds,
+                                         const uint2 ix, uint32_t col4) {
+  const uint32_t x0 = lds_at(lds, bcast_add<4 * J + 0>(ix.x, col4));
+  const uint32_t x1 = lds_at(lds, bcast_add<4 * J + 0>(ix.y, col4));
+  const uint32_t x2 = lds_at(lds, bcast_add<4 * J + 1>(ix.x, col4));
+  const uint32_t x3 = lds_at(lds, bcast_add<4 * J + 1>(ix.y, col4));
+  const uint32_t x4 = lds_at(lds, bcast_add<4 * J + 2>(ix.x, col4));
+  const uint32_t x5 = lds_at(lds, bcast_add<4 * J + 2>(ix.y, col4));
+  const uint32_t x6 = lds_at(lds, bcast_add<4 * J + 3>(ix.x, col4));
+  const uint32_t x7 = lds_at(lds, bcast_add<4 * J + 3>(ix.y, col4));
+  const uint32_t a1 = full_add(c[0], x0, x1);
+  const uint32_t a2 = full_add(c[0], x2, x3);
+  const uint32_t b1 = full_add(c[1], a1, a2);
+  const uint32_t a3 = full_add(c[0], x4, x5);
+  const uint32_t a4 = full_add(c[0], x6, x7);
+  const uint32_t b2 = full_add(c[1], a3, a4);
+  return full_add(c[2], b1, b2);
+}
+
 template <int KC, int KD>
 __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
-                                                        const uint4* __restrict__ lidx,
+                                                        const uint2* __restrict__ lidx,
                                                         const int32_t* __restrict__ lstart,
                                                         const int32_t* __restrict__ lngroups,
                                                         const int32_t* __restrict__ lorder,
@@ -550,10 +591,16 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   const int lg = lane / kListLG, col = lane % kListLG;
   constexpr int GPW = kWave / kListLG;  // genes per wavefront
 
-  // tile -> LDS (contiguous copy)
+  // tile -> LDS (contiguous copy, 16 B per lane)
   const int tile_dwords = (N + 1) * kListRS;
-  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * tile_dwords;
-  for (int i = tid; i < tile_dwords; i += blockDim.x) tile_lds[i] = src[i];
+  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N);
+  {
+    const uint4* src4 = reinterpret_cast<const uint4*>(src);   // tiles are 16-B aligned per tile
+    uint4* dst4 = reinterpret_cast<uint4*>(tile_lds);
+    const int n4 = tile_dwords / 4;
+    for (int i = tid; i < n4; i += blockDim.x) dst4[i] = src4[i];
+    for (int i = n4 * 4 + tid; i < tile_dwords; i += blockDim.x) tile_lds[i] = src[i];
+  }
   __syncthreads();
 
   // permutations of this lane's word that exist (the last tile may be ragged)
@@ -564,66 +611,49 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   const int q_lo = blockIdx.x * quads_per_block;
   const int q_hi = min(nquads, q_lo + quads_per_block);
   for (int q = q_lo + wave; q < q_hi; q += nwaves) {
-    const int slot = q * GPW + lg;
-    const bool have = slot < G;
-    const int my_start = have ? lstart[slot] : 0;
-    const int my_ng = have ? lngroups[slot] : 0;
-    int ngmax = my_ng;  // wave-uniform maximum over the lane groups
-#pragma unroll
-    for (int off = 32; off >= kListLG; off >>= 1) ngmax = max(ngmax, __shfl_xor(ngmax, off));
-    ngmax = __builtin_amdgcn_readfirstlane(ngmax);
+    const int slot = min(q * GPW + lg, G - 1);
+    const bool have = q * GPW + lg < G;
+    // every gene of a quad has the same (padded) number of 32-entry groups
+    const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);
+    // 32 list entries (byte offsets of LDS rows) per step, two per lane of the
+    // 16-lane group: one coalesced 8-byte load per lane, no redundancy
+    const uint2* lp = lidx + (int64_t)lstart[slot] * 16 + col;
+    const uint32_t col4 = (uint32_t)col * 4u;
 
-    uint32_t c[KC];
+    uint32_t c[16];
 #pragma unroll
-    for (int k = 0; k < KC; ++k) c[k] = 0u;
-    uint32_t pend = 0u;   // a weight-8 carry waiting for a partner
-    bool has_pend = false;
-    const uint32_t zero_row = (uint32_t)N * kListRS;
-    for (int grp = 0; grp < ngmax; ++grp) {
-      uint4 ia, ib;
-      if (grp < my_ng) {
-        ia = lidx[(int64_t)(my_start + grp) * 2];
-        ib = lidx[(int64_t)(my_start + grp) * 2 + 1];
-      } else {
-        ia = ib = make_uint4(zero_row, zero_row, zero_row, zero_row);
-      }
-      const uint32_t x0 = tile_lds[ia.x + col], x1 = tile_lds[ia.y + col];
-      const uint32_t x2 = tile_lds[ia.z + col], x3 = tile_lds[ia.w + col];
-      const uint32_t x4 = tile_lds[ib.x + col], x5 = tile_lds[ib.y + col];
-      const uint32_t x6 = tile_lds[ib.z + col], x7 = tile_lds[ib.w + col];
-      // 8 words -> planes 0..2 + one carry of weight 8
-      const uint32_t a1 = full_add(c[0], x0, x1);
-      const uint32_t a2 = full_add(c[0], x2, x3);
-      const uint32_t b1 = full_add(c[1], a1, a2);
-      const uint32_t a3 = full_add(c[0], x4, x5);
-      const uint32_t a4 = full_add(c[0], x6, x7);
-      const uint32_t b2 = full_add(c[1], a3, a4);
-      uint32_t carry = full_add(c[2], b1, b2);
-      if (!has_pend) {
-        pend = carry;
-        has_pend = true;
-      } else {
-        carry = full_add(c[3], pend, carry);  // weight 16
-        has_pend = false;
+    for (int k = 0; k < 16; ++k) c[k] = 0u;
+    auto add32 = [&](const uint2 ix) {
+      const uint32_t cA = add8<0>(c, tile_lds, ix, col4);
+      const uint32_t cB = add8<1>(c, tile_lds, ix, col4);
+      const uint32_t e1 = full_add(c[3], cA, cB);               // weight 16
+      const uint32_t cC = add8<2>(c, tile_lds, ix, col4);
+      const uint32_t cD = add8<3>(c, tile_lds, ix, col4);
+      const uint32_t e2 = full_add(c[3], cC, cD);
+      uint32_t carry = full_add(c[4], e1, e2);                  // weight 32
 #pragma unroll
-        for (int k = 4; k < KC; ++k) {        // ripple (half adders)
-          const uint32_t nc = c[k] & carry;
-          c[k] ^= carry;
-          carry = nc;
-        }
-      }
-    }
-    if (has_pend) {
-      uint32_t carry = pend;
-#pragma unroll
-      for (int k = 3; k < KC; ++k) {
+      for (int k = 5; k < KC; ++k) {                            // ripple (half adders)
         const uint32_t nc = c[k] & carry;
         c[k] ^= carry;
         carry = nc;
       }
+    };
+    // index vectors are prefetched four steps ahead (2 VGPRs per step)
+    const int last = max(nsuper - 1, 0);
+    uint2 b0 = lp[0], b1 = lp[(int64_t)min(1, last) * 16], b2 = lp[(int64_t)min(2, last) * 16],
+          b3 = lp[(int64_t)min(3, last) * 16];
+    for (int sg = 0; sg < nsuper; sg += 4) {
+      add32(b0);
+      b0 = lp[(int64_t)min(sg + 4, last) * 16];
+      if (sg + 1 < nsuper) add32(b1);
+      b1 = lp[(int64_t)min(sg + 5, last) * 16];
+      if (sg + 2 < nsuper) add32(b2);
+      b2 = lp[(int64_t)min(sg + 6, last) * 16];
+      if (sg + 3 < nsuper) add32(b3);
+      b3 = lp[(int64_t)min(sg + 7, last) * 16];
     }
     // region test, bit-sliced against this lane group's constants
-    const uint2 cr = have ? lcrit[(int64_t)t * G + slot] : make_uint2(0u, 0u);
+    const uint2 cr = lcrit[(int64_t)t * G + slot];
     const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
     const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
     const uint32_t always = (cr.y >> 31) ? 0xffffffffu : 0u;
@@ -1286,9 +1316,10 @@ int scoary_row_hash(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
   const int64_t tile_perms = kListLG * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  return T * ntiles * (N + 1) * kListRS;
+  return T * ntiles * list_tile_dwords(N);
 }
-int64_t scoary_list_row_stride(void) { return kListRS; }
+int64_t scoary_list_row_stride(void) { return kListRS * 4; }   /* bytes */
+int64_t scoary_list_tile_words(int64_t N) { return list_tile_dwords(N); }
 int64_t scoary_list_max_isolates(void) { return (160 * 1024 - 64) / (kListRS * 4) - 1; }
 
 int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
@@ -1354,7 +1385,7 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   }
   KernelTimer kt(h, s, "k_permute_lists");
   hipLaunchKernelGGL((k_permute_lists<KC, KD>), dim3((unsigned)chunks, (unsigned)ntiles, (unsigned)T),
-                     dim3(1024), lds, s, d_tiles, reinterpret_cast<const uint4*>(d_lidx), d_lstart,
+                     dim3(1024), lds, s, d_tiles, reinterpret_cast<const uint2*>(d_lidx), d_lstart,
                      d_lngroups, d_lorder, reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P,
                      (int)ntiles, (int)qpb, d_r);
   HIP_TRY(h, hipGetLastError());

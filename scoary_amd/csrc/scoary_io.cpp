@@ -274,50 +274,75 @@ static inline int64_t row_popcount(const uint64_t* r, int64_t W) {
   return n;
 }
 
-int64_t scoary_lists_count(const uint64_t* rows64, int64_t G, int64_t N) {
+// Padded length of every list: a multiple of kListPad entries, and equal for the
+// kListQuad genes that share a wavefront (slots 4q .. 4q+3 of the length-sorted
+// order), so that the kernel's loop count is wave-uniform.
+static const int64_t kListPad = 32, kListQuad = 4;
+
+static void list_plan(const uint64_t* rows64, int64_t G, int64_t N, std::vector<int32_t>& len,
+                      std::vector<int32_t>& order, std::vector<int32_t>& padded, uint8_t* flipped) {
   const int64_t W = (N + 63) / 64;
-  int64_t total = 0;
+  len.assign(G, 0);
+  order.assign(G, 0);
+  padded.assign(G, 0);
+  std::vector<uint8_t> fl(G);
   for (int64_t g = 0; g < G; ++g) {
-    int64_t n1 = row_popcount(rows64 + g * W, W);
-    int64_t len = n1 * 2 <= N ? n1 : N - n1;
-    total += (len + 7) / 8 * 8;
+    const int64_t n1 = row_popcount(rows64 + g * W, W);
+    fl[g] = n1 * 2 <= N ? 0 : 1;
+    len[g] = (int32_t)(fl[g] ? N - n1 : n1);
+    if (flipped) flipped[g] = fl[g];
   }
+  std::vector<int64_t> bucket(N + 2, 0);      // counting sort, descending length, stable
+  for (int64_t g = 0; g < G; ++g) ++bucket[N - len[g] + 1];
+  for (int64_t k = 1; k <= N + 1; ++k) bucket[k] += bucket[k - 1];
+  for (int64_t g = 0; g < G; ++g) order[bucket[N - len[g]]++] = (int32_t)g;
+  for (int64_t q = 0; q < G; q += kListQuad) {
+    const int64_t L = (len[order[q]] + kListPad - 1) / kListPad * kListPad;  // longest of the quad
+    for (int64_t k = q; k < G && k < q + kListQuad; ++k) padded[k] = (int32_t)L;
+  }
+}
+
+int64_t scoary_lists_count(const uint64_t* rows64, int64_t G, int64_t N) {
+  std::vector<int32_t> len, order, padded;
+  list_plan(rows64, G, N, len, order, padded, nullptr);
+  int64_t total = 0;
+  for (int64_t k = 0; k < G; ++k) total += padded[k];
   return total;
 }
 
 void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t row_stride_dwords,
-                        uint32_t* idx, int32_t* start, int32_t* ngroups, int32_t* order,
+                        uint32_t* idx, int32_t* start, int32_t* ngroups, int32_t* order_out,
                         uint8_t* flipped) {
   const int64_t W = (N + 63) / 64;
-  std::vector<int32_t> len(G);
-  for (int64_t g = 0; g < G; ++g) {
-    int64_t n1 = row_popcount(rows64 + g * W, W);
-    flipped[g] = n1 * 2 <= N ? 0 : 1;
-    len[g] = (int32_t)(flipped[g] ? N - n1 : n1);
-  }
-  // counting sort by descending length (stable in gene id)
-  std::vector<int64_t> bucket(N + 2, 0);
-  for (int64_t g = 0; g < G; ++g) ++bucket[N - len[g] + 1];
-  for (int64_t k = 1; k <= N + 1; ++k) bucket[k] += bucket[k - 1];
-  for (int64_t g = 0; g < G; ++g) order[bucket[N - len[g]]++] = (int32_t)g;
+  std::vector<int32_t> len, order, padded;
+  list_plan(rows64, G, N, len, order, padded, flipped);
   int64_t pos = 0;
   for (int64_t k = 0; k < G; ++k) {
     const int64_t g = order[k];
+    order_out[k] = (int32_t)g;
     const uint64_t* r = rows64 + g * W;
     const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
-    start[k] = (int32_t)(pos / 8);
+    start[k] = (int32_t)(pos / kListPad);
+    ngroups[k] = (int32_t)(padded[k] / kListPad);
+    // Slots k and k^1 share a 32-lane half of the wavefront and read the LDS
+    // label tile in lockstep; even slots walk their even-numbered isolates
+    // first, odd slots their odd-numbered ones, so the two hit different bank
+    // halves (a row starts at bank 0 or 16 by the parity of its index).
     int64_t n = 0;
-    for (int64_t w = 0; w < W; ++w) {
-      uint64_t bits = r[w] ^ inv;
-      if (w == W - 1 && (N & 63)) bits &= (((uint64_t)1 << (N & 63)) - 1);
-      while (bits) {
-        const int b = __builtin_ctzll(bits);
-        bits &= bits - 1;
-        idx[pos + n++] = (uint32_t)((w * 64 + b) * row_stride_dwords);
+    for (int pass = 0; pass < 2; ++pass) {
+      const uint64_t want_odd = (uint64_t)((k & 1) ^ pass);      // parity taken in this pass
+      const uint64_t sel = want_odd ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+      for (int64_t w = 0; w < W; ++w) {
+        uint64_t bits = (r[w] ^ inv) & sel;
+        if (w == W - 1 && (N & 63)) bits &= (((uint64_t)1 << (N & 63)) - 1);
+        while (bits) {
+          const int b = __builtin_ctzll(bits);
+          bits &= bits - 1;
+          idx[pos + n++] = (uint32_t)((w * 64 + b) * row_stride_dwords);
+        }
       }
     }
-    while (n % 8) idx[pos + n++] = (uint32_t)(N * row_stride_dwords);
-    ngroups[k] = (int32_t)(n / 8);
+    while (n < padded[k]) idx[pos + n++] = (uint32_t)(N * row_stride_dwords);
     pos += n;
   }
 }

@@ -55,7 +55,8 @@ def build_lists(rows64, N, row_stride_dwords):
     G = rows64.shape[0]
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)        # noqa: E731
     total = L.scoary_lists_count(p(rows64), G, int(N))
-    out = {"idx": np.zeros(max(total, 8), dtype=np.uint32),
+    # + 64 entries of slack: the kernel prefetches index vectors unconditionally
+    out = {"idx": np.zeros(total + 64, dtype=np.uint32),
            "start": np.zeros(G, dtype=np.int32), "ngroups": np.zeros(G, dtype=np.int32),
            "order": np.zeros(G, dtype=np.int32), "flipped": np.zeros(G, dtype=np.uint8)}
     L.scoary_lists_build(p(rows64), G, int(N), int(row_stride_dwords), p(out["idx"]),

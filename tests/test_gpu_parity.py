@@ -350,13 +350,14 @@ def test_perm_tiles_are_the_transposed_row_labels(eng):
     _, margins = eng.counts(eng.pack_dense(np.ones((1, N), dtype=np.uint8)), trv, masks)
     rows = eng.perm_generate(masks, margins, N, P, base, 5).cpu().numpy().view(np.uint32)
     tiles = eng.perm_generate_tiles(masks, margins, N, P, base, 5).cpu().numpy().view(np.uint32)
-    RS = int(eng.lib.scoary_list_row_stride())
+    RS = int(eng.lib.scoary_list_row_stride()) // 4
     ntiles = -(-P // 512)
-    tiles = tiles.reshape(T, ntiles, N + 1, RS)
+    tw = int(eng.lib.scoary_list_tile_words(N))
+    tiles = tiles.reshape(T, ntiles, tw)[:, :, :(N + 1) * RS].reshape(T, ntiles, N + 1, RS)
     bits = np.unpackbits(rows.view(np.uint8).reshape(T, P, -1), axis=2, bitorder="little")[:, :, :N]
     for t in range(T):
         for tile in range(ntiles):
-            tb_ = np.unpackbits(np.ascontiguousarray(tiles[t, tile, :, :RS - 1]).view(np.uint8),
+            tb_ = np.unpackbits(np.ascontiguousarray(tiles[t, tile, :, :16]).view(np.uint8),
                                 axis=1, bitorder="little")            # (N+1, 512)
             assert not tb_[N].any()
             lo, hi = tile * 512, min(P, tile * 512 + 512)
