@@ -553,24 +553,27 @@ __device__ __forceinline__ uint32_t lds_at(const uint32_t* lds, uint32_t byte_of
   return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + byte_off);
 }
 
-// 8 listed rows (entries 8J..8J+7 of the 32 held as (x, y) of lanes 0..15 of the
-// group) -> counter planes 0..2, returns the carry of weight 8
+// Issue the 8 LDS reads of entries 8J..8J+7 (held as (x, y) of lanes 4J..4J+3 of
+// the group) into x[8J..8J+7].
 template <int J>
-__device__ __forceinline__ uint32_t add8(uint32_t (&c)[16], const uint32_t* __restrict__ lds,
-                                         const uint2 ix, uint32_t col4) {
-  const uint32_t x0 = lds_at(lds, bcast_add<4 * J + 0>(ix.x, col4));
-  const uint32_t x1 = lds_at(lds, bcast_add<4 * J + 0>(ix.y, col4));
-  const uint32_t x2 = lds_at(lds, bcast_add<4 * J + 1>(ix.x, col4));
-  const uint32_t x3 = lds_at(lds, bcast_add<4 * J + 1>(ix.y, col4));
-  const uint32_t x4 = lds_at(lds, bcast_add<4 * J + 2>(ix.x, col4));
-  const uint32_t x5 = lds_at(lds, bcast_add<4 * J + 2>(ix.y, col4));
-  const uint32_t x6 = lds_at(lds, bcast_add<4 * J + 3>(ix.x, col4));
-  const uint32_t x7 = lds_at(lds, bcast_add<4 * J + 3>(ix.y, col4));
-  const uint32_t a1 = full_add(c[0], x0, x1);
-  const uint32_t a2 = full_add(c[0], x2, x3);
+__device__ __forceinline__ void read8(uint32_t (&x)[32], const uint32_t* __restrict__ lds,
+                                      const uint2 ix, uint32_t col4) {
+  x[8 * J + 0] = lds_at(lds, bcast_add<4 * J + 0>(ix.x, col4));
+  x[8 * J + 1] = lds_at(lds, bcast_add<4 * J + 0>(ix.y, col4));
+  x[8 * J + 2] = lds_at(lds, bcast_add<4 * J + 1>(ix.x, col4));
+  x[8 * J + 3] = lds_at(lds, bcast_add<4 * J + 1>(ix.y, col4));
+  x[8 * J + 4] = lds_at(lds, bcast_add<4 * J + 2>(ix.x, col4));
+  x[8 * J + 5] = lds_at(lds, bcast_add<4 * J + 2>(ix.y, col4));
+  x[8 * J + 6] = lds_at(lds, bcast_add<4 * J + 3>(ix.x, col4));
+  x[8 * J + 7] = lds_at(lds, bcast_add<4 * J + 3>(ix.y, col4));
+}
+// 8 row words -> counter planes 0..2, returns the carry of weight 8
+__device__ __forceinline__ uint32_t sum8(uint32_t (&c)[16], const uint32_t* x) {
+  const uint32_t a1 = full_add(c[0], x[0], x[1]);
+  const uint32_t a2 = full_add(c[0], x[2], x[3]);
   const uint32_t b1 = full_add(c[1], a1, a2);
-  const uint32_t a3 = full_add(c[0], x4, x5);
-  const uint32_t a4 = full_add(c[0], x6, x7);
+  const uint32_t a3 = full_add(c[0], x[4], x[5]);
+  const uint32_t a4 = full_add(c[0], x[6], x[7]);
   const uint32_t b2 = full_add(c[1], a3, a4);
   return full_add(c[2], b1, b2);
 }
@@ -623,12 +626,18 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     uint32_t c[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) c[k] = 0u;
-    auto add32 = [&](const uint2 ix) {
-      const uint32_t cA = add8<0>(c, tile_lds, ix, col4);
-      const uint32_t cB = add8<1>(c, tile_lds, ix, col4);
+    auto read32 = [&](uint32_t (&x)[32], const uint2 ix) {
+      read8<0>(x, tile_lds, ix, col4);
+      read8<1>(x, tile_lds, ix, col4);
+      read8<2>(x, tile_lds, ix, col4);
+      read8<3>(x, tile_lds, ix, col4);
+    };
+    auto sum32 = [&](const uint32_t (&x)[32]) {
+      const uint32_t cA = sum8(c, x);
+      const uint32_t cB = sum8(c, x + 8);
       const uint32_t e1 = full_add(c[3], cA, cB);               // weight 16
-      const uint32_t cC = add8<2>(c, tile_lds, ix, col4);
-      const uint32_t cD = add8<3>(c, tile_lds, ix, col4);
+      const uint32_t cC = sum8(c, x + 16);
+      const uint32_t cD = sum8(c, x + 24);
       const uint32_t e2 = full_add(c[3], cC, cD);
       uint32_t carry = full_add(c[4], e1, e2);                  // weight 32
 #pragma unroll
@@ -638,19 +647,26 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
         carry = nc;
       }
     };
-    // index vectors are prefetched four steps ahead (2 VGPRs per step)
+    // Software pipeline: index vectors are fetched four steps ahead (2 VGPRs per
+    // step), the 32 LDS row reads of step s+1 are in flight while step s is summed.
     const int last = max(nsuper - 1, 0);
     uint2 b0 = lp[0], b1 = lp[(int64_t)min(1, last) * 16], b2 = lp[(int64_t)min(2, last) * 16],
           b3 = lp[(int64_t)min(3, last) * 16];
+    uint32_t xa[32], xb[32];
+    if (nsuper > 0) read32(xa, b0);
     for (int sg = 0; sg < nsuper; sg += 4) {
-      add32(b0);
       b0 = lp[(int64_t)min(sg + 4, last) * 16];
-      if (sg + 1 < nsuper) add32(b1);
+      if (sg + 1 < nsuper) read32(xb, b1);
+      sum32(xa);
       b1 = lp[(int64_t)min(sg + 5, last) * 16];
-      if (sg + 2 < nsuper) add32(b2);
+      if (sg + 2 < nsuper) read32(xa, b2);
+      if (sg + 1 < nsuper) sum32(xb);
       b2 = lp[(int64_t)min(sg + 6, last) * 16];
-      if (sg + 3 < nsuper) add32(b3);
+      if (sg + 3 < nsuper) read32(xb, b3);
+      if (sg + 2 < nsuper) sum32(xa);
       b3 = lp[(int64_t)min(sg + 7, last) * 16];
+      if (sg + 4 < nsuper) read32(xa, b0);
+      if (sg + 3 < nsuper) sum32(xb);
     }
     // region test, bit-sliced against this lane group's constants
     const uint2 cr = lcrit[(int64_t)t * G + slot];

@@ -538,6 +538,9 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED):
         if b <= a:
             return torch.zeros((T, 0, dist.REC_WORDS), dtype=torch.int32, device=eng.device)
         gm = table.on_device(eng) if (a, b) == (0, G) else eng.tile_rows(table.rows64[a:b], N)
+        if permutations > 0 and gm.lists is None and eng.lists_supported(N):
+            # list-driven permutation kernel: cost follows each gene's minority count
+            eng.build_lists(gm, table.rows64[a:b])
         res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed)
         return dist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
 
