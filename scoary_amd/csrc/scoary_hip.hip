@@ -589,7 +589,10 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
                                                         int quads_per_block,
                                                         uint32_t* __restrict__ r) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
-  const int t = blockIdx.z, tile = blockIdx.y;
+  // blockIdx.x = (trait, tile) fastest, blockIdx.y = gene chunk: the blocks that
+  // run together walk the SAME chunk of index lists against different label
+  // tiles, so the lists stream from HBM once and are re-read from L2.
+  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int lg = lane / kListLG, col = lane % kListLG;
   constexpr int GPW = kWave / kListLG;  // genes per wavefront
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   const uint32_t valid = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
 
   const int nquads = (G + GPW - 1) / GPW;
-  const int q_lo = blockIdx.x * quads_per_block;
+  const int q_lo = blockIdx.y * quads_per_block;
   const int q_hi = min(nquads, q_lo + quads_per_block);
   for (int q = q_lo + wave; q < q_hi; q += nwaves) {
     const int slot = min(q * GPW + lg, G - 1);
@@ -1386,8 +1389,13 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
   const int GPW = kWave / kListLG;
   const int64_t nquads = (G + GPW - 1) / GPW;
-  // enough blocks for ~16 rounds over the CUs, each a multiple of 16 quads
+  // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index
+  // lists (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the
+  // chunk run; each chunk a multiple of 16 quads
   int64_t chunks = ((int64_t)h->num_cu * 16 + ntiles * T - 1) / (ntiles * T);
+  const int64_t by_l2 = (G * N / 4 * 4 + (2 << 20) - 1) / (2 << 20);   // ~N/4 entries x 4 B per gene
+  if (chunks < by_l2) chunks = by_l2;
+  if (chunks > 65535) chunks = 65535;
   if (chunks < 1) chunks = 1;
   int64_t qpb = (nquads + chunks - 1) / chunks;
   qpb = (qpb + 15) / 16 * 16;
@@ -1400,7 +1408,7 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
     attr_set = true;
   }
   KernelTimer kt(h, s, "k_permute_lists");
-  hipLaunchKernelGGL((k_permute_lists<KC, KD>), dim3((unsigned)chunks, (unsigned)ntiles, (unsigned)T),
+  hipLaunchKernelGGL((k_permute_lists<KC, KD>), dim3((unsigned)(ntiles * T), (unsigned)chunks),
                      dim3(1024), lds, s, d_tiles, reinterpret_cast<const uint2*>(d_lidx), d_lstart,
                      d_lngroups, d_lorder, reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P,
                      (int)ntiles, (int)qpb, d_r);
