@@ -205,6 +205,12 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
     for (int x = mode; x > a; --x) w = w_down(w, x, n1, n2, n);
   const double thr = w * (1.0 + kTie);
 
+  // Both walks stop once a term is inside the rejection region AND below
+  // 2^-90 of the observed table's weight: what is left of the
+  // (super-geometrically decaying) tail is < 1e-26 of the included sum, so p
+  // keeps its RELATIVE accuracy even when it is 1e-200, and the region
+  // boundary has already been passed, so (L, H) are exact.
+  const double tiny = 8.077935669463161e-28 * (thr < 1.0 ? thr : 1.0);   // 2^-90 * w_obs
   double tot = 0.0, inc = 0.0;
   int H = hi + 1, L = lo - 1;
   w = 1.0;
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
     if (w <= thr) {
       inc += w;
       if (H > hi) H = x;
+      if (w < tiny) break;
     }
     w = w_up(w, x, n1, n2, n);
   }
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
     if (w <= thr) {
       inc += w;
       if (L < lo) L = x - 1;
+      if (w < tiny) break;
     }
   }
   const bool all = (H == mode);
