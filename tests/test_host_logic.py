@@ -327,3 +327,46 @@ def test_io_library_exports_every_declared_symbol():
     assert len(names) == 13
     for n in names:
         assert hasattr(lib, n), n
+
+
+# ------------------------------------------------- minority index lists ------
+def test_minority_lists_builder():
+    """scoary_lists_build (host native): per gene the positions of its minority
+    value, padded with N to a multiple of 32 and to the quad's longest list,
+    genes ordered by descending length, even slots even-rows-first / odd slots
+    odd-rows-first (LDS bank trick), entries premultiplied by the row stride."""
+    from scoary_amd import io_native
+    from scoary_amd.engine import pack_bits_rows
+    rng = np.random.default_rng(9)
+    G, N, stride = 203, 333, 64
+    dense = (rng.random((G, N)) < rng.uniform(0.0, 1.0, (G, 1))).astype(np.uint8)
+    dense[0] = 0
+    dense[1] = 1
+    L = io_native.build_lists(pack_bits_rows(dense), N, stride)
+    order, start, ng, flipped = L["order"], L["start"], L["ngroups"], L["flipped"]
+    assert sorted(order.tolist()) == list(range(G))
+    n1 = dense.sum(1).astype(np.int64)
+    length = np.where(n1 * 2 <= N, n1, N - n1)
+    assert np.array_equal(flipped, (n1 * 2 > N).astype(np.uint8))
+    assert np.all(np.diff(length[order]) <= 0)                      # descending
+    total = 0
+    for k in range(G):
+        g = order[k]
+        ent = L["idx"][start[k] * 32:(start[k] + ng[k]) * 32]
+        assert start[k] * 32 == total
+        total += ng[k] * 32
+        assert ng[k] == ng[(k // 4) * 4]                            # equal within a quad
+        assert ng[k] * 32 >= length[g] and (ng[(k // 4) * 4] * 32 - length[order[(k // 4) * 4]]) < 32
+        assert np.all(ent % stride == 0)
+        pos = (ent // stride).astype(np.int64)
+        real = pos[:length[g]]
+        assert np.all(pos[length[g]:] == N)                         # padding -> zero row
+        want = np.nonzero(dense[g] == (0 if flipped[g] else 1))[0]
+        assert sorted(real.tolist()) == want.tolist()
+        first = k & 1                                               # parity walked first
+        par = real & 1
+        assert np.all(np.diff((par != first).astype(int)) >= 0)     # one switch at most
+        for cls in (0, 1):
+            sub = real[par == cls]
+            assert np.all(np.diff(sub) > 0)                         # ascending within parity
+    assert L["entries"] == total and len(L["idx"]) >= total + 32
