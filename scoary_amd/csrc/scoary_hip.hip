@@ -645,20 +645,14 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
       read8<2>(x, tile_lds, ix, col4);
       read8<3>(x, tile_lds, ix, col4);
     };
-    auto sum32 = [&](const uint32_t (&x)[32]) {
+    auto sum32 = [&](const uint32_t (&x)[32]) -> uint32_t {
       const uint32_t cA = sum8(c, x);
       const uint32_t cB = sum8(c, x + 8);
       const uint32_t e1 = full_add(c[3], cA, cB);               // weight 16
       const uint32_t cC = sum8(c, x + 16);
       const uint32_t cD = sum8(c, x + 24);
       const uint32_t e2 = full_add(c[3], cC, cD);
-      uint32_t carry = full_add(c[4], e1, e2);                  // weight 32
-#pragma unroll
-      for (int k = 5; k < KC; ++k) {                            // ripple (half adders)
-        const uint32_t nc = c[k] & carry;
-        c[k] ^= carry;
-        carry = nc;
-      }
+      return full_add(c[4], e1, e2);                            // weight 32
     };
     // Software pipeline: index vectors are fetched four steps ahead (2 VGPRs per
     // step), the 32 LDS row reads of step s+1 are in flight while step s is summed.
@@ -668,18 +662,30 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     uint32_t xa[32], xb[32];
     if (nsuper > 0) read32(xa, b0);
     for (int sg = 0; sg < nsuper; sg += 4) {
+      // four steps (128 rows) per trip; their weight-32 carries are paired up
+      // the tree before the (short) half-adder ripple
+      uint32_t f1 = 0u, f2 = 0u, f3 = 0u;
       b0 = lp[(int64_t)min(sg + 4, last) * 16];
       if (sg + 1 < nsuper) read32(xb, b1);
-      sum32(xa);
+      const uint32_t f0 = sum32(xa);
       b1 = lp[(int64_t)min(sg + 5, last) * 16];
       if (sg + 2 < nsuper) read32(xa, b2);
-      if (sg + 1 < nsuper) sum32(xb);
+      if (sg + 1 < nsuper) f1 = sum32(xb);
       b2 = lp[(int64_t)min(sg + 6, last) * 16];
       if (sg + 3 < nsuper) read32(xb, b3);
-      if (sg + 2 < nsuper) sum32(xa);
+      if (sg + 2 < nsuper) f2 = sum32(xa);
       b3 = lp[(int64_t)min(sg + 7, last) * 16];
       if (sg + 4 < nsuper) read32(xa, b0);
-      if (sg + 3 < nsuper) sum32(xb);
+      if (sg + 3 < nsuper) f3 = sum32(xb);
+      const uint32_t g0 = full_add(c[5], f0, f1);               // weight 64
+      const uint32_t g1 = full_add(c[5], f2, f3);
+      uint32_t carry = full_add(c[6], g0, g1);                  // weight 128
+#pragma unroll
+      for (int k = 7; k < KC; ++k) {                            // ripple (half adders)
+        const uint32_t nc = c[k] & carry;
+        c[k] ^= carry;
+        carry = nc;
+      }
     }
     // region test, bit-sliced against this lane group's constants
     const uint2 cr = lcrit[(int64_t)t * G + slot];
