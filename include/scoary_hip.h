@@ -139,12 +139,15 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
  * cheap.  Available while a tile fits in LDS: N <= scoary_list_max_isolates().
  *   d_tiles : uint32 [scoary_list_tiles_words(N, P, T)]
  *   d_lidx / d_lstart / d_lngroups / d_lorder / d_lflipped : scoary_lists_build
- *             output (row stride = scoary_list_row_stride() bytes), copied to the GPU
+ *             output (arguments from scoary_list_params), copied to the GPU
  *   d_lcrit : scratch, uint32 [T][G][2] */
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T);
 int64_t scoary_list_tile_words(int64_t N);   /* dwords per (trait, tile) */
-int64_t scoary_list_row_stride(void);
 int64_t scoary_list_max_isolates(void);
+/* out4 = { lanes per gene (16 for N <= 2559, 8 for N <= 5119), row stride in
+ * bytes, genes per wavefront, residue classes } -- the last three are the
+ * arguments scoary_lists_build wants.  Error if N is too large. */
+int scoary_list_params(int64_t N, int64_t *out4);
 int scoary_perm_generate_tiles(scoary_handle h, const uint32_t *d_masks,
                                const int32_t *d_margins, int64_t T, int64_t N, int64_t P,
                                int64_t perm_base, int64_t trait_base, uint64_t seed,

@@ -47,25 +47,28 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
 
 /* ---- minority index lists for the list-driven permutation kernel ----------
  * (scoary_permute_lists, include/scoary_hip.h).  For every gene row of a
- * rows64 matrix [G][W64] over N isolates: the ascending positions of its
- * MINORITY value (ones if popcount <= N/2, else zeros; flipped[g] = 1 in the
- * latter case), padded with the value N (an all-zero row on the device) to a
- * multiple of 32 entries and to the longest list of its quad.  Lists are laid
- * out back to back in `order`: genes sorted by descending list length, so that
- * the four genes (a "quad": slots 4q..4q+3) a wavefront processes together have
+ * rows64 matrix [G][W64] over N isolates: the positions of its MINORITY value
+ * (ones if popcount <= N/2, else zeros; flipped[g] = 1 in the latter case),
+ * padded with the value N (an all-zero row on the device) to a multiple of 32
+ * entries and to the longest list of its wavefront group.  Lists are laid out
+ * back to back in `order`: genes sorted by descending list length, so that the
+ * `genes_per_wave` genes a wavefront processes together (slots w*gpw ..) have
  * similar lengths and, after padding, the same number of 32-entry groups.
+ * Within a list the positions are grouped by (position mod classes), slot k
+ * starting with class k mod classes (LDS bank trick, see the kernel).
+ * row_stride / genes_per_wave / classes come from scoary_list_params(N).
  *   first call  : scoary_lists_count -> total number of entries
  *   second call : scoary_lists_build fills
  *       idx     uint32 [total]   entry = position * row_stride (the LDS byte offset of
  *                                that isolate's label row in the list-driven kernel)
  *       start   int32  [G]       first entry of gene order[k], in groups of 32
- *       ngroups int32  [G]       groups of 32 of gene order[k] (equal within a quad)
+ *       ngroups int32  [G]       groups of 32 of gene order[k] (equal within a wave group)
  *       order   int32  [G]       gene id of slot k
  *       flipped uint8  [G]       per gene id */
-int64_t scoary_lists_count(const uint64_t *rows64, int64_t G, int64_t N);
-void scoary_lists_build(const uint64_t *rows64, int64_t G, int64_t N, int64_t row_stride_dwords,
-                        uint32_t *idx, int32_t *start, int32_t *ngroups, int32_t *order,
-                        uint8_t *flipped);
+int64_t scoary_lists_count(const uint64_t *rows64, int64_t G, int64_t N, int64_t genes_per_wave);
+void scoary_lists_build(const uint64_t *rows64, int64_t G, int64_t N, int64_t row_stride,
+                        int64_t genes_per_wave, int64_t classes, uint32_t *idx, int32_t *start,
+                        int32_t *ngroups, int32_t *order, uint8_t *flipped);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ SIGNATURES = {
     "scoary_permute": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "scoary_list_tiles_words": (_i64, [_i64, _i64, _i64]),
     "scoary_list_tile_words": (_i64, [_i64]),
-    "scoary_list_row_stride": (_i64, []),
+    "scoary_list_params": (_i32, [_i64, _vp]),
     "scoary_list_max_isolates": (_i64, []),
     "scoary_perm_generate_tiles": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp,
                                           _vp]),

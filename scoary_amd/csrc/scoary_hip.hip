@@ -435,16 +435,21 @@ __global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict_
 // ~0.11 * |list| ops per test versus 0.0625 * N * 2: a gene present in 26 %
 // of 2000 isolates costs 57 ops per test instead of 137, a rare variant ~20x less.
 // A wavefront = 64/LG lane groups = 64/LG genes of similar list length.
-constexpr int kListLG = 16;           // lanes (32-permutation words) per gene
+// LG = lanes (32-permutation words) per gene: 16 while a tile of 512
+// permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
+// N <= 5119.  One wavefront processes 64/LG genes; the 32/LG lane groups of a
+// 32-lane half read LDS in lockstep.
 // LDS row stride in dwords.  No padding: with a 16-dword stride a row starts at
 // bank 0 or 16 by the PARITY of its isolate index, and the list builder orders
 // the two genes that share a 32-lane half so that one walks its even rows while
 // the other walks its odd rows (scoary_lists_build) -- conflict-free except where
 // their even/odd counts differ.
-constexpr int kListRS = kListLG;
+__host__ __device__ constexpr int list_lg(int64_t N) {
+  return N <= 2559 ? 16 : (N <= 5119 ? 8 : 0);
+}
 // dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
-__host__ __device__ constexpr int64_t list_tile_dwords(int64_t N) {
-  return ((N + 1) * kListRS + 3) / 4 * 4;
+__host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int LG) {
+  return ((N + 1) * LG + 3) / 4 * 4;
 }
 
 __device__ __forceinline__ uint32_t bit_xor3(uint32_t a, uint32_t b, uint32_t c) {
@@ -464,10 +469,11 @@ __device__ __forceinline__ uint32_t full_add(uint32_t& c, uint32_t x, uint32_t y
   return carry;
 }
 
-// Isolate-major label tiles: tiles[t][tile][row 0..N][kListRS] dwords, row N all
+// Isolate-major label tiles: tiles[t][tile][row 0..N][LG] dwords, row N all
 // zero; dword j of a row = labels of permutations tile*LG*32 + 32j .. +31.
 // One wavefront generates 64 consecutive permutations (spec S4, same draws as
 // k_perm_generate) and transposes them with ballots.
+template <int LG>
 __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __restrict__ masks,
                                                             const int32_t* __restrict__ margins,
                                                             int N, int Wp, int64_t P,
@@ -480,10 +486,10 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
   const int64_t pl = wave * kWave + lane;
   const bool live = pl < P;
   const uint32_t pi = (uint32_t)(perm_base + pl);
-  const int waves_per_tile = kListLG / 2;
+  const int waves_per_tile = LG / 2;
   const int tile = (int)(wave / waves_per_tile);
   const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
-  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N) + col;
+  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG) + col;
   uint64_t needed = (uint64_t)margins[2 * t], remaining = (uint64_t)margins[2 * t + 1];
   const uint32_t* mrow = masks + (int64_t)t * Wp;
   const int nw = (N + 31) / 32;
@@ -512,8 +518,8 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
         if ((iso & 63) == 63 || iso == nw * 32 - 1) {  // 64 isolates collected: one row per lane
           const int row = (iso & ~63) + lane;
           if (row < N) {
-            base[(int64_t)row * kListRS] = (uint32_t)mine;
-            base[(int64_t)row * kListRS + 1] = (uint32_t)(mine >> 32);
+            base[(int64_t)row * LG] = (uint32_t)mine;
+            base[(int64_t)row * LG + 1] = (uint32_t)(mine >> 32);
           }
           mine = 0;
         }
@@ -521,8 +527,8 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
     }
   }
   if (lane == 0) {  // the all-zero row that list padding points at
-    base[(int64_t)N * kListRS] = 0u;
-    base[(int64_t)N * kListRS + 1] = 0u;
+    base[(int64_t)N * LG] = 0u;
+    base[(int64_t)N * LG + 1] = 0u;
   }
 }
 
@@ -553,29 +559,39 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
   out[(int64_t)t * G + k] = o;
 }
 
-// Entry K of a 16-lane group's index vector (held one per lane) -> every lane of
-// the group, fused into the address add:  v_add_u32_dpp ... row_newbcast:K
-template <int K>
-__device__ __forceinline__ uint32_t bcast_add(uint32_t v, uint32_t add) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + K, 0xf, 0xf, false) + add;
+// Entry J (0..31) of a gene's 32-entry index vector -> every lane of its group,
+// plus the lane's column offset.  The vector is held 32/LG entries per lane.
+// LG = 16: a DPP row IS a group, so  v_add_u32_dpp ... row_newbcast:lane  does
+// broadcast and add in one instruction.  LG = 8: a DPP row holds two groups;
+// each gets its own source lane through bank-masked broadcasts.
+template <int LG, int J>
+__device__ __forceinline__ uint32_t entry_addr(const uint32_t (&e)[32 / LG], uint32_t col4) {
+  constexpr int EPL = 32 / LG;
+  const int v = (int)e[J % EPL];
+  if constexpr (LG == 16) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x150 + J / EPL, 0xf, 0xf, false) + col4;
+  } else {
+    const int t1 = __builtin_amdgcn_update_dpp(0, v, 0x150 + J / EPL, 0xf, 0x3, false);
+    const int t2 = __builtin_amdgcn_update_dpp(t1, v, 0x150 + 8 + J / EPL, 0xf, 0xc, false);
+    return (uint32_t)t2 + col4;
+  }
 }
 __device__ __forceinline__ uint32_t lds_at(const uint32_t* lds, uint32_t byte_off) {
   return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + byte_off);
 }
 
-// Issue the 8 LDS reads of entries 8J..8J+7 (held as (x, y) of lanes 4J..4J+3 of
-// the group) into x[8J..8J+7].
-template <int J>
+// Issue the 8 LDS reads of entries 8J..8J+7 into x[8J..8J+7].
+template <int LG, int J>
 __device__ __forceinline__ void read8(uint32_t (&x)[32], const uint32_t* __restrict__ lds,
-                                      const uint2 ix, uint32_t col4) {
-  x[8 * J + 0] = lds_at(lds, bcast_add<4 * J + 0>(ix.x, col4));
-  x[8 * J + 1] = lds_at(lds, bcast_add<4 * J + 0>(ix.y, col4));
-  x[8 * J + 2] = lds_at(lds, bcast_add<4 * J + 1>(ix.x, col4));
-  x[8 * J + 3] = lds_at(lds, bcast_add<4 * J + 1>(ix.y, col4));
-  x[8 * J + 4] = lds_at(lds, bcast_add<4 * J + 2>(ix.x, col4));
-  x[8 * J + 5] = lds_at(lds, bcast_add<4 * J + 2>(ix.y, col4));
-  x[8 * J + 6] = lds_at(lds, bcast_add<4 * J + 3>(ix.x, col4));
-  x[8 * J + 7] = lds_at(lds, bcast_add<4 * J + 3>(ix.y, col4));
+                                      const uint32_t (&e)[32 / LG], uint32_t col4) {
+  x[8 * J + 0] = lds_at(lds, entry_addr<LG, 8 * J + 0>(e, col4));
+  x[8 * J + 1] = lds_at(lds, entry_addr<LG, 8 * J + 1>(e, col4));
+  x[8 * J + 2] = lds_at(lds, entry_addr<LG, 8 * J + 2>(e, col4));
+  x[8 * J + 3] = lds_at(lds, entry_addr<LG, 8 * J + 3>(e, col4));
+  x[8 * J + 4] = lds_at(lds, entry_addr<LG, 8 * J + 4>(e, col4));
+  x[8 * J + 5] = lds_at(lds, entry_addr<LG, 8 * J + 5>(e, col4));
+  x[8 * J + 6] = lds_at(lds, entry_addr<LG, 8 * J + 6>(e, col4));
+  x[8 * J + 7] = lds_at(lds, entry_addr<LG, 8 * J + 7>(e, col4));
 }
 // 8 row words -> counter planes 0..2, returns the carry of weight 8
 __device__ __forceinline__ uint32_t sum8(uint32_t (&c)[16], const uint32_t* x) {
@@ -588,9 +604,9 @@ __device__ __forceinline__ uint32_t sum8(uint32_t (&c)[16], const uint32_t* x) {
   return full_add(c[2], b1, b2);
 }
 
-template <int KC, int KD>
+template <int LG, int KC, int KD>
 __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
-                                                        const uint2* __restrict__ lidx,
+                                                        const uint32_t* __restrict__ lidx,
                                                         const int32_t* __restrict__ lstart,
                                                         const int32_t* __restrict__ lngroups,
                                                         const int32_t* __restrict__ lorder,
@@ -604,12 +620,13 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   // tiles, so the lists stream from HBM once and are re-read from L2.
   const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int lg = lane / kListLG, col = lane % kListLG;
-  constexpr int GPW = kWave / kListLG;  // genes per wavefront
+  const int lg = lane / LG, col = lane % LG;
+  constexpr int GPW = kWave / LG;   // genes per wavefront
+  constexpr int EPL = 32 / LG;      // index entries per lane and step
 
   // tile -> LDS (contiguous copy, 16 B per lane)
-  const int tile_dwords = (N + 1) * kListRS;
-  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N);
+  const int tile_dwords = (N + 1) * LG;
+  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG);
   {
     const uint4* src4 = reinterpret_cast<const uint4*>(src);   // tiles are 16-B aligned per tile
     uint4* dst4 = reinterpret_cast<uint4*>(tile_lds);
@@ -620,7 +637,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   __syncthreads();
 
   // permutations of this lane's word that exist (the last tile may be ragged)
-  const int64_t p_first = ((int64_t)tile * kListLG + col) * 32;
+  const int64_t p_first = ((int64_t)tile * LG + col) * 32;
   const uint32_t valid = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
 
   const int nquads = (G + GPW - 1) / GPW;
@@ -631,19 +648,20 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const bool have = q * GPW + lg < G;
     // every gene of a quad has the same (padded) number of 32-entry groups
     const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);
-    // 32 list entries (byte offsets of LDS rows) per step, two per lane of the
-    // 16-lane group: one coalesced 8-byte load per lane, no redundancy
-    const uint2* lp = lidx + (int64_t)lstart[slot] * 16 + col;
+    // 32 list entries (byte offsets of LDS rows) per step, 32/LG per lane of the
+    // group: one coalesced 8- or 16-byte load per lane, no redundancy
+    struct alignas(4 * EPL) Ent { uint32_t e[EPL]; };
+    const Ent* lp = reinterpret_cast<const Ent*>(lidx) + (int64_t)lstart[slot] * LG + col;
     const uint32_t col4 = (uint32_t)col * 4u;
 
     uint32_t c[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) c[k] = 0u;
-    auto read32 = [&](uint32_t (&x)[32], const uint2 ix) {
-      read8<0>(x, tile_lds, ix, col4);
-      read8<1>(x, tile_lds, ix, col4);
-      read8<2>(x, tile_lds, ix, col4);
-      read8<3>(x, tile_lds, ix, col4);
+    auto read32 = [&](uint32_t (&x)[32], const Ent& ix) {
+      read8<LG, 0>(x, tile_lds, ix.e, col4);
+      read8<LG, 1>(x, tile_lds, ix.e, col4);
+      read8<LG, 2>(x, tile_lds, ix.e, col4);
+      read8<LG, 3>(x, tile_lds, ix.e, col4);
     };
     auto sum32 = [&](const uint32_t (&x)[32]) -> uint32_t {
       const uint32_t cA = sum8(c, x);
@@ -657,24 +675,24 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     // Software pipeline: index vectors are fetched four steps ahead (2 VGPRs per
     // step), the 32 LDS row reads of step s+1 are in flight while step s is summed.
     const int last = max(nsuper - 1, 0);
-    uint2 b0 = lp[0], b1 = lp[(int64_t)min(1, last) * 16], b2 = lp[(int64_t)min(2, last) * 16],
-          b3 = lp[(int64_t)min(3, last) * 16];
+    Ent b0 = lp[0], b1 = lp[(int64_t)min(1, last) * LG], b2 = lp[(int64_t)min(2, last) * LG],
+        b3 = lp[(int64_t)min(3, last) * LG];
     uint32_t xa[32], xb[32];
     if (nsuper > 0) read32(xa, b0);
     for (int sg = 0; sg < nsuper; sg += 4) {
       // four steps (128 rows) per trip; their weight-32 carries are paired up
       // the tree before the (short) half-adder ripple
       uint32_t f1 = 0u, f2 = 0u, f3 = 0u;
-      b0 = lp[(int64_t)min(sg + 4, last) * 16];
+      b0 = lp[(int64_t)min(sg + 4, last) * LG];
       if (sg + 1 < nsuper) read32(xb, b1);
       const uint32_t f0 = sum32(xa);
-      b1 = lp[(int64_t)min(sg + 5, last) * 16];
+      b1 = lp[(int64_t)min(sg + 5, last) * LG];
       if (sg + 2 < nsuper) read32(xa, b2);
       if (sg + 1 < nsuper) f1 = sum32(xb);
-      b2 = lp[(int64_t)min(sg + 6, last) * 16];
+      b2 = lp[(int64_t)min(sg + 6, last) * LG];
       if (sg + 3 < nsuper) read32(xb, b3);
       if (sg + 2 < nsuper) f2 = sum32(xa);
-      b3 = lp[(int64_t)min(sg + 7, last) * 16];
+      b3 = lp[(int64_t)min(sg + 7, last) * LG];
       if (sg + 4 < nsuper) read32(xa, b0);
       if (sg + 3 < nsuper) f3 = sum32(xb);
       const uint32_t g0 = full_add(c[5], f0, f1);               // weight 64
@@ -706,7 +724,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     ex &= valid;
     int cnt = have ? __popc(ex) : 0;
 #pragma unroll
-    for (int off = kListLG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    for (int off = LG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
     if (have && col == 0 && cnt) atomicAdd(&r[(int64_t)t * G + lorder[slot]], (uint32_t)cnt);
   }
 }
@@ -1349,13 +1367,23 @@ int scoary_row_hash(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_
 }
 
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
-  const int64_t tile_perms = kListLG * 32;
+  const int LG = list_lg(N);
+  if (!LG) return 0;
+  const int64_t tile_perms = LG * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  return T * ntiles * list_tile_dwords(N);
+  return T * ntiles * list_tile_dwords(N, LG);
 }
-int64_t scoary_list_row_stride(void) { return kListRS * 4; }   /* bytes */
-int64_t scoary_list_tile_words(int64_t N) { return list_tile_dwords(N); }
-int64_t scoary_list_max_isolates(void) { return (160 * 1024 - 64) / (kListRS * 4) - 1; }
+int64_t scoary_list_tile_words(int64_t N) { return list_lg(N) ? list_tile_dwords(N, list_lg(N)) : 0; }
+int64_t scoary_list_max_isolates(void) { return 5119; }
+int scoary_list_params(int64_t N, int64_t* out4) {
+  if (!out4) return SCOARY_ERR_ARG;
+  const int LG = list_lg(N);
+  out4[0] = LG;                       /* lanes per gene (0: N too large for the list kernel) */
+  out4[1] = LG * 4;                   /* LDS / tile row stride in bytes */
+  out4[2] = LG ? kWave / LG : 0;      /* genes per wavefront: lists padded to equal length */
+  out4[3] = LG ? 32 / LG : 0;         /* residue classes of the isolate index (bank trick) */
+  return LG ? SCOARY_OK : SCOARY_ERR_SIZE;
+}
 
 int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
                                int64_t T, int64_t N, int64_t P, int64_t perm_base,
@@ -1366,18 +1394,69 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
     return fail(h, SCOARY_ERR_ARG, "scoary_perm_generate_tiles: bad argument");
   if (T > 65535 || perm_base + P > 0xffffffffLL)
     return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: T > 65535 or permutation index >= 2^32");
+  const int LG = list_lg(N);
+  if (!LG) return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: N too large for LDS tiles");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int64_t tile_perms = kListLG * 32;
+  const int64_t tile_perms = LG * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
+  const dim3 grid((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T);
   KernelTimer kt(h, s, "k_perm_generate_tiles");
-  hipLaunchKernelGGL(k_perm_generate_tiles, dim3((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T),
-                     dim3(kWave), 0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P,
-                     perm_base, (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles,
-                     d_tiles);
+#define GEN_TILES(LGV)                                                                              \
+  hipLaunchKernelGGL((k_perm_generate_tiles<LGV>), grid, dim3(kWave), 0, s, d_masks, d_margins, (int)N, \
+                     (int)scoary_row_words(N), P, perm_base, (int)trait_base, (uint32_t)seed,        \
+                     (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
+  if (LG == 16) GEN_TILES(16); else GEN_TILES(8);
+#undef GEN_TILES
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }
+
+extern "C++" {
+template <int LG, int KC, int KD>
+static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* d_tiles,
+                                const uint32_t* d_lidx, const int32_t* d_lstart,
+                                const int32_t* d_lngroups, const int32_t* d_lorder,
+                                const uint8_t* d_lflipped, const uint32_t* d_crit,
+                                const int32_t* d_margins, uint32_t* d_lcrit, int64_t G, int64_t T,
+                                int64_t N, int64_t P, uint32_t* d_r) {
+  {
+    KernelTimer kt(h, s, "k_lists_crit");
+    hipLaunchKernelGGL(k_lists_crit, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                       reinterpret_cast<const uint2*>(d_crit), d_margins, d_lorder, d_lflipped,
+                       (int)G, KD, reinterpret_cast<uint2*>(d_lcrit));
+  }
+  const int64_t tile_perms = LG * 32;
+  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
+  constexpr int GPW = kWave / LG;
+  const int64_t nquads = (G + GPW - 1) / GPW;
+  // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index
+  // lists (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the
+  // chunk run; each chunk a multiple of 16 wave-groups
+  int64_t chunks = ((int64_t)h->num_cu * 16 + ntiles * T - 1) / (ntiles * T);
+  const int64_t by_l2 = (G * N / 4 * 4 + (2 << 20) - 1) / (2 << 20);   // ~N/4 entries x 4 B per gene
+  if (chunks < by_l2) chunks = by_l2;
+  if (chunks > 65535) chunks = 65535;
+  if (chunks < 1) chunks = 1;
+  int64_t qpb = (nquads + chunks - 1) / chunks;
+  qpb = (qpb + 15) / 16 * 16;
+  chunks = (nquads + qpb - 1) / qpb;
+  const size_t lds = (size_t)(N + 1) * LG * sizeof(uint32_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_permute_lists<LG, KC, KD>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  KernelTimer kt(h, s, "k_permute_lists");
+  hipLaunchKernelGGL((k_permute_lists<LG, KC, KD>), dim3((unsigned)(ntiles * T), (unsigned)chunks),
+                     dim3(1024), lds, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                     reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P, (int)ntiles, (int)qpb,
+                     d_r);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+}  // extern "C++"
 
 int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_t* d_lidx,
                          const int32_t* d_lstart, const int32_t* d_lngroups,
@@ -1389,47 +1468,18 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   if (!d_tiles || !d_lidx || !d_lstart || !d_lngroups || !d_lorder || !d_lflipped || !d_crit ||
       !d_margins || !d_lcrit || !d_r || G < 1 || T < 1 || N < 1 || P < 1)
     return fail(h, SCOARY_ERR_ARG, "scoary_permute_lists: bad argument");
-  if (N > scoary_list_max_isolates())
+  const int LG = list_lg(N);
+  if (!LG)
     return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: label tile does not fit in LDS for this N");
   if (T > 65535) return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: T > 65535");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  constexpr int KC = 11, KD = 13;   // lists <= 2047 entries, 2N+3 <= 8192
-  {
-    KernelTimer kt(h, s, "k_lists_crit");
-    hipLaunchKernelGGL(k_lists_crit, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
-                       reinterpret_cast<const uint2*>(d_crit), d_margins, d_lorder, d_lflipped,
-                       (int)G, KD, reinterpret_cast<uint2*>(d_lcrit));
-  }
-  const int64_t tile_perms = kListLG * 32;
-  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  const int GPW = kWave / kListLG;
-  const int64_t nquads = (G + GPW - 1) / GPW;
-  // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index
-  // lists (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the
-  // chunk run; each chunk a multiple of 16 quads
-  int64_t chunks = ((int64_t)h->num_cu * 16 + ntiles * T - 1) / (ntiles * T);
-  const int64_t by_l2 = (G * N / 4 * 4 + (2 << 20) - 1) / (2 << 20);   // ~N/4 entries x 4 B per gene
-  if (chunks < by_l2) chunks = by_l2;
-  if (chunks > 65535) chunks = 65535;
-  if (chunks < 1) chunks = 1;
-  int64_t qpb = (nquads + chunks - 1) / chunks;
-  qpb = (qpb + 15) / 16 * 16;
-  chunks = (nquads + qpb - 1) / qpb;
-  const size_t lds = (size_t)(N + 1) * kListRS * sizeof(uint32_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_permute_lists<KC, KD>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  KernelTimer kt(h, s, "k_permute_lists");
-  hipLaunchKernelGGL((k_permute_lists<KC, KD>), dim3((unsigned)(ntiles * T), (unsigned)chunks),
-                     dim3(1024), lds, s, d_tiles, reinterpret_cast<const uint2*>(d_lidx), d_lstart,
-                     d_lngroups, d_lorder, reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P,
-                     (int)ntiles, (int)qpb, d_r);
-  HIP_TRY(h, hipGetLastError());
-  return SCOARY_OK;
+  // counter planes KC: lists hold <= N/2 entries; compare planes KD: 2N+3 <= 2^KD
+  if (LG == 16)
+    return launch_permute_lists<16, 11, 13>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                            d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  return launch_permute_lists<8, 12, 14>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                         d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
 }
 
 int scoary_set_timing(scoary_handle h, int enabled) {

@@ -275,12 +275,13 @@ static inline int64_t row_popcount(const uint64_t* r, int64_t W) {
 }
 
 // Padded length of every list: a multiple of kListPad entries, and equal for the
-// kListQuad genes that share a wavefront (slots 4q .. 4q+3 of the length-sorted
-// order), so that the kernel's loop count is wave-uniform.
-static const int64_t kListPad = 32, kListQuad = 4;
+// `gpw` genes that share a wavefront (slots w*gpw .. w*gpw+gpw-1 of the
+// length-sorted order), so that the kernel's loop count is wave-uniform.
+static const int64_t kListPad = 32;
 
-static void list_plan(const uint64_t* rows64, int64_t G, int64_t N, std::vector<int32_t>& len,
-                      std::vector<int32_t>& order, std::vector<int32_t>& padded, uint8_t* flipped) {
+static void list_plan(const uint64_t* rows64, int64_t G, int64_t N, int64_t gpw,
+                      std::vector<int32_t>& len, std::vector<int32_t>& order,
+                      std::vector<int32_t>& padded, uint8_t* flipped) {
   const int64_t W = (N + 63) / 64;
   len.assign(G, 0);
   order.assign(G, 0);
@@ -296,26 +297,30 @@ static void list_plan(const uint64_t* rows64, int64_t G, int64_t N, std::vector<
   for (int64_t g = 0; g < G; ++g) ++bucket[N - len[g] + 1];
   for (int64_t k = 1; k <= N + 1; ++k) bucket[k] += bucket[k - 1];
   for (int64_t g = 0; g < G; ++g) order[bucket[N - len[g]]++] = (int32_t)g;
-  for (int64_t q = 0; q < G; q += kListQuad) {
-    const int64_t L = (len[order[q]] + kListPad - 1) / kListPad * kListPad;  // longest of the quad
-    for (int64_t k = q; k < G && k < q + kListQuad; ++k) padded[k] = (int32_t)L;
+  for (int64_t q = 0; q < G; q += gpw) {
+    const int64_t L = (len[order[q]] + kListPad - 1) / kListPad * kListPad;  // longest of the group
+    for (int64_t k = q; k < G && k < q + gpw; ++k) padded[k] = (int32_t)L;
   }
 }
 
-int64_t scoary_lists_count(const uint64_t* rows64, int64_t G, int64_t N) {
+int64_t scoary_lists_count(const uint64_t* rows64, int64_t G, int64_t N, int64_t genes_per_wave) {
   std::vector<int32_t> len, order, padded;
-  list_plan(rows64, G, N, len, order, padded, nullptr);
+  list_plan(rows64, G, N, genes_per_wave, len, order, padded, nullptr);
   int64_t total = 0;
   for (int64_t k = 0; k < G; ++k) total += padded[k];
   return total;
 }
 
-void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t row_stride_dwords,
-                        uint32_t* idx, int32_t* start, int32_t* ngroups, int32_t* order_out,
-                        uint8_t* flipped) {
+void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t row_stride,
+                        int64_t genes_per_wave, int64_t classes, uint32_t* idx, int32_t* start,
+                        int32_t* ngroups, int32_t* order_out, uint8_t* flipped) {
   const int64_t W = (N + 63) / 64;
   std::vector<int32_t> len, order, padded;
-  list_plan(rows64, G, N, len, order, padded, flipped);
+  list_plan(rows64, G, N, genes_per_wave, len, order, padded, flipped);
+  // bit masks of the isolate positions congruent to c modulo `classes` (a power
+  // of two <= 64, so the pattern is the same in every 64-bit word)
+  std::vector<uint64_t> cmask(classes, 0);
+  for (int b = 0; b < 64; ++b) cmask[b % classes] |= (uint64_t)1 << b;
   int64_t pos = 0;
   for (int64_t k = 0; k < G; ++k) {
     const int64_t g = order[k];
@@ -324,25 +329,24 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
     const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
     start[k] = (int32_t)(pos / kListPad);
     ngroups[k] = (int32_t)(padded[k] / kListPad);
-    // Slots k and k^1 share a 32-lane half of the wavefront and read the LDS
-    // label tile in lockstep; even slots walk their even-numbered isolates
-    // first, odd slots their odd-numbered ones, so the two hit different bank
-    // halves (a row starts at bank 0 or 16 by the parity of its index).
+    // The `classes` lane groups of a 32-lane half read the LDS label tile in
+    // lockstep, and a row's bank range is fixed by (isolate index mod classes).
+    // Slot k starts with the rows of class (k mod classes) and rotates through
+    // the classes, so the groups of a half hit disjoint banks.
     int64_t n = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-      const uint64_t want_odd = (uint64_t)((k & 1) ^ pass);      // parity taken in this pass
-      const uint64_t sel = want_odd ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull;
+    for (int64_t pass = 0; pass < classes; ++pass) {
+      const uint64_t sel = cmask[(k + pass) % classes];
       for (int64_t w = 0; w < W; ++w) {
         uint64_t bits = (r[w] ^ inv) & sel;
         if (w == W - 1 && (N & 63)) bits &= (((uint64_t)1 << (N & 63)) - 1);
         while (bits) {
           const int b = __builtin_ctzll(bits);
           bits &= bits - 1;
-          idx[pos + n++] = (uint32_t)((w * 64 + b) * row_stride_dwords);
+          idx[pos + n++] = (uint32_t)((w * 64 + b) * row_stride);
         }
       }
     }
-    while (n < padded[k]) idx[pos + n++] = (uint32_t)(N * row_stride_dwords);
+    while (n < padded[k]) idx[pos + n++] = (uint32_t)(N * row_stride);
     pos += n;
   }
 }

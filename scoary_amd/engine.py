@@ -141,11 +141,20 @@ class AssociationEngine:
         the same genes as ``genes``) for the list-driven permutation kernel."""
         torch = _torch()
         from . import io_native
-        d = io_native.build_lists(rows64, genes.N, int(self.lib.scoary_list_row_stride()))
+        lanes, stride, gpw, classes = self.list_params(genes.N)
+        if not lanes:
+            raise ValueError("N=%d is too large for the list-driven kernel" % genes.N)
+        d = io_native.build_lists(rows64, genes.N, stride, gpw, classes)
         dev = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(self.device)  # noqa: E731
         genes.lists = GeneLists(dev(d["idx"]), dev(d["start"]), dev(d["ngroups"]),
                                 dev(d["order"]), dev(d["flipped"]), d["entries"])
         return genes.lists
+
+    def list_params(self, N):
+        """(lanes per gene, row stride bytes, genes per wavefront, classes)."""
+        out = (ctypes.c_int64 * 4)()
+        self.lib.scoary_list_params(int(N), out)
+        return tuple(int(x) for x in out)
 
     def lists_supported(self, N):
         return int(N) <= int(self.lib.scoary_list_max_isolates())
@@ -244,6 +253,7 @@ class AssociationEngine:
             T = traits.shape[0]
             r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
             per = int(self.lib.scoary_list_tiles_words(genes.N, 512, T)) * 4   # bytes / 512 perms
+            per = max(per, 1)
             batch = int(max(512, min(-(-permutations // 512) * 512, ((8 << 30) // per) * 512)))
             done = 0
             while done < permutations:

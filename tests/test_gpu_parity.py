@@ -312,6 +312,8 @@ def test_headline_config_properties(eng, orc):
 @pytest.mark.parametrize("G,N,T,P", [
     (1, 1, 1, 10), (7, 40, 2, 33), (300, 100, 2, 512), (513, 130, 3, 600), (1000, 500, 1, 1100),
     (400, 700, 2, 65), (260, 1500, 1, 700), (500, 2000, 3, 1030), (90, 2400, 2, 520),
+    (64, 2559, 1, 513), (70, 2560, 1, 300), (130, 3000, 2, 260), (200, 4000, 1, 530),
+    (90, 5000, 2, 257), (40, 5119, 1, 100),          # 8 lanes per gene, tiles of 256
 ])
 def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     """The list-driven kernel (minority lists + bit-sliced counters) gives
@@ -338,11 +340,12 @@ def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     assert np.array_equal(lists.view(np.uint32), want)
 
 
-def test_perm_tiles_are_the_transposed_row_labels(eng):
+@pytest.mark.parametrize("N", [333, 2700])
+def test_perm_tiles_are_the_transposed_row_labels(eng, N):
     """k_perm_generate_tiles writes the same spec-S4 labels as k_perm_generate,
     isolate-major in tiles of 512 permutations, zero row + zero ragged tail."""
     rng = np.random.default_rng(2)
-    N, T, P, base = 333, 2, 700, 40
+    T, P, base = 2, 700, 40
     traits = (rng.random((T, N)) < 0.4).astype(np.uint8)
     traits[1, rng.random(N) < 0.1] = 2
     tb, mb = _bits(eng, traits)
@@ -350,16 +353,18 @@ def test_perm_tiles_are_the_transposed_row_labels(eng):
     _, margins = eng.counts(eng.pack_dense(np.ones((1, N), dtype=np.uint8)), trv, masks)
     rows = eng.perm_generate(masks, margins, N, P, base, 5).cpu().numpy().view(np.uint32)
     tiles = eng.perm_generate_tiles(masks, margins, N, P, base, 5).cpu().numpy().view(np.uint32)
-    RS = int(eng.lib.scoary_list_row_stride()) // 4
-    ntiles = -(-P // 512)
+    lanes, stride, gpw, classes = eng.list_params(N)
+    RS = stride // 4
+    tperm = lanes * 32
+    ntiles = -(-P // tperm)
     tw = int(eng.lib.scoary_list_tile_words(N))
     tiles = tiles.reshape(T, ntiles, tw)[:, :, :(N + 1) * RS].reshape(T, ntiles, N + 1, RS)
     bits = np.unpackbits(rows.view(np.uint8).reshape(T, P, -1), axis=2, bitorder="little")[:, :, :N]
     for t in range(T):
         for tile in range(ntiles):
-            tb_ = np.unpackbits(np.ascontiguousarray(tiles[t, tile, :, :16]).view(np.uint8),
-                                axis=1, bitorder="little")            # (N+1, 512)
+            tb_ = np.unpackbits(np.ascontiguousarray(tiles[t, tile, :, :lanes]).view(np.uint8),
+                                axis=1, bitorder="little")            # (N+1, tile perms)
             assert not tb_[N].any()
-            lo, hi = tile * 512, min(P, tile * 512 + 512)
+            lo, hi = tile * tperm, min(P, tile * tperm + tperm)
             assert np.array_equal(tb_[:N, :hi - lo], bits[t, lo:hi].T)
             assert not tb_[:N, hi - lo:].any()

@@ -330,7 +330,8 @@ def test_io_library_exports_every_declared_symbol():
 
 
 # ------------------------------------------------- minority index lists ------
-def test_minority_lists_builder():
+@pytest.mark.parametrize("gpw,classes,stride", [(4, 2, 64), (8, 4, 32)])
+def test_minority_lists_builder(gpw, classes, stride):
     """scoary_lists_build (host native): per gene the positions of its minority
     value, padded with N to a multiple of 32 and to the quad's longest list,
     genes ordered by descending length, even slots even-rows-first / odd slots
@@ -338,11 +339,11 @@ def test_minority_lists_builder():
     from scoary_amd import io_native
     from scoary_amd.engine import pack_bits_rows
     rng = np.random.default_rng(9)
-    G, N, stride = 203, 333, 64
+    G, N = 203, 333
     dense = (rng.random((G, N)) < rng.uniform(0.0, 1.0, (G, 1))).astype(np.uint8)
     dense[0] = 0
     dense[1] = 1
-    L = io_native.build_lists(pack_bits_rows(dense), N, stride)
+    L = io_native.build_lists(pack_bits_rows(dense), N, stride, gpw, classes)
     order, start, ng, flipped = L["order"], L["start"], L["ngroups"], L["flipped"]
     assert sorted(order.tolist()) == list(range(G))
     n1 = dense.sum(1).astype(np.int64)
@@ -355,18 +356,19 @@ def test_minority_lists_builder():
         ent = L["idx"][start[k] * 32:(start[k] + ng[k]) * 32]
         assert start[k] * 32 == total
         total += ng[k] * 32
-        assert ng[k] == ng[(k // 4) * 4]                            # equal within a quad
-        assert ng[k] * 32 >= length[g] and (ng[(k // 4) * 4] * 32 - length[order[(k // 4) * 4]]) < 32
+        assert ng[k] == ng[(k // gpw) * gpw]                        # equal within a wave group
+        assert ng[k] * 32 >= length[g] and \
+            (ng[(k // gpw) * gpw] * 32 - length[order[(k // gpw) * gpw]]) < 32
         assert np.all(ent % stride == 0)
         pos = (ent // stride).astype(np.int64)
         real = pos[:length[g]]
         assert np.all(pos[length[g]:] == N)                         # padding -> zero row
         want = np.nonzero(dense[g] == (0 if flipped[g] else 1))[0]
         assert sorted(real.tolist()) == want.tolist()
-        first = k & 1                                               # parity walked first
-        par = real & 1
-        assert np.all(np.diff((par != first).astype(int)) >= 0)     # one switch at most
-        for cls in (0, 1):
-            sub = real[par == cls]
-            assert np.all(np.diff(sub) > 0)                         # ascending within parity
+        cls = real % classes                                        # classes in rotation order
+        rot = (cls - k) % classes
+        assert np.all(np.diff(rot) >= 0)
+        for c in range(classes):
+            sub = real[cls == c]
+            assert np.all(np.diff(sub) > 0)                         # ascending within a class
     assert L["entries"] == total and len(L["idx"]) >= total + 32
