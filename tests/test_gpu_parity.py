@@ -368,3 +368,58 @@ def test_perm_tiles_are_the_transposed_row_labels(eng, N):
             lo, hi = tile * tperm, min(P, tile * tperm + tperm)
             assert np.array_equal(tb_[:N, :hi - lo], bits[t, lo:hi].T)
             assert not tb_[:N, hi - lo:].any()
+
+
+def test_capacity_config_shard_vs_oracle_subsample(eng, orc):
+    """BASELINE configs[4] ("HBM-capacity stress", 1M x 10000 x 50 over 8 GPUs):
+    one GPU's row length and trait count at a reduced gene / permutation count
+    (the per-GPU shard is 125k genes; 20k here keep the host-side generation
+    short).  Exercises the chunked dense kernel (N > 5119), 50 traits, int64
+    indexing; a gene subsample is compared with the oracle bit for bit."""
+    from scoary_amd import synth
+    rng = np.random.default_rng(20260904)
+    G, N, T, P = 20000, 10000, 50, 96
+    genes = synth.make_genes(G, N, rng, core_frac=0.05)
+    traits = synth.make_traits(T, N, rng, missing_traits=(8, 9, 33))
+    tb, mb = _bits(eng, traits)
+    assert not eng.lists_supported(N)
+    res = eng.associate(eng.pack_dense(genes), eng.vecrows(tb, N), eng.vecrows(mb, N),
+                        permutations=P, seed=11)
+    counts = res["counts"].cpu().numpy()
+    r = res["r"].cpu().numpy().view(np.uint32)
+    p = res["p"].cpu().numpy()
+    nval = (traits != 2).sum(1)
+    assert np.array_equal(counts.sum(2), np.broadcast_to(nval[:, None], (T, G)))
+    assert r.max() <= P
+    sub = np.arange(0, G, 331)
+    gb = orc.pack_rows(genes[sub])
+    want_c = orc.counts_packed(gb, tb, mb).transpose(1, 0, 2)
+    assert np.array_equal(counts[:, sub], want_c)
+    _, want_p = orc.fisher_many(np.ascontiguousarray(want_c).reshape(-1, 4))
+    assert np.max(np.abs(p[:, sub].ravel() - want_p)) < P_TOL
+    assert np.array_equal(r[:, sub], orc.permute_r(gb, tb, mb, N, P, 11).T)
+
+
+def test_c_abi_error_codes(eng):
+    """Bad arguments come back as negative status + message, never a crash."""
+    import ctypes
+    import torch
+    lib, h = eng.lib, eng.h
+    null = ctypes.c_void_p()
+    buf = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    p = ctypes.c_void_p(buf.data_ptr())
+    assert lib.scoary_counts(h, null, p, p, 1, 1, 1, p, p, null) == -1
+    assert b"scoary_counts" in lib.scoary_last_error(h)
+    assert lib.scoary_fisher(h, p, 0, p, p, null, null) == -1
+    assert lib.scoary_permute(h, p, p, p, 1, 70000, 10, 10, p, null) == -3          # T > 65535
+    assert lib.scoary_perm_generate(h, p, p, 1, 10, 2**33, 0, 0, 1, p, null) == -3   # index >= 2^32
+    assert lib.scoary_permute_lists(h, p, p, p, p, p, p, p, p, p, 4, 1, 6000, 10, p, null) == -3
+    assert b"LDS" in lib.scoary_last_error(h)
+    assert lib.scoary_tree_pairs(h, p, 3, 40, p, p, 1, 1, 2, p, null) == -3          # stack_depth > 32
+    assert lib.scoary_counts(null, p, p, p, 1, 1, 1, p, p, null) == -1
+    out = ctypes.c_void_p()
+    assert lib.scoary_create(99, ctypes.byref(out)) == -4 and not out.value
+    params = (ctypes.c_int64 * 4)()
+    assert lib.scoary_list_params(2000, params) == 0 and list(params) == [16, 64, 4, 2]
+    assert lib.scoary_list_params(5000, params) == 0 and list(params) == [8, 32, 8, 4]
+    assert lib.scoary_list_params(5120, params) == -3 and params[0] == 0
