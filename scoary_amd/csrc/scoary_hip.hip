@@ -824,105 +824,108 @@ __global__ __launch_bounds__(256) void k_row_hash(const uint4* __restrict__ tile
 // f-1: maximum contrasting pairs on a tree (PhyloTree, scoary/classes.py:199-592)
 // ----------------------------------------------------------------------------
 // State index 0 = AB, 1 = Ab, 2 = aB, 3 = ab, 4 = "0" (no free path); per state
-// (total, supporting, opposing) pairs, -1 = unreachable.
+// (total, supporting, opposing) pairs, or "unreachable".
+//
+// The reference keeps, per state, the best total and -- among the candidate
+// pairings that reach it -- the best supporting and the best opposing count,
+// each maximised on its own (classes.py:407-453).  That rule is exactly an
+// integer max over two packed keys
+//     ks = total << 16 | supporting      ko = total << 16 | opposing
+// (counts <= tips/2 < 2^15, so adding two keys never carries between fields),
+// with "unreachable" = a large negative key that stays negative through one
+// addition and is re-clamped after every merge.  A pairing of a left and a
+// right state is then TWO integer adds, choosing between pairings TWO v_max.
 struct TreeNode {
-  int tot[5], pro[5], anti[5];
+  int ks[5], ko[5];
 };
-
-// One candidate pairing of a left state with a right state
-// (classes.py:320-405 / :492-539).  Keeps the best total and, among the
-// candidates that reach it, the best supporting and best opposing counts
-// independently (classes.py:407-453).
-__device__ __forceinline__ void tree_candidate(const TreeNode& L, int ls, const TreeNode& R, int rs,
-                                               int dt, int dp, int da, int& bt, int& bp, int& ba) {
-  if (L.tot[ls] > -1 && R.tot[rs] > -1) {
-    const int t = L.tot[ls] + R.tot[rs] + dt;
-    const int p = L.pro[ls] + R.pro[rs] + dp;
-    const int a = L.anti[ls] + R.anti[rs] + da;
-    if (t > bt) {
-      bt = t;
-      bp = p;
-      ba = a;
-    } else if (t == bt) {
-      bp = max(bp, p);
-      ba = max(ba, a);
-    }
-  }
-}
-
-__device__ __forceinline__ void tree_merge(const TreeNode& L, const TreeNode& R, TreeNode& out) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {  // a free path to state c survives on one side
-    int bt = -1, bp = -1, ba = -1;
-#pragma unroll
-    for (int x = 0; x < 5; ++x) tree_candidate(L, c, R, x, 0, 0, 0, bt, bp, ba);
-#pragma unroll
-    for (int x = 0; x < 5; ++x)
-      if (x != c) tree_candidate(L, x, R, c, 0, 0, 0, bt, bp, ba);
-    out.tot[c] = bt;
-    out.pro[c] = bp;
-    out.anti[c] = ba;
-  }
-  int bt = -1, bp = -1, ba = -1;  // no free path: both closed, or one new pair across the root
-  tree_candidate(L, 4, R, 4, 0, 0, 0, bt, bp, ba);
-  tree_candidate(L, 0, R, 3, 1, 1, 0, bt, bp, ba);
-  tree_candidate(L, 3, R, 0, 1, 1, 0, bt, bp, ba);
-  tree_candidate(L, 1, R, 2, 1, 0, 1, bt, bp, ba);
-  tree_candidate(L, 2, R, 1, 1, 0, 1, bt, bp, ba);
-  out.tot[4] = bt;
-  out.pro[4] = bp;
-  out.anti[4] = ba;
-}
-
-// Merge with a Tip of state s (one-hot node, classes.py:575-592): the generic
-// candidate list collapses to
-//   out[c] = L[c]                          for the free states c != s,
-//   out[s] = best of ALL five states of L  (the tip supplies the free path),
-//   out[4] = L[3 - s] + one new pair       (AB|ab supporting, Ab|aB opposing),
-// ~20x fewer VALU ops than tree_merge; about half the merges of a tree are these.
-__device__ __forceinline__ void tree_merge_tip(const TreeNode& L, int s, TreeNode& out) {
-  int bt = -1, bp = -1, ba = -1;
-#pragma unroll
-  for (int x = 0; x < 5; ++x) {
-    if (L.tot[x] > bt) {
-      bt = L.tot[x];
-      bp = L.pro[x];
-      ba = L.anti[x];
-    } else if (L.tot[x] == bt) {
-      bp = max(bp, L.pro[x]);
-      ba = max(ba, L.anti[x]);
-    }
-  }
-  const int cs = 3 - s;
-  int ct = -1, cp = -1, ca = -1;
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-    if (x == cs) {
-      ct = L.tot[x];
-      cp = L.pro[x];
-      ca = L.anti[x];
-    }
-  const bool pair = ct > -1;
-  const bool supporting = (s == 0) || (s == 3);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    out.tot[c] = (c == s) ? bt : L.tot[c];
-    out.pro[c] = (c == s) ? bp : L.pro[c];
-    out.anti[c] = (c == s) ? ba : L.anti[c];
-  }
-  out.tot[4] = pair ? ct + 1 : -1;
-  out.pro[4] = pair ? cp + (supporting ? 1 : 0) : -1;
-  out.anti[4] = pair ? ca + (supporting ? 0 : 1) : -1;
-}
+constexpr int kTreeNone = -(1 << 30);
 
 __device__ __forceinline__ void tree_tip(TreeNode& n, int state) {
 #pragma unroll
-  for (int c = 0; c < 5; ++c) n.tot[c] = n.pro[c] = n.anti[c] = (c == state) ? 0 : -1;
+  for (int c = 0; c < 5; ++c) n.ks[c] = n.ko[c] = (c == state) ? 0 : kTreeNone;
+}
+
+// Generic node merge (classes.py:268-572).  For a free state c the nine
+// candidates of the reference are {L[c]} x {all five R states} and
+// {the four L states other than c} x {R[c]}; max distributes over +, so
+//   out[c] = max( L[c] + max(R[0..4]),  max(L[x], x != c) + R[c] ).
+// "No free path": both closed, or one new pair across the root (+1 total and
+// +1 supporting for AB|ab, +1 opposing for Ab|aB).  ~80 VALU ops.
+__device__ __forceinline__ void tree_merge(const TreeNode& L, const TreeNode& R, TreeNode& out) {
+  int rs = R.ks[0], ro = R.ko[0];
+#pragma unroll
+  for (int x = 1; x < 5; ++x) {
+    rs = max(rs, R.ks[x]);
+    ro = max(ro, R.ko[x]);
+  }
+  // max of L over the states below / above c
+  int pre_s[5], pre_o[5], suf_s[5], suf_o[5];
+  pre_s[0] = pre_o[0] = kTreeNone;
+#pragma unroll
+  for (int x = 1; x < 5; ++x) {
+    pre_s[x] = max(pre_s[x - 1], L.ks[x - 1]);
+    pre_o[x] = max(pre_o[x - 1], L.ko[x - 1]);
+  }
+  suf_s[4] = suf_o[4] = kTreeNone;
+#pragma unroll
+  for (int x = 3; x >= 0; --x) {
+    suf_s[x] = max(suf_s[x + 1], L.ks[x + 1]);
+    suf_o[x] = max(suf_o[x + 1], L.ko[x + 1]);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int es = max(pre_s[c], suf_s[c]), eo = max(pre_o[c], suf_o[c]);
+    out.ks[c] = max(max(L.ks[c] + rs, es + R.ks[c]), kTreeNone);
+    out.ko[c] = max(max(L.ko[c] + ro, eo + R.ko[c]), kTreeNone);
+  }
+  constexpr int kPair = 1 << 16;
+  int ns = L.ks[4] + R.ks[4], no = L.ko[4] + R.ko[4];
+  ns = max(ns, L.ks[0] + R.ks[3] + (kPair + 1));
+  no = max(no, L.ko[0] + R.ko[3] + kPair);
+  ns = max(ns, L.ks[3] + R.ks[0] + (kPair + 1));
+  no = max(no, L.ko[3] + R.ko[0] + kPair);
+  ns = max(ns, L.ks[1] + R.ks[2] + kPair);
+  no = max(no, L.ko[1] + R.ko[2] + (kPair + 1));
+  ns = max(ns, L.ks[2] + R.ks[1] + kPair);
+  no = max(no, L.ko[2] + R.ko[1] + (kPair + 1));
+  out.ks[4] = max(ns, kTreeNone);
+  out.ko[4] = max(no, kTreeNone);
+}
+
+// Merge with a Tip of state s (one-hot node, classes.py:575-592): the candidate
+// list collapses to
+//   out[c] = L[c]                          for the free states c != s,
+//   out[s] = best of ALL five states of L  (the tip supplies the free path),
+//   out[4] = L[3 - s] + one new pair       (AB|ab supporting, Ab|aB opposing).
+__device__ __forceinline__ void tree_merge_tip(const TreeNode& L, int s, TreeNode& out) {
+  int as = L.ks[0], ao = L.ko[0];
+#pragma unroll
+  for (int x = 1; x < 5; ++x) {
+    as = max(as, L.ks[x]);
+    ao = max(ao, L.ko[x]);
+  }
+  const int cs = 3 - s;
+  int ps = kTreeNone, po = kTreeNone;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+    if (x == cs) {
+      ps = L.ks[x];
+      po = L.ko[x];
+    }
+  const bool supporting = (s == 0) || (s == 3);
+  constexpr int kPair = 1 << 16;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    out.ks[c] = (c == s) ? as : L.ks[c];
+    out.ko[c] = (c == s) ? ao : L.ko[c];
+  }
+  out.ks[4] = max(ps + kPair + (supporting ? 1 : 0), kTreeNone);
+  out.ko[4] = max(po + kPair + (supporting ? 0 : 1), kTreeNone);
 }
 
 // One thread per (gene row g, label row l).  The stack program is wave-uniform
 // (scalar loads, uniform branches); the top of the stack lives in registers,
-// deeper entries in LDS as int16 [depth][15][64 lanes].
+// deeper entries in LDS as int32 keys [depth][10][64 lanes].
 template <bool EXCEED>
 __global__ __launch_bounds__(64) void k_tree_dp(const int32_t* __restrict__ ops, int nops,
                                                 const uint32_t* __restrict__ gene_bits,
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(64) void k_tree_dp(const int32_t* __restrict__ ops,
                                                 int64_t L, int Wt, const int32_t* __restrict__ obs,
                                                 int32_t* __restrict__ out3,
                                                 uint8_t* __restrict__ exceed) {
-  extern __shared__ __attribute__((aligned(16))) short stack_lds[];
+  extern __shared__ __attribute__((aligned(16))) int stack_lds[];
   const int lane = threadIdx.x;
   const int64_t id = (int64_t)blockIdx.x * kWave + lane;
   const bool live = id < G * L;
@@ -949,9 +952,8 @@ __global__ __launch_bounds__(64) void k_tree_dp(const int32_t* __restrict__ ops,
       --sp;
 #pragma unroll
       for (int f = 0; f < 5; ++f) {
-        left.tot[f] = stack_lds[((sp * 15) + f) * kWave + lane];
-        left.pro[f] = stack_lds[((sp * 15) + 5 + f) * kWave + lane];
-        left.anti[f] = stack_lds[((sp * 15) + 10 + f) * kWave + lane];
+        left.ks[f] = stack_lds[((sp * 10) + f) * kWave + lane];
+        left.ko[f] = stack_lds[((sp * 10) + 5 + f) * kWave + lane];
       }
       TreeNode m;
       tree_merge(left, top, m);
@@ -968,9 +970,8 @@ __global__ __launch_bounds__(64) void k_tree_dp(const int32_t* __restrict__ ops,
         if (k > 0) {
 #pragma unroll
           for (int f = 0; f < 5; ++f) {
-            stack_lds[((sp * 15) + f) * kWave + lane] = (short)top.tot[f];
-            stack_lds[((sp * 15) + 5 + f) * kWave + lane] = (short)top.pro[f];
-            stack_lds[((sp * 15) + 10 + f) * kWave + lane] = (short)top.anti[f];
+            stack_lds[((sp * 10) + f) * kWave + lane] = top.ks[f];
+            stack_lds[((sp * 10) + 5 + f) * kWave + lane] = top.ko[f];
           }
           ++sp;
         }
@@ -983,12 +984,14 @@ __global__ __launch_bounds__(64) void k_tree_dp(const int32_t* __restrict__ ops,
     }
   }
   if (!live) return;
+  // three independent maxima over the five states (classes.py:246-249)
   int bt = -1, bp = -1, ba = -1;
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
-    bt = max(bt, top.tot[c]);
-    bp = max(bp, top.pro[c]);
-    ba = max(ba, top.anti[c]);
+    const bool ok = top.ks[c] >= 0;
+    bt = max(bt, ok ? (top.ks[c] >> 16) : -1);
+    bp = max(bp, ok ? (top.ks[c] & 0xffff) : -1);
+    ba = max(ba, ok ? (top.ko[c] & 0xffff) : -1);
   }
   if (!EXCEED) {
     out3[id * 3 + 0] = bt;
@@ -1314,13 +1317,13 @@ static int launch_tree(scoary_handle h, const char* what, bool exceed_mode, cons
       stack_depth < 1 || (exceed_mode ? (!d_obs || !d_exceed) : !d_out3))
     return fail(h, SCOARY_ERR_ARG, std::string(what) + ": bad argument");
   if (stack_depth > 32) return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": stack_depth > 32");
-  if (K > 32767 * 2) return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": more than 65534 tips");
+  if (K > 65534) return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": more than 65534 tips");
   const int64_t threads = G * L;
   if ((threads + kWave - 1) / kWave > 0x7fffffffLL)
     return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": G*L too large for one launch");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)stack_depth * 15 * kWave * sizeof(short);
+  const size_t lds = (size_t)stack_depth * 10 * kWave * sizeof(int);
   const int Wt = (int)((K + 31) / 32);
   dim3 grid((unsigned)((threads + kWave - 1) / kWave));
   KernelTimer kt(h, s, "k_tree_dp");
