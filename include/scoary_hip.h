@@ -111,7 +111,7 @@ int scoary_fisher(scoary_handle h, const int32_t *d_tables, int64_t M,
  * the number that enters the Philox counter): the
  * trait's npos positive labels placed on a uniformly random subset of its
  * valid isolates (counter-based: Philox4x32-10 keyed by `seed`, counter
- * (isolate>>1, pi, trait, "SCOA"), sequential selection sampling -- DESIGN.md
+ * (isolate>>2, pi, trait, "SCOA"), sequential selection sampling -- DESIGN.md
  * spec S4; the CPU oracle regenerates the same bits).
  *   d_perms : vecrows [T][P][Wp] */
 int scoary_perm_generate(scoary_handle h, const uint32_t *d_masks,

@@ -211,8 +211,9 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2],
  * of size npos of the valid isolates (== shuffling the 0/1 labels among the
  * non-missing isolates, PermuteGTC methods.py:1377-1383), by sequential
  * selection sampling (Knuth 3.4.2 Algorithm S).  Isolate i consumes the
- * 64-bit draw u = Philox(key = seed, ctr = (i>>1, pi, t, "SCOA")) words
- * (2*(i&1), 2*(i&1)+1); it is selected iff  mulhi64(u, remaining) < needed. */
+ * 32-bit draw u = word (i&3) of Philox(key = seed, ctr = (i>>2, pi, t, "SCOA"));
+ * it is selected iff  (u * remaining) >> 32 < needed  (the selection
+ * probability needed/remaining rounded up to a multiple of 2^-32). */
 void orc_perm_labels(uint64_t seed, uint32_t t, uint32_t pi,
                      const uint64_t *mask, int64_t npos, int64_t N,
                      uint64_t *out)
@@ -225,15 +226,13 @@ void orc_perm_labels(uint64_t seed, uint32_t t, uint32_t pi,
     memset(out, 0, (size_t)W * sizeof(uint64_t));
     uint32_t rnd[4] = {0, 0, 0, 0};
     for (int64_t i = 0; i < N; ++i) {
-        if (!(i & 1)) {
-            uint32_t ctr[4] = {(uint32_t)(i >> 1), pi, t, ORC_PERM_DOMAIN};
+        if (!(i & 3)) {
+            uint32_t ctr[4] = {(uint32_t)(i >> 2), pi, t, ORC_PERM_DOMAIN};
             orc_philox4x32_10(ctr, key, rnd);
         }
         if (!((mask[i >> 6] >> (i & 63)) & 1))
             continue;
-        uint64_t u = (i & 1) ? ((uint64_t)rnd[3] << 32 | rnd[2])
-                             : ((uint64_t)rnd[1] << 32 | rnd[0]);
-        uint64_t hi = (uint64_t)(((unsigned __int128)u * remaining) >> 64);
+        uint64_t hi = ((uint64_t)rnd[i & 3] * remaining) >> 32;
         if (hi < needed) {
             out[i >> 6] |= (uint64_t)1 << (i & 63);
             --needed;

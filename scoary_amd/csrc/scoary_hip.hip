@@ -266,7 +266,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // One thread per (trait, permutation): sequential selection sampling over the
 // isolates, 32 at a time; the validity word is wave-uniform (blockIdx.y =
-// trait), the 64-bit draws come from Philox keyed by (isolate>>1, pi, trait).
+// trait), the 32-bit draws come from Philox keyed by (isolate>>2, pi, trait).
 __global__ __launch_bounds__(64) void k_perm_generate(const uint32_t* __restrict__ masks,
                                                       const int32_t* __restrict__ margins, int N,
                                                       int Wp, int64_t P, int64_t perm_base,
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void k_perm_generate(const uint32_t* __restrict
   const int64_t pl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pl >= P) return;
   const uint32_t pi = (uint32_t)(perm_base + pl);
-  uint64_t needed = (uint64_t)margins[2 * t], remaining = (uint64_t)margins[2 * t + 1];
+  uint32_t needed = (uint32_t)margins[2 * t], remaining = (uint32_t)margins[2 * t + 1];
   const uint32_t* mrow = masks + (int64_t)t * Wp;
   uint32_t* out = perms + ((int64_t)t * P + pl) * Wp;
   const int nw = (N + 31) / 32;
@@ -284,24 +284,19 @@ __global__ __launch_bounds__(64) void k_perm_generate(const uint32_t* __restrict
     const uint32_t mw = mrow[k];
     uint32_t word = 0;
 #pragma unroll 4
-    for (int jj = 0; jj < 16; ++jj) {
+    for (int jj = 0; jj < 8; ++jj) {             // one Philox call = four isolates
       uint32_t r[4];
-      philox4x32_10((uint32_t)(k * 16 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
-      if ((mw >> (2 * jj)) & 1u) {
-        const uint64_t u = ((uint64_t)r[1] << 32) | r[0];
-        if (__umul64hi(u, remaining) < needed) {
-          word |= 1u << (2 * jj);
-          --needed;
+      philox4x32_10((uint32_t)(k * 8 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int bit = 4 * jj + q;
+        if ((mw >> bit) & 1u) {
+          if (__umulhi(r[q], remaining) < needed) {
+            word |= 1u << bit;
+            --needed;
+          }
+          --remaining;
         }
-        --remaining;
-      }
-      if ((mw >> (2 * jj + 1)) & 1u) {
-        const uint64_t u = ((uint64_t)r[3] << 32) | r[2];
-        if (__umul64hi(u, remaining) < needed) {
-          word |= 1u << (2 * jj + 1);
-          --needed;
-        }
-        --remaining;
       }
     }
     out[k] = word;
@@ -490,23 +485,22 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
   const int tile = (int)(wave / waves_per_tile);
   const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
   uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG) + col;
-  uint64_t needed = (uint64_t)margins[2 * t], remaining = (uint64_t)margins[2 * t + 1];
+  uint32_t needed = (uint32_t)margins[2 * t], remaining = (uint32_t)margins[2 * t + 1];
   const uint32_t* mrow = masks + (int64_t)t * Wp;
   const int nw = (N + 31) / 32;
   uint64_t mine = 0;
   for (int k = 0; k < nw; ++k) {
     const uint32_t mw = mrow[k];
 #pragma unroll 2
-    for (int jj = 0; jj < 16; ++jj) {
+    for (int jj = 0; jj < 8; ++jj) {
       uint32_t r[4];
-      philox4x32_10((uint32_t)(k * 16 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
+      philox4x32_10((uint32_t)(k * 8 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int bit = 2 * jj + h;
+      for (int q = 0; q < 4; ++q) {
+        const int bit = 4 * jj + q;
         bool sel = false;
         if ((mw >> bit) & 1u) {
-          const uint64_t u = ((uint64_t)r[2 * h + 1] << 32) | r[2 * h];
-          if (__umul64hi(u, remaining) < needed) {
+          if (__umulhi(r[q], remaining) < needed) {
             sel = live;
             --needed;
           }
@@ -1016,6 +1010,7 @@ struct scoary_ctx {
   int num_cu = 256;
   std::string err;
   bool timing = false;
+  int lists_lds_optin = 0;   // k_permute_lists variants (by LG) with the 160 KB LDS opt-in done
   struct Timed {
     std::string name;
     hipEvent_t start, stop;
@@ -1445,11 +1440,10 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   qpb = (qpb + 15) / 16 * 16;
   chunks = (nquads + qpb - 1) / qpb;
   const size_t lds = (size_t)(N + 1) * LG * sizeof(uint32_t);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(h->lists_lds_optin & LG)) {   // once per handle (= per device) and kernel variant
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_permute_lists<LG, KC, KD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    h->lists_lds_optin |= LG;
   }
   KernelTimer kt(h, s, "k_permute_lists");
   hipLaunchKernelGGL((k_permute_lists<LG, KC, KD>), dim3((unsigned)(ntiles * T), (unsigned)chunks),

@@ -30,8 +30,9 @@ def main():
         rows = c.execute("select name, total_calls, total_duration, average, percentage "
                          "from top_kernels").fetchall()
         with open(prefix + "_kernel_stats.txt", "w") as f:
-            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline "
-                    "--steps 5 --warmup 2   (durations in us)\n")
+            cmd = "python tools/bench_tree.py" if "tree" in (sys.argv[3] if len(sys.argv) > 3 else "") \
+                else "python bench.py --no-cpu-baseline --steps 5 --warmup 2"
+            f.write("# rocprofv3 --kernel-trace --stats -- %s   (durations in us)\n" % cmd)
             f.write("%-34s %6s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
             for name, calls, tot, avg, pct in rows:
                 f.write("%-34s %6d %14.3f %12.3f %8.3f\n" % (short(name)[:34], calls, tot, avg, pct))
