@@ -159,6 +159,7 @@ def main():
         recv_bufs = [torch.empty((world, T, G, sdist.REC_WORDS), dtype=torch.int32,
                                  device=eng.device) for _ in range(2)]
     step_no = [0]
+    exchange = ["gather"]
 
     def drain(keep=0):
         while len(pending) > keep:
@@ -170,9 +171,18 @@ def main():
         if world > 1:
             drain(keep=1)
             rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
-            _, finish = sdist.gather_genes(rec, G * world, dst=0, async_op=True,
-                                           recv=recv_bufs[step_no[0] % 2])
-            pending.append(finish)
+            if exchange[0] == "gather":
+                try:
+                    _, finish = sdist.gather_genes(rec, G * world, dst=0, async_op=True,
+                                                   recv=recv_bufs[step_no[0] % 2])
+                    pending.append(finish)
+                except (RuntimeError, NotImplementedError) as e:   # backend without gather
+                    if rank == 0:
+                        print("bench: dist.gather unavailable (%s); using all_gather" % e,
+                              file=sys.stderr)
+                    exchange[0] = "all_gather"
+            if exchange[0] == "all_gather":
+                res["gathered"] = sdist.all_gather_genes(rec, G * world)
             step_no[0] += 1
         return res
 
@@ -236,7 +246,9 @@ def main():
                                    "counts + Fisher + label permutations + exceedance counts"
                                    % (args.config, G, N, T, P),
                        "genes_per_gpu": G, "isolates": N, "traits": T, "permutations": P,
-                       "parallelism": "gene-shard x%d" % world},
+                       "parallelism": "gene-shard x%d" % world,
+                       "exchange": ("rccl %s of per-gene records" % exchange[0]) if world > 1
+                       else "none (single GPU)"},
             "roofline": {
                 "bound": "hbm",
                 "kernel": k3_name,
