@@ -144,7 +144,7 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T);
 int64_t scoary_list_tile_words(int64_t N);   /* dwords per (trait, tile) */
 int64_t scoary_list_max_isolates(void);
-/* out4 = { lanes per gene (16 for N <= 2559, 8 for N <= 5119), row stride in
+/* out4 = { lanes per gene (16 for N <= 2559, 8 for N <= 5119, 4 for N <= 10239), row stride in
  * bytes, genes per wavefront, residue classes } -- the last three are the
  * arguments scoary_lists_build wants.  Error if N is too large. */
 int scoary_list_params(int64_t N, int64_t *out4);

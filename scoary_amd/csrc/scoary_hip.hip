@@ -432,16 +432,20 @@ __global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict_
 // A wavefront = 64/LG lane groups = 64/LG genes of similar list length.
 // LG = lanes (32-permutation words) per gene: 16 while a tile of 512
 // permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
-// N <= 5119.  One wavefront processes 64/LG genes; the 32/LG lane groups of a
-// 32-lane half read LDS in lockstep.
+// N <= 5119, 4 (tiles of 128) up to N <= 10239.  One wavefront processes 64/LG
+// genes; the 32/LG lane groups of a 32-lane half read LDS in lockstep.
 // LDS row stride in dwords.  No padding: with a 16-dword stride a row starts at
 // bank 0 or 16 by the PARITY of its isolate index, and the list builder orders
 // the two genes that share a 32-lane half so that one walks its even rows while
 // the other walks its odd rows (scoary_lists_build) -- conflict-free except where
 // their even/odd counts differ.
 __host__ __device__ constexpr int list_lg(int64_t N) {
-  return N <= 2559 ? 16 : (N <= 5119 ? 8 : 0);
+  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : 0));
 }
+// index entries held per lane and step: LG = 16 spreads the 32 entries of a step
+// over the group's 16 lanes (row_newbcast); LG = 8 / 4 give every QUAD of the
+// group its own copy, 8 entries per lane (quad_perm broadcast)
+__host__ __device__ constexpr int list_epl(int LG) { return LG == 16 ? 2 : 8; }
 // dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
 __host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int LG) {
   return ((N + 1) * LG + 3) / 4 * 4;
@@ -554,20 +558,18 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
 }
 
 // Entry J (0..31) of a gene's 32-entry index vector -> every lane of its group,
-// plus the lane's column offset.  The vector is held 32/LG entries per lane.
-// LG = 16: a DPP row IS a group, so  v_add_u32_dpp ... row_newbcast:lane  does
-// broadcast and add in one instruction.  LG = 8: a DPP row holds two groups;
-// each gets its own source lane through bank-masked broadcasts.
+// plus the lane's column offset, as ONE v_add_u32_dpp:
+//   LG = 16: a DPP row is a group; entries sit two per lane -> row_newbcast:J/2
+//   LG < 16: every quad of the group holds all 32 entries, eight per lane
+//            -> quad_perm:[s,s,s,s] with s = J/8
 template <int LG, int J>
-__device__ __forceinline__ uint32_t entry_addr(const uint32_t (&e)[32 / LG], uint32_t col4) {
-  constexpr int EPL = 32 / LG;
+__device__ __forceinline__ uint32_t entry_addr(const uint32_t (&e)[list_epl(LG)], uint32_t col4) {
+  constexpr int EPL = list_epl(LG);
   const int v = (int)e[J % EPL];
   if constexpr (LG == 16) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x150 + J / EPL, 0xf, 0xf, false) + col4;
   } else {
-    const int t1 = __builtin_amdgcn_update_dpp(0, v, 0x150 + J / EPL, 0xf, 0x3, false);
-    const int t2 = __builtin_amdgcn_update_dpp(t1, v, 0x150 + 8 + J / EPL, 0xf, 0xc, false);
-    return (uint32_t)t2 + col4;
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, v, (J / EPL) * 0x55, 0xf, 0xf, false) + col4;
   }
 }
 __device__ __forceinline__ uint32_t lds_at(const uint32_t* lds, uint32_t byte_off) {
@@ -577,7 +579,7 @@ __device__ __forceinline__ uint32_t lds_at(const uint32_t* lds, uint32_t byte_of
 // Issue the 8 LDS reads of entries 8J..8J+7 into x[8J..8J+7].
 template <int LG, int J>
 __device__ __forceinline__ void read8(uint32_t (&x)[32], const uint32_t* __restrict__ lds,
-                                      const uint32_t (&e)[32 / LG], uint32_t col4) {
+                                      const uint32_t (&e)[list_epl(LG)], uint32_t col4) {
   x[8 * J + 0] = lds_at(lds, entry_addr<LG, 8 * J + 0>(e, col4));
   x[8 * J + 1] = lds_at(lds, entry_addr<LG, 8 * J + 1>(e, col4));
   x[8 * J + 2] = lds_at(lds, entry_addr<LG, 8 * J + 2>(e, col4));
@@ -616,7 +618,8 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int lg = lane / LG, col = lane % LG;
   constexpr int GPW = kWave / LG;   // genes per wavefront
-  constexpr int EPL = 32 / LG;      // index entries per lane and step
+  constexpr int EPL = list_epl(LG); // index entries per lane and step
+  constexpr int LPS = 32 / EPL;     // lanes that together hold one step's 32 entries
 
   // tile -> LDS (contiguous copy, 16 B per lane)
   const int tile_dwords = (N + 1) * LG;
@@ -642,10 +645,11 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const bool have = q * GPW + lg < G;
     // every gene of a quad has the same (padded) number of 32-entry groups
     const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);
-    // 32 list entries (byte offsets of LDS rows) per step, 32/LG per lane of the
-    // group: one coalesced 8- or 16-byte load per lane, no redundancy
-    struct alignas(4 * EPL) Ent { uint32_t e[EPL]; };
-    const Ent* lp = reinterpret_cast<const Ent*>(lidx) + (int64_t)lstart[slot] * LG + col;
+    // 32 list entries (byte offsets of LDS rows) per step, EPL per lane: the
+    // group's 16 lanes (LG = 16) or each of its quads (LG < 16) hold all 32
+    struct alignas(EPL == 2 ? 8 : 16) Ent { uint32_t e[EPL]; };
+    const Ent* lp = reinterpret_cast<const Ent*>(lidx) + (int64_t)lstart[slot] * LPS +
+                    (LG == 16 ? col : (lane & 3));
     const uint32_t col4 = (uint32_t)col * 4u;
 
     uint32_t c[16];
@@ -669,24 +673,24 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     // Software pipeline: index vectors are fetched four steps ahead (2 VGPRs per
     // step), the 32 LDS row reads of step s+1 are in flight while step s is summed.
     const int last = max(nsuper - 1, 0);
-    Ent b0 = lp[0], b1 = lp[(int64_t)min(1, last) * LG], b2 = lp[(int64_t)min(2, last) * LG],
-        b3 = lp[(int64_t)min(3, last) * LG];
+    Ent b0 = lp[0], b1 = lp[(int64_t)min(1, last) * LPS], b2 = lp[(int64_t)min(2, last) * LPS],
+        b3 = lp[(int64_t)min(3, last) * LPS];
     uint32_t xa[32], xb[32];
     if (nsuper > 0) read32(xa, b0);
     for (int sg = 0; sg < nsuper; sg += 4) {
       // four steps (128 rows) per trip; their weight-32 carries are paired up
       // the tree before the (short) half-adder ripple
       uint32_t f1 = 0u, f2 = 0u, f3 = 0u;
-      b0 = lp[(int64_t)min(sg + 4, last) * LG];
+      b0 = lp[(int64_t)min(sg + 4, last) * LPS];
       if (sg + 1 < nsuper) read32(xb, b1);
       const uint32_t f0 = sum32(xa);
-      b1 = lp[(int64_t)min(sg + 5, last) * LG];
+      b1 = lp[(int64_t)min(sg + 5, last) * LPS];
       if (sg + 2 < nsuper) read32(xa, b2);
       if (sg + 1 < nsuper) f1 = sum32(xb);
-      b2 = lp[(int64_t)min(sg + 6, last) * LG];
+      b2 = lp[(int64_t)min(sg + 6, last) * LPS];
       if (sg + 3 < nsuper) read32(xb, b3);
       if (sg + 2 < nsuper) f2 = sum32(xa);
-      b3 = lp[(int64_t)min(sg + 7, last) * LG];
+      b3 = lp[(int64_t)min(sg + 7, last) * LPS];
       if (sg + 4 < nsuper) read32(xa, b0);
       if (sg + 3 < nsuper) f3 = sum32(xb);
       const uint32_t g0 = full_add(c[5], f0, f1);               // weight 64
@@ -1372,7 +1376,7 @@ int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
   return T * ntiles * list_tile_dwords(N, LG);
 }
 int64_t scoary_list_tile_words(int64_t N) { return list_lg(N) ? list_tile_dwords(N, list_lg(N)) : 0; }
-int64_t scoary_list_max_isolates(void) { return 5119; }
+int64_t scoary_list_max_isolates(void) { return 10239; }
 int scoary_list_params(int64_t N, int64_t* out4) {
   if (!out4) return SCOARY_ERR_ARG;
   const int LG = list_lg(N);
@@ -1404,7 +1408,7 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
   hipLaunchKernelGGL((k_perm_generate_tiles<LGV>), grid, dim3(kWave), 0, s, d_masks, d_margins, (int)N, \
                      (int)scoary_row_words(N), P, perm_base, (int)trait_base, (uint32_t)seed,        \
                      (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
-  if (LG == 16) GEN_TILES(16); else GEN_TILES(8);
+  if (LG == 16) GEN_TILES(16); else if (LG == 8) GEN_TILES(8); else GEN_TILES(4);
 #undef GEN_TILES
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
@@ -1475,7 +1479,10 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   if (LG == 16)
     return launch_permute_lists<16, 11, 13>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                             d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  return launch_permute_lists<8, 12, 14>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+  if (LG == 8)
+    return launch_permute_lists<8, 12, 14>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                           d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  return launch_permute_lists<4, 13, 15>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                          d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
 }
 

@@ -314,6 +314,7 @@ def test_headline_config_properties(eng, orc):
     (400, 700, 2, 65), (260, 1500, 1, 700), (500, 2000, 3, 1030), (90, 2400, 2, 520),
     (64, 2559, 1, 513), (70, 2560, 1, 300), (130, 3000, 2, 260), (200, 4000, 1, 530),
     (90, 5000, 2, 257), (40, 5119, 1, 100),          # 8 lanes per gene, tiles of 256
+    (50, 5120, 1, 129), (120, 7000, 2, 200), (70, 10000, 1, 130), (33, 10239, 1, 64),   # 4 lanes
 ])
 def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     """The list-driven kernel (minority lists + bit-sliced counters) gives
@@ -340,7 +341,7 @@ def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     assert np.array_equal(lists.view(np.uint32), want)
 
 
-@pytest.mark.parametrize("N", [333, 2700])
+@pytest.mark.parametrize("N", [333, 2700, 6000])
 def test_perm_tiles_are_the_transposed_row_labels(eng, N):
     """k_perm_generate_tiles writes the same spec-S4 labels as k_perm_generate,
     isolate-major in tiles of 512 permutations, zero row + zero ragged tail."""
@@ -382,9 +383,14 @@ def test_capacity_config_shard_vs_oracle_subsample(eng, orc):
     genes = synth.make_genes(G, N, rng, core_frac=0.05)
     traits = synth.make_traits(T, N, rng, missing_traits=(8, 9, 33))
     tb, mb = _bits(eng, traits)
-    assert not eng.lists_supported(N)
-    res = eng.associate(eng.pack_dense(genes), eng.vecrows(tb, N), eng.vecrows(mb, N),
-                        permutations=P, seed=11)
+    from scoary_amd.engine import pack_bits_rows
+    gm = eng.pack_dense(genes)
+    res = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=11,
+                        use_lists=False)                    # chunked dense kernel
+    eng.build_lists(gm, pack_bits_rows(genes))
+    res_l = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=11,
+                          use_lists=True)                   # 4-lane list kernel
+    assert np.array_equal(res_l["r"].cpu().numpy(), res["r"].cpu().numpy())
     counts = res["counts"].cpu().numpy()
     r = res["r"].cpu().numpy().view(np.uint32)
     p = res["p"].cpu().numpy()
@@ -413,7 +419,7 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_fisher(h, p, 0, p, p, null, null) == -1
     assert lib.scoary_permute(h, p, p, p, 1, 70000, 10, 10, p, null) == -3          # T > 65535
     assert lib.scoary_perm_generate(h, p, p, 1, 10, 2**33, 0, 0, 1, p, null) == -3   # index >= 2^32
-    assert lib.scoary_permute_lists(h, p, p, p, p, p, p, p, p, p, 4, 1, 6000, 10, p, null) == -3
+    assert lib.scoary_permute_lists(h, p, p, p, p, p, p, p, p, p, 4, 1, 10240, 10, p, null) == -3
     assert b"LDS" in lib.scoary_last_error(h)
     assert lib.scoary_tree_pairs(h, p, 3, 40, p, p, 1, 1, 2, p, null) == -3          # stack_depth > 32
     assert lib.scoary_counts(null, p, p, p, 1, 1, 1, p, p, null) == -1
@@ -422,4 +428,5 @@ def test_c_abi_error_codes(eng):
     params = (ctypes.c_int64 * 4)()
     assert lib.scoary_list_params(2000, params) == 0 and list(params) == [16, 64, 4, 2]
     assert lib.scoary_list_params(5000, params) == 0 and list(params) == [8, 32, 8, 4]
-    assert lib.scoary_list_params(5120, params) == -3 and params[0] == 0
+    assert lib.scoary_list_params(5120, params) == 0 and list(params) == [4, 16, 16, 8]
+    assert lib.scoary_list_params(10240, params) == -3 and params[0] == 0

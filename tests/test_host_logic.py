@@ -330,7 +330,7 @@ def test_io_library_exports_every_declared_symbol():
 
 
 # ------------------------------------------------- minority index lists ------
-@pytest.mark.parametrize("gpw,classes,stride", [(4, 2, 64), (8, 4, 32)])
+@pytest.mark.parametrize("gpw,classes,stride", [(4, 2, 64), (8, 4, 32), (16, 8, 16)])
 def test_minority_lists_builder(gpw, classes, stride):
     """scoary_lists_build (host native): per gene the positions of its minority
     value, padded with N to a multiple of 32 and to the quad's longest list,
