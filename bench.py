@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4"])
     ap.add_argument("--genes", type=int, default=None, help="override G (per GPU)")
     ap.add_argument("--permutations", type=int, default=None, help="override P")
+    ap.add_argument("--isolates", type=int, default=None, help="override N (shape experiments)")
+    ap.add_argument("--traits", type=int, default=None, help="override T (shape experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", default="auto", choices=["auto", "dense", "lists"],
                     help="permutation kernel: dense (k_permute_reg/chunked) or list-driven")
@@ -125,7 +127,8 @@ def main():
     from scoary_amd.engine import AssociationEngine, pack_bits_rows
 
     # every rank: its own gene shard (different seed offset), same traits
-    genes, traits, P, seed = synth.make_config(args.config, G=args.genes)
+    genes, traits, P, seed = synth.make_config(args.config, G=args.genes, N=args.isolates,
+                                               T=args.traits)
     if rank > 0:
         rng = np.random.default_rng(seed + 1000 * rank)
         genes = synth.make_genes(genes.shape[0], genes.shape[1], rng,
@@ -226,7 +229,8 @@ def main():
         alg_bytes = 16.0 * W64 * tests_per_launch        # 16*W bytes / test
         achieved = alg_bytes / (k3_ms * 1e-3) / 1e9
         traffic, traffic_src = load_traffic(
-            args.config, args.genes is None and args.permutations is None, k3_name)
+            args.config, args.genes is None and args.permutations is None
+            and args.isolates is None and args.traits is None, k3_name)
         w32 = -(-N // 32)
         valu_ops = tests_per_launch * (2.0 * w32 + 6)     # dense-kernel op model (reference point)
         out = {
