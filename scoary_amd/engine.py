@@ -75,6 +75,11 @@ class AssociationEngine:
             pass
 
     # -- plumbing -----------------------------------------------------------
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = _torch().cuda.Stream(device=self.device)
+        return self._side
+
     def _stream(self):
         return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
@@ -244,27 +249,41 @@ class AssociationEngine:
         Returns dict of device tensors: counts [T,G,4], margins [T,2],
         p / odds [T,G], r [T,G] (uint32 bit pattern in int32) or None."""
         torch = _torch()
-        counts, margins = self.counts(genes, traits, masks)
-        p, odds, crit = self.fisher(counts, want_crit=permutations > 0)
-        r = None
         if use_lists is None:
             use_lists = genes.lists is not None and self.lists_supported(genes.N)
+        counts, margins = self.counts(genes, traits, masks)
+        r = None
         if permutations > 0 and use_lists:
             T = traits.shape[0]
-            r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
             per = int(self.lib.scoary_list_tiles_words(genes.N, 512, T)) * 4   # bytes / 512 perms
             per = max(per, 1)
             batch = int(max(512, min(-(-permutations // 512) * 512, ((8 << 30) // per) * 512)))
+            # The first batch of label tiles needs only the trait margins, not the
+            # Fisher pass: generate it on a side stream while k_fisher runs.
+            main = torch.cuda.current_stream(self.device)
+            side = self._side_stream()
+            side.wait_stream(main)
+            nb0 = min(batch, permutations)
+            need = int(self.lib.scoary_list_tiles_words(genes.N, nb0, T))
+            buf = tiles_buffer[:need] if (tiles_buffer is not None and
+                                          tiles_buffer.numel() >= need) else None
+            with torch.cuda.stream(side):
+                tiles = self.perm_generate_tiles(masks, margins, genes.N, nb0, 0, seed, out=buf)
+            tiles.record_stream(main)
+            p, odds, crit = self.fisher(counts, want_crit=True)
+            r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
+            main.wait_stream(side)
             done = 0
             while done < permutations:
                 nb = min(batch, permutations - done)
-                need = int(self.lib.scoary_list_tiles_words(genes.N, nb, T))
-                buf = tiles_buffer[:need] if (tiles_buffer is not None and
-                                              tiles_buffer.numel() >= need) else None
-                tiles = self.perm_generate_tiles(masks, margins, genes.N, nb, done, seed, out=buf)
+                if done > 0:
+                    tiles = self.perm_generate_tiles(masks, margins, genes.N, nb, done, seed)
                 self.permute_lists(genes, tiles, crit, margins, nb, r)
                 done += nb
-        elif permutations > 0:
+            return {"counts": counts, "margins": margins, "p": p, "odds": odds, "crit": crit,
+                    "r": r}
+        p, odds, crit = self.fisher(counts, want_crit=permutations > 0)
+        if permutations > 0:
             T = traits.shape[0]
             r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
             if perm_buffer is not None:

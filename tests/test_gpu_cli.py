@@ -253,3 +253,18 @@ def test_collapse_device_hash_equals_exact_grouping(monkeypatch):
         assert list(res2["Results"][tr]) == list(res["Results"][tr])
         assert np.array_equal(res2["Results"][tr].column("BH_p"), res["Results"][tr].column("BH_p"))
         assert res2["Results"][tr].number_of_tests == res["Results"][tr].number_of_tests
+
+
+def test_cli_custom_newick_tree_equals_upgma_run(exampledir, tmp_path):
+    """-n <tree> (the reference's Travis "Test4" flag): feeding the shipped
+    ExampleTree.nwk -- which IS the UPGMA tree of exampledata -- must reproduce
+    the default-mode files."""
+    a = tmp_path / "a"
+    b = tmp_path / "b"
+    fa = run_cli(_inputs(exampledir), a)
+    fb = run_cli(_inputs(exampledir) + ["-n", os.path.join(exampledir, "ExampleTree.nwk")], b)
+    assert fa.keys() == fb.keys() and len(fa) == 2
+    for k in fa:
+        assert fa[k] == fb[k]
+    top = list(csv.reader(io.StringIO(fb["Tetracycline_resistance.results.csv"])))[1]
+    assert top[0] == "TetRCG" and [int(x) for x in top[13:16]] == [25, 25, 1]
