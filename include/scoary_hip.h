@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SCOARY_ABI_VERSION 2
+#define SCOARY_ABI_VERSION 3
 
 /* error codes */
 #define SCOARY_OK 0
@@ -144,10 +144,11 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T);
 int64_t scoary_list_tile_words(int64_t N);   /* dwords per (trait, tile) */
 int64_t scoary_list_max_isolates(void);
-/* out4 = { lanes per gene (16 for N <= 2559, 8 for N <= 5119, 4 for N <= 10239), row stride in
- * bytes, genes per wavefront, residue classes } -- the last three are the
- * arguments scoary_lists_build wants.  Error if N is too large. */
-int scoary_list_params(int64_t N, int64_t *out4);
+/* out5 = { tile row width in dwords of 32 permutations (16 for N <= 2559, 8 for N <= 5119,
+ * 4 for N <= 10239), row stride in bytes, genes per wavefront, residue classes,
+ * interleave piece } -- the last four are the arguments scoary_lists_build
+ * wants.  Error if N is too large. */
+int scoary_list_params(int64_t N, int64_t *out5);
 int scoary_perm_generate_tiles(scoary_handle h, const uint32_t *d_masks,
                                const int32_t *d_margins, int64_t T, int64_t N, int64_t P,
                                int64_t perm_base, int64_t trait_base, uint64_t seed,

@@ -56,7 +56,13 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
  * similar lengths and, after padding, the same number of 32-entry groups.
  * Within a list the positions are grouped by (position mod classes), slot k
  * starting with class k mod classes (LDS bank trick, see the kernel).
- * row_stride / genes_per_wave / classes come from scoary_list_params(N).
+ * With piece > 0 the lists of one wavefront group are interleaved in pieces of
+ * `piece` entries -- entry e of the group's j-th gene sits at
+ * group_base + ((e / piece) * genes_per_wave + j) * piece + e % piece -- so that
+ * the wavefront's index loads are contiguous; start[] is then the group base
+ * for every slot of the group and the last group is stored in full (missing
+ * genes all padding).  piece = 0: every list contiguous, back to back.
+ * row_stride / genes_per_wave / classes / piece come from scoary_list_params(N).
  *   first call  : scoary_lists_count -> total number of entries
  *   second call : scoary_lists_build fills
  *       idx     uint32 [total]   entry = position * row_stride (the LDS byte offset of
@@ -65,10 +71,11 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
  *       ngroups int32  [G]       groups of 32 of gene order[k] (equal within a wave group)
  *       order   int32  [G]       gene id of slot k
  *       flipped uint8  [G]       per gene id */
-int64_t scoary_lists_count(const uint64_t *rows64, int64_t G, int64_t N, int64_t genes_per_wave);
+int64_t scoary_lists_count(const uint64_t *rows64, int64_t G, int64_t N, int64_t genes_per_wave,
+                           int64_t piece);
 void scoary_lists_build(const uint64_t *rows64, int64_t G, int64_t N, int64_t row_stride,
-                        int64_t genes_per_wave, int64_t classes, uint32_t *idx, int32_t *start,
-                        int32_t *ngroups, int32_t *order, uint8_t *flipped);
+                        int64_t genes_per_wave, int64_t classes, int64_t piece, uint32_t *idx,
+                        int32_t *start, int32_t *ngroups, int32_t *order, uint8_t *flipped);
 
 #ifdef __cplusplus
 }

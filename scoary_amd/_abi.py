@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libscoary_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "scoary_hip.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _i64, _u64, _i32, _vp, _cp = (ctypes.c_int64, ctypes.c_uint64, ctypes.c_int,
                               ctypes.c_void_p, ctypes.c_char_p)

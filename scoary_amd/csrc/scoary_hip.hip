@@ -461,6 +461,34 @@ __device__ __forceinline__ uint32_t bit_maj(uint32_t a, uint32_t b, uint32_t c) 
   asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe8" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+// majority(~a, b, c): the borrow of a - b - c
+__device__ __forceinline__ uint32_t bit_majn(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x8e" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// Bit-sliced rejection-region test (spec S5) on KC counter planes: bit j of the
+// result = ((count_j - base) mod 2^KD) < span.  Three LUT ops per plane.
+template <int KC, int KD>
+__device__ __forceinline__ uint32_t region_lt(const uint32_t (&c)[16], uint32_t base,
+                                              uint32_t span) {
+  uint32_t borrow = 0u, lt = 0u;   // d = u - base ; lt = (d < span)
+#pragma unroll
+  for (int k = 0; k < KD; ++k) {
+    const uint32_t bk = (uint32_t)__builtin_amdgcn_sbfe((int)base, k, 1);   // 0 / ~0
+    const uint32_t sk = (uint32_t)__builtin_amdgcn_sbfe((int)span, k, 1);
+    uint32_t dk;
+    if (k < KC) {
+      dk = bit_xor3(c[k], bk, borrow);
+      borrow = bit_majn(c[k], bk, borrow);
+    } else {
+      dk = bk ^ borrow;
+      borrow |= bk;
+    }
+    lt = bit_majn(dk, sk, lt);
+  }
+  return lt;
+}
 // c += x + y at bit-plane weight 1: returns the carry (weight 2)
 __device__ __forceinline__ uint32_t full_add(uint32_t& c, uint32_t x, uint32_t y) {
   const uint32_t carry = bit_maj(c, x, y);
@@ -708,21 +736,198 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
     const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
     const uint32_t always = (cr.y >> 31) ? 0xffffffffu : 0u;
-    uint32_t borrow = 0u, lt = 0u;   // d = u - base ; lt = (d < span)
-#pragma unroll
-    for (int k = 0; k < KD; ++k) {
-      const uint32_t ck = k < KC ? c[k] : 0u;
-      const uint32_t bk = (uint32_t)__builtin_amdgcn_sbfe((int)base, k, 1);   // 0 / ~0
-      const uint32_t sk = (uint32_t)__builtin_amdgcn_sbfe((int)span, k, 1);
-      const uint32_t dk = ck ^ bk ^ borrow;
-      borrow = (~ck & (bk | borrow)) | (bk & borrow);
-      lt = (~dk & (sk | lt)) | (sk & lt);
-    }
+    const uint32_t lt = region_lt<KC, KD>(c, base, span);
     uint32_t ex = ((~lt) ^ inv) | always;
     ex &= valid;
     int cnt = have ? __popc(ex) : 0;
 #pragma unroll
     for (int off = LG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (have && col == 0 && cnt) atomicAdd(&r[(int64_t)t * G + lorder[slot]], (uint32_t)cnt);
+  }
+}
+
+
+
+// 128 permutations per lane: 4 lanes per gene read the 16-dword tile rows with
+// ds_read_b128, 16 genes per wavefront.  One address add serves four words
+// (~2.2 VALU ops per listed isolate and 32 permutations).  ds_read_b128 is served
+// in the lane groups {0-3,12-15,20-27} ...: with slot k starting at residue
+// class k mod 4 (scoary_lists_build) each group's four genes sit on distinct
+// 64-byte bank slots.
+__device__ __forceinline__ uint4 lds128_at(const uint32_t* lds, uint32_t byte_off) {
+  return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds) + byte_off);
+}
+struct Rows4 { uint32_t w0[4], w1[4], w2[4], w3[4]; };   // 4 tile rows x 4 permutation words
+// The 4 entries held by lane H of every LPG-lane gene group -> 4 ds_read_b128.
+template <int LPG, int H>
+__device__ __forceinline__ void read4x4(Rows4& x, const uint32_t* __restrict__ lds,
+                                        const uint32_t (&e)[4], uint32_t colb) {
+  // quad_perm broadcast of lane H of the group: [H,H,H,H] or [H,H,2+H,2+H]
+  constexpr int kCtrl = LPG == 4 ? H * 0x55 : 0xA0 + H * 0x55;
+#define RD(J)                                                                                      \
+  {                                                                                                \
+    uint32_t a;                                                                                    \
+    if constexpr (LPG == 1)                                                                        \
+      a = e[J];                                                                                    \
+    else                                                                                           \
+      a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e[J], kCtrl, 0xf, 0xf, false) + colb;      \
+    const uint4 v = lds128_at(lds, a);                                                             \
+    x.w0[J] = v.x;                                                                                 \
+    x.w1[J] = v.y;                                                                                 \
+    x.w2[J] = v.z;                                                                                 \
+    x.w3[J] = v.w;                                                                                 \
+  }
+  RD(0) RD(1) RD(2) RD(3)
+#undef RD
+}
+// 4 row words -> counter planes 0..1, returns the carry of weight 4
+__device__ __forceinline__ uint32_t sum4(uint32_t (&c)[16], const uint32_t (&x)[4]) {
+  const uint32_t a1 = full_add(c[0], x[0], x[1]);
+  const uint32_t a2 = full_add(c[0], x[2], x[3]);
+  return full_add(c[1], a1, a2);
+}
+struct Carry4 { uint32_t w[4]; };
+
+// LPG lanes per gene (4, 2, 1 for 16-, 8-, 4-dword tile rows), 64/LPG genes per
+// wavefront.  Lists are walked in sub-steps of 4 entries: lane j of a gene group
+// holds entries 4j..4j+3 of each 4*LPG-entry piece.
+template <int LPG, int KC, int KD>
+__global__ __launch_bounds__(1024) void k_permute_lists128(const uint32_t* __restrict__ tiles,
+                                                           const uint32_t* __restrict__ lidx,
+                                                           const int32_t* __restrict__ lstart,
+                                                           const int32_t* __restrict__ lngroups,
+                                                           const int32_t* __restrict__ lorder,
+                                                           const uint2* __restrict__ lcrit, int G,
+                                                           int N, int64_t P, int ntiles,
+                                                           int quads_per_block,
+                                                           uint32_t* __restrict__ r) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
+  constexpr int TW = 4 * LPG;        // tile row, dwords
+  constexpr int GPW = kWave / LPG;   // genes per wavefront
+  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int lg = lane / LPG, col = lane % LPG;
+
+  const int tile_dwords = (N + 1) * TW;
+  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW);
+  {
+    const uint4* src4 = reinterpret_cast<const uint4*>(src);
+    uint4* dst4 = reinterpret_cast<uint4*>(tile_lds);
+    const int n4 = tile_dwords / 4;
+    for (int i = tid; i < n4; i += blockDim.x) dst4[i] = src4[i];
+  }
+  __syncthreads();
+
+  uint32_t valid[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int64_t p_first = ((int64_t)tile * TW + 4 * col + w) * 32;
+    valid[w] = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
+  }
+
+  const int nquads = (G + GPW - 1) / GPW;
+  const int q_lo = blockIdx.y * quads_per_block;
+  const int q_hi = min(nquads, q_lo + quads_per_block);
+  for (int q = q_lo + wave; q < q_hi; q += nwaves) {
+    const int slot = min(q * GPW + lg, G - 1);
+    const bool have = q * GPW + lg < G;
+    const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);   // 32-entry steps
+    // interleaved lists (piece = TW entries): the wavefront's 64 lanes read 64
+    // consecutive 16-byte index vectors per piece
+    struct alignas(16) Ent { uint32_t e[4]; };
+    const Ent* lp = reinterpret_cast<const Ent*>(lidx) +
+                    (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 8 + lane;
+    const uint32_t colb = (uint32_t)col * 16u;
+
+    uint32_t c0[16], c1[16], c2[16], c3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c0[k] = c1[k] = c2[k] = c3[k] = 0u;
+    Rows4 xa, xb;
+    auto s4 = [&](const Rows4& x) -> Carry4 {
+      Carry4 b;
+      b.w[0] = sum4(c0, x.w0);
+      b.w[1] = sum4(c1, x.w1);
+      b.w[2] = sum4(c2, x.w2);
+      b.w[3] = sum4(c3, x.w3);
+      return b;
+    };
+    auto fa = [&](int plane, const Carry4& a, const Carry4& b) -> Carry4 {
+      Carry4 o;
+      o.w[0] = full_add(c0[plane], a.w[0], b.w[0]);
+      o.w[1] = full_add(c1[plane], a.w[1], b.w[1]);
+      o.w[2] = full_add(c2[plane], a.w[2], b.w[2]);
+      o.w[3] = full_add(c3[plane], a.w[3], b.w[3]);
+      return o;
+    };
+    // pieces of 4*LPG entries; the index loads run three pieces ahead.  Reads past
+    // the end of the list re-read its last piece (valid rows, never summed).
+    const int last = max(nsuper * (8 / LPG) - 1, 0);
+    int piece = 0;
+    Ent cur = lp[0], nxt = lp[(int64_t)min(1, last) * kWave], nn = lp[(int64_t)min(2, last) * kWave];
+    read4x4<LPG, 0>(xa, tile_lds, cur.e, colb);
+    // sub-step S of a step: issue the reads of sub-step S+1 into `other`, sum `mine`
+#define SUBSTEP(S, MINE, OTHER)                                        \
+  [&]() -> Carry4 {                                                    \
+    constexpr int Hn = ((S) + 1) % LPG;                                \
+    if constexpr (Hn == 0) {                                           \
+      cur = nxt;                                                       \
+      nxt = nn;                                                        \
+      ++piece;                                                         \
+      nn = lp[(int64_t)min(piece + 2, last) * kWave];                  \
+    }                                                                  \
+    read4x4<LPG, Hn>(OTHER, tile_lds, cur.e, colb);                    \
+    return s4(MINE);                                                   \
+  }()
+    for (int sg = 0; sg < nsuper; sg += 4) {
+      const Carry4 zero = {{0u, 0u, 0u, 0u}};
+      auto step = [&](int k) -> Carry4 {                    // 32 listed isolates
+        if (sg + k >= nsuper) return zero;
+        const Carry4 b0 = SUBSTEP(0, xa, xb);
+        const Carry4 b1 = SUBSTEP(1, xb, xa);
+        const Carry4 d0 = fa(2, b0, b1);
+        const Carry4 b2 = SUBSTEP(2, xa, xb);
+        const Carry4 b3 = SUBSTEP(3, xb, xa);
+        const Carry4 d1 = fa(2, b2, b3);
+        const Carry4 e0 = fa(3, d0, d1);
+        const Carry4 b4 = SUBSTEP(4, xa, xb);
+        const Carry4 b5 = SUBSTEP(5, xb, xa);
+        const Carry4 d2 = fa(2, b4, b5);
+        const Carry4 b6 = SUBSTEP(6, xa, xb);
+        const Carry4 b7 = SUBSTEP(7, xb, xa);
+        const Carry4 d3 = fa(2, b6, b7);
+        const Carry4 e1 = fa(3, d2, d3);
+        return fa(4, e0, e1);                               // weight 32
+      };
+      const Carry4 f0 = step(0), f1 = step(1);
+      const Carry4 g0 = fa(5, f0, f1);
+      const Carry4 f2 = step(2), f3 = step(3);
+      const Carry4 g1 = fa(5, f2, f3);
+      Carry4 carry = fa(6, g0, g1);
+#pragma unroll
+      for (int k = 7; k < KC; ++k) {
+#define RIPPLE(C, W)                         \
+  {                                          \
+    const uint32_t nc = C[k] & carry.w[W];   \
+    C[k] ^= carry.w[W];                      \
+    carry.w[W] = nc;                         \
+  }
+        RIPPLE(c0, 0) RIPPLE(c1, 1) RIPPLE(c2, 2) RIPPLE(c3, 3)
+#undef RIPPLE
+      }
+    }
+#undef SUBSTEP
+    const uint2 cr = lcrit[(int64_t)t * G + slot];
+    const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
+    const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
+    const uint32_t always = (cr.y >> 31) ? 0xffffffffu : 0u;
+    int cnt = 0;
+    cnt += __popc((((~region_lt<KC, KD>(c0, base, span)) ^ inv) | always) & valid[0]);
+    cnt += __popc((((~region_lt<KC, KD>(c1, base, span)) ^ inv) | always) & valid[1]);
+    cnt += __popc((((~region_lt<KC, KD>(c2, base, span)) ^ inv) | always) & valid[2]);
+    cnt += __popc((((~region_lt<KC, KD>(c3, base, span)) ^ inv) | always) & valid[3]);
+    if (!have) cnt = 0;
+#pragma unroll
+    for (int off = LPG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
     if (have && col == 0 && cnt) atomicAdd(&r[(int64_t)t * G + lorder[slot]], (uint32_t)cnt);
   }
 }
@@ -1377,13 +1582,23 @@ int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
 }
 int64_t scoary_list_tile_words(int64_t N) { return list_lg(N) ? list_tile_dwords(N, list_lg(N)) : 0; }
 int64_t scoary_list_max_isolates(void) { return 10239; }
-int scoary_list_params(int64_t N, int64_t* out4) {
-  if (!out4) return SCOARY_ERR_ARG;
+// Words (32 permutations each) per lane: 4 = k_permute_lists128 (the default), 1 =
+// k_permute_lists, the ds_read_b32 kernel it replaced, kept for A/B measurements
+// and selected with SCOARY_LISTS_WPL=1 in the environment.
+static int lists_wpl(int64_t) {
+  const char* e = std::getenv("SCOARY_LISTS_WPL");
+  return e && e[0] == '1' && !e[1] ? 1 : 4;
+}
+int scoary_list_params(int64_t N, int64_t* out5) {
+  if (!out5) return SCOARY_ERR_ARG;
   const int LG = list_lg(N);
-  out4[0] = LG;                       /* lanes per gene (0: N too large for the list kernel) */
-  out4[1] = LG * 4;                   /* LDS / tile row stride in bytes */
-  out4[2] = LG ? kWave / LG : 0;      /* genes per wavefront: lists padded to equal length */
-  out4[3] = LG ? 32 / LG : 0;         /* residue classes of the isolate index (bank trick) */
+  const int wpl = lists_wpl(N);
+  out5[0] = LG;                            /* tile row width in dwords (0: N too large for LDS tiles) */
+  out5[1] = LG * 4;                        /* LDS / tile row stride in bytes */
+  out5[2] = LG ? kWave / LG * wpl : 0;     /* genes per wavefront: lists padded to equal length */
+  out5[3] = LG ? (wpl == 4 ? 64 : 32) / LG : 0;   /* residue classes of the isolate index:
+                                              ds_read_b128 is banked over 256 B, ds_read_b32 over 128 B */
+  out5[4] = LG && wpl == 4 ? LG : 0;       /* interleave piece, entries (0: contiguous lists) */
   return LG ? SCOARY_OK : SCOARY_ERR_SIZE;
 }
 
@@ -1415,7 +1630,7 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
 }
 
 extern "C++" {
-template <int LG, int KC, int KD>
+template <int LG, int KC, int KD, int WPL = 1>
 static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* d_tiles,
                                 const uint32_t* d_lidx, const int32_t* d_lstart,
                                 const int32_t* d_lngroups, const int32_t* d_lorder,
@@ -1430,7 +1645,7 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   }
   const int64_t tile_perms = LG * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  constexpr int GPW = kWave / LG;
+  constexpr int GPW = kWave / LG * WPL;
   const int64_t nquads = (G + GPW - 1) / GPW;
   // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index
   // lists (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the
@@ -1444,16 +1659,25 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   qpb = (qpb + 15) / 16 * 16;
   chunks = (nquads + qpb - 1) / qpb;
   const size_t lds = (size_t)(N + 1) * LG * sizeof(uint32_t);
-  if (!(h->lists_lds_optin & LG)) {   // once per handle (= per device) and kernel variant
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_permute_lists<LG, KC, KD>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    h->lists_lds_optin |= LG;
+  constexpr int kFlag = WPL == 4 ? 64 * LG : LG;
+  const void* fn;
+  if constexpr (WPL == 4) fn = reinterpret_cast<const void*>(&k_permute_lists128<LG / 4, KC, KD>);
+  else fn = reinterpret_cast<const void*>(&k_permute_lists<LG, KC, KD>);
+  if (!(h->lists_lds_optin & kFlag)) {   // once per handle (= per device) and kernel variant
+    HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    h->lists_lds_optin |= kFlag;
   }
   KernelTimer kt(h, s, "k_permute_lists");
-  hipLaunchKernelGGL((k_permute_lists<LG, KC, KD>), dim3((unsigned)(ntiles * T), (unsigned)chunks),
-                     dim3(1024), lds, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                     reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P, (int)ntiles, (int)qpb,
-                     d_r);
+  const dim3 grid((unsigned)(ntiles * T), (unsigned)chunks);
+  const uint2* lcrit2 = reinterpret_cast<const uint2*>(d_lcrit);
+  if constexpr (WPL == 4)
+    hipLaunchKernelGGL((k_permute_lists128<LG / 4, KC, KD>), grid, dim3(1024), lds, s, d_tiles, d_lidx,
+                       d_lstart, d_lngroups, d_lorder, lcrit2, (int)G, (int)N, P, (int)ntiles,
+                       (int)qpb, d_r);
+  else
+    hipLaunchKernelGGL((k_permute_lists<LG, KC, KD>), grid, dim3(1024), lds, s, d_tiles, d_lidx,
+                       d_lstart, d_lngroups, d_lorder, lcrit2, (int)G, (int)N, P, (int)ntiles,
+                       (int)qpb, d_r);
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }
@@ -1476,9 +1700,19 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   // counter planes KC: lists hold <= N/2 entries; compare planes KD: 2N+3 <= 2^KD
+  const int wpl = lists_wpl(N);
+  if (LG == 16 && wpl == 4)
+    return launch_permute_lists<16, 11, 13, 4>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                               d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
   if (LG == 16)
     return launch_permute_lists<16, 11, 13>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                             d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  if (LG == 8 && wpl == 4)
+    return launch_permute_lists<8, 12, 14, 4>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                              d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  if (LG == 4 && wpl == 4)
+    return launch_permute_lists<4, 13, 15, 4>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                              d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
   if (LG == 8)
     return launch_permute_lists<8, 12, 14>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                            d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);

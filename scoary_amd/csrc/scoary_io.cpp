@@ -303,17 +303,20 @@ static void list_plan(const uint64_t* rows64, int64_t G, int64_t N, int64_t gpw,
   }
 }
 
-int64_t scoary_lists_count(const uint64_t* rows64, int64_t G, int64_t N, int64_t genes_per_wave) {
+int64_t scoary_lists_count(const uint64_t* rows64, int64_t G, int64_t N, int64_t genes_per_wave,
+                           int64_t piece) {
   std::vector<int32_t> len, order, padded;
   list_plan(rows64, G, N, genes_per_wave, len, order, padded, nullptr);
   int64_t total = 0;
   for (int64_t k = 0; k < G; ++k) total += padded[k];
+  // interleaved layout: the last wave group is stored as a full group
+  if (piece > 0 && G % genes_per_wave) total += (genes_per_wave - G % genes_per_wave) * padded[G - 1];
   return total;
 }
 
 void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t row_stride,
-                        int64_t genes_per_wave, int64_t classes, uint32_t* idx, int32_t* start,
-                        int32_t* ngroups, int32_t* order_out, uint8_t* flipped) {
+                        int64_t genes_per_wave, int64_t classes, int64_t piece, uint32_t* idx,
+                        int32_t* start, int32_t* ngroups, int32_t* order_out, uint8_t* flipped) {
   const int64_t W = (N + 63) / 64;
   std::vector<int32_t> len, order, padded;
   list_plan(rows64, G, N, genes_per_wave, len, order, padded, flipped);
@@ -321,18 +324,19 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
   // of two <= 64, so the pattern is the same in every 64-bit word)
   std::vector<uint64_t> cmask(classes, 0);
   for (int b = 0; b < 64; ++b) cmask[b % classes] |= (uint64_t)1 << b;
-  int64_t pos = 0;
+  int64_t pos = 0;          // piece == 0: next free entry; piece > 0: base of the wave group
+  std::vector<uint32_t> one;
   for (int64_t k = 0; k < G; ++k) {
     const int64_t g = order[k];
     order_out[k] = (int32_t)g;
     const uint64_t* r = rows64 + g * W;
     const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
-    start[k] = (int32_t)(pos / kListPad);
     ngroups[k] = (int32_t)(padded[k] / kListPad);
     // The `classes` lane groups of a 32-lane half read the LDS label tile in
     // lockstep, and a row's bank range is fixed by (isolate index mod classes).
     // Slot k starts with the rows of class (k mod classes) and rotates through
     // the classes, so the groups of a half hit disjoint banks.
+    one.assign(padded[k], (uint32_t)(N * row_stride));          // padding -> the zero row
     int64_t n = 0;
     for (int64_t pass = 0; pass < classes; ++pass) {
       const uint64_t sel = cmask[(k + pass) % classes];
@@ -342,12 +346,26 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
         while (bits) {
           const int b = __builtin_ctzll(bits);
           bits &= bits - 1;
-          idx[pos + n++] = (uint32_t)((w * 64 + b) * row_stride);
+          one[n++] = (uint32_t)((w * 64 + b) * row_stride);
         }
       }
     }
-    while (n < padded[k]) idx[pos + n++] = (uint32_t)(N * row_stride);
-    pos += n;
+    if (piece <= 0) {                     // gene-contiguous
+      start[k] = (int32_t)(pos / kListPad);
+      std::memcpy(idx + pos, one.data(), one.size() * sizeof(uint32_t));
+      pos += padded[k];
+    } else {                              // pieces of the group's genes interleaved
+      const int64_t j = k % genes_per_wave, L = padded[k];
+      start[k] = (int32_t)(pos / kListPad);
+      for (int64_t e = 0; e < L; ++e)
+        idx[pos + ((e / piece) * genes_per_wave + j) * piece + e % piece] = one[e];
+      if (k == G - 1)                     // missing genes of the last group: all padding
+        for (int64_t jj = j + 1; jj < genes_per_wave; ++jj)
+          for (int64_t e = 0; e < L; ++e)
+            idx[pos + ((e / piece) * genes_per_wave + jj) * piece + e % piece] =
+                (uint32_t)(N * row_stride);
+      if (j == genes_per_wave - 1) pos += genes_per_wave * L;
+    }
   }
 }
 

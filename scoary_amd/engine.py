@@ -146,18 +146,19 @@ class AssociationEngine:
         the same genes as ``genes``) for the list-driven permutation kernel."""
         torch = _torch()
         from . import io_native
-        lanes, stride, gpw, classes = self.list_params(genes.N)
+        lanes, stride, gpw, classes, piece = self.list_params(genes.N)
         if not lanes:
             raise ValueError("N=%d is too large for the list-driven kernel" % genes.N)
-        d = io_native.build_lists(rows64, genes.N, stride, gpw, classes)
+        d = io_native.build_lists(rows64, genes.N, stride, gpw, classes, piece)
         dev = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(self.device)  # noqa: E731
         genes.lists = GeneLists(dev(d["idx"]), dev(d["start"]), dev(d["ngroups"]),
                                 dev(d["order"]), dev(d["flipped"]), d["entries"])
         return genes.lists
 
     def list_params(self, N):
-        """(lanes per gene, row stride bytes, genes per wavefront, classes)."""
-        out = (ctypes.c_int64 * 4)()
+        """(tile row dwords, row stride bytes, genes per wavefront, classes,
+        interleave piece) -- scoary_list_params."""
+        out = (ctypes.c_int64 * 5)()
         self.lib.scoary_list_params(int(N), out)
         return tuple(int(x) for x in out)
 

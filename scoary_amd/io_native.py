@@ -41,26 +41,27 @@ def _load():
     return _lib
 
 
-def build_lists(rows64, N, row_stride, genes_per_wave, classes):
+def build_lists(rows64, N, row_stride, genes_per_wave, classes, piece=0):
     """Minority index lists of every gene row (include/scoary_io.h,
     scoary_lists_build): dict of numpy arrays idx (uint32), start, ngroups,
-    order (int32), flipped (uint8).  The three layout arguments come from
+    order (int32), flipped (uint8).  The four layout arguments come from
     scoary_list_params(N)."""
     L = _load()
     vp, i64 = ctypes.c_void_p, ctypes.c_int64
-    L.scoary_lists_count.argtypes = [vp, i64, i64, i64]
+    L.scoary_lists_count.argtypes = [vp, i64, i64, i64, i64]
     L.scoary_lists_count.restype = i64
-    L.scoary_lists_build.argtypes = [vp, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.scoary_lists_build.argtypes = [vp, i64, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp]
     L.scoary_lists_build.restype = None
     rows64 = np.ascontiguousarray(rows64, dtype=np.uint64)
     G = rows64.shape[0]
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)        # noqa: E731
-    total = L.scoary_lists_count(p(rows64), G, int(N), int(genes_per_wave))
+    total = L.scoary_lists_count(p(rows64), G, int(N), int(genes_per_wave), int(piece))
     # + 64 entries of slack: the kernel prefetches index vectors unconditionally
     out = {"idx": np.zeros(total + 64, dtype=np.uint32),
            "start": np.zeros(G, dtype=np.int32), "ngroups": np.zeros(G, dtype=np.int32),
            "order": np.zeros(G, dtype=np.int32), "flipped": np.zeros(G, dtype=np.uint8)}
     L.scoary_lists_build(p(rows64), G, int(N), int(row_stride), int(genes_per_wave), int(classes),
+                         int(piece),
                          p(out["idx"]), p(out["start"]), p(out["ngroups"]), p(out["order"]),
                          p(out["flipped"]))
     out["entries"] = int(total)

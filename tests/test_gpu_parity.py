@@ -313,8 +313,8 @@ def test_headline_config_properties(eng, orc):
     (1, 1, 1, 10), (7, 40, 2, 33), (300, 100, 2, 512), (513, 130, 3, 600), (1000, 500, 1, 1100),
     (400, 700, 2, 65), (260, 1500, 1, 700), (500, 2000, 3, 1030), (90, 2400, 2, 520),
     (64, 2559, 1, 513), (70, 2560, 1, 300), (130, 3000, 2, 260), (200, 4000, 1, 530),
-    (90, 5000, 2, 257), (40, 5119, 1, 100),          # 8 lanes per gene, tiles of 256
-    (50, 5120, 1, 129), (120, 7000, 2, 200), (70, 10000, 1, 130), (33, 10239, 1, 64),   # 4 lanes
+    (90, 5000, 2, 257), (40, 5119, 1, 100),          # 8-dword tile rows, tiles of 256
+    (50, 5120, 1, 129), (120, 7000, 2, 200), (70, 10000, 1, 130), (33, 10239, 1, 64),   # 4-dword
 ])
 def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     """The list-driven kernel (minority lists + bit-sliced counters) gives
@@ -341,6 +341,25 @@ def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     assert np.array_equal(lists.view(np.uint32), want)
 
 
+@pytest.mark.parametrize("G,N,T,P", [(300, 100, 2, 512), (500, 2000, 2, 1030), (130, 3000, 2, 260),
+                                     (70, 10000, 1, 130)])
+def test_permute_lists_b32_variant(eng, orc, monkeypatch, G, N, T, P):
+    """SCOARY_LISTS_WPL=1 selects k_permute_lists (one 32-permutation word per
+    lane, contiguous lists) -- the A/B baseline of k_permute_lists128; same r."""
+    monkeypatch.setenv("SCOARY_LISTS_WPL", "1")
+    assert eng.list_params(N)[4] == 0                           # contiguous lists
+    rng = np.random.default_rng(G + N)
+    genes, traits = _random_case(rng, G, N, T)
+    tb, mb = _bits(eng, traits)
+    from scoary_amd.engine import pack_bits_rows
+    gm = eng.pack_dense(genes)
+    eng.build_lists(gm, pack_bits_rows(genes))
+    got = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=3,
+                        use_lists=True)["r"].cpu().numpy()
+    want = orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, 3).T
+    assert np.array_equal(got.view(np.uint32), want)
+
+
 @pytest.mark.parametrize("N", [333, 2700, 6000])
 def test_perm_tiles_are_the_transposed_row_labels(eng, N):
     """k_perm_generate_tiles writes the same spec-S4 labels as k_perm_generate,
@@ -354,7 +373,7 @@ def test_perm_tiles_are_the_transposed_row_labels(eng, N):
     _, margins = eng.counts(eng.pack_dense(np.ones((1, N), dtype=np.uint8)), trv, masks)
     rows = eng.perm_generate(masks, margins, N, P, base, 5).cpu().numpy().view(np.uint32)
     tiles = eng.perm_generate_tiles(masks, margins, N, P, base, 5).cpu().numpy().view(np.uint32)
-    lanes, stride, gpw, classes = eng.list_params(N)
+    lanes, stride, gpw, classes, _piece = eng.list_params(N)
     RS = stride // 4
     tperm = lanes * 32
     ntiles = -(-P // tperm)
@@ -425,8 +444,8 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_counts(null, p, p, p, 1, 1, 1, p, p, null) == -1
     out = ctypes.c_void_p()
     assert lib.scoary_create(99, ctypes.byref(out)) == -4 and not out.value
-    params = (ctypes.c_int64 * 4)()
-    assert lib.scoary_list_params(2000, params) == 0 and list(params) == [16, 64, 4, 2]
-    assert lib.scoary_list_params(5000, params) == 0 and list(params) == [8, 32, 8, 4]
-    assert lib.scoary_list_params(5120, params) == 0 and list(params) == [4, 16, 16, 8]
+    params = (ctypes.c_int64 * 5)()
+    assert lib.scoary_list_params(2000, params) == 0 and list(params) == [16, 64, 16, 4, 16]
+    assert lib.scoary_list_params(5000, params) == 0 and list(params) == [8, 32, 32, 8, 8]
+    assert lib.scoary_list_params(5120, params) == 0 and list(params) == [4, 16, 64, 16, 4]
     assert lib.scoary_list_params(10240, params) == -3 and params[0] == 0

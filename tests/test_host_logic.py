@@ -330,12 +330,15 @@ def test_io_library_exports_every_declared_symbol():
 
 
 # ------------------------------------------------- minority index lists ------
-@pytest.mark.parametrize("gpw,classes,stride", [(4, 2, 64), (8, 4, 32), (16, 8, 16)])
-def test_minority_lists_builder(gpw, classes, stride):
+@pytest.mark.parametrize("gpw,classes,stride,piece", [(4, 2, 64, 0), (8, 4, 32, 0), (16, 8, 16, 0),
+                                                       (16, 4, 64, 16), (32, 8, 32, 8),
+                                                       (64, 16, 16, 4)])
+def test_minority_lists_builder(gpw, classes, stride, piece):
     """scoary_lists_build (host native): per gene the positions of its minority
-    value, padded with N to a multiple of 32 and to the quad's longest list,
-    genes ordered by descending length, even slots even-rows-first / odd slots
-    odd-rows-first (LDS bank trick), entries premultiplied by the row stride."""
+    value, padded with N to a multiple of 32 and to the wave group's longest list,
+    genes ordered by descending length, slot k starting with residue class
+    k mod classes (LDS bank trick), entries premultiplied by the row stride;
+    piece > 0: the group's lists interleaved in pieces, last group stored in full."""
     from scoary_amd import io_native
     from scoary_amd.engine import pack_bits_rows
     rng = np.random.default_rng(9)
@@ -343,7 +346,7 @@ def test_minority_lists_builder(gpw, classes, stride):
     dense = (rng.random((G, N)) < rng.uniform(0.0, 1.0, (G, 1))).astype(np.uint8)
     dense[0] = 0
     dense[1] = 1
-    L = io_native.build_lists(pack_bits_rows(dense), N, stride, gpw, classes)
+    L = io_native.build_lists(pack_bits_rows(dense), N, stride, gpw, classes, piece)
     order, start, ng, flipped = L["order"], L["start"], L["ngroups"], L["flipped"]
     assert sorted(order.tolist()) == list(range(G))
     n1 = dense.sum(1).astype(np.int64)
@@ -353,9 +356,18 @@ def test_minority_lists_builder(gpw, classes, stride):
     total = 0
     for k in range(G):
         g = order[k]
-        ent = L["idx"][start[k] * 32:(start[k] + ng[k]) * 32]
-        assert start[k] * 32 == total
-        total += ng[k] * 32
+        if piece == 0:
+            ent = L["idx"][start[k] * 32:(start[k] + ng[k]) * 32]
+            assert start[k] * 32 == total
+            total += ng[k] * 32
+        else:
+            j, base = k % gpw, start[k] * 32
+            assert start[k] == start[(k // gpw) * gpw]
+            if j == 0:
+                assert base == total
+                total += gpw * ng[k] * 32                           # full groups, also the last
+            e = np.arange(ng[k] * 32)
+            ent = L["idx"][base + ((e // piece) * gpw + j) * piece + e % piece]
         assert ng[k] == ng[(k // gpw) * gpw]                        # equal within a wave group
         assert ng[k] * 32 >= length[g] and \
             (ng[(k // gpw) * gpw] * 32 - length[order[(k // gpw) * gpw]]) < 32
@@ -371,4 +383,10 @@ def test_minority_lists_builder(gpw, classes, stride):
         for c in range(classes):
             sub = real[cls == c]
             assert np.all(np.diff(sub) > 0)                         # ascending within a class
+    if piece:                                                       # missing genes of the last group
+        k0 = (G - 1) // gpw * gpw
+        e = np.arange(ng[k0] * 32)
+        for j in range(G - k0, gpw):
+            ent = L["idx"][start[k0] * 32 + ((e // piece) * gpw + j) * piece + e % piece]
+            assert np.all(ent == N * stride)
     assert L["entries"] == total and len(L["idx"]) >= total + 32

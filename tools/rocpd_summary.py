@@ -36,6 +36,14 @@ def main():
             f.write("%-34s %6s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
             for name, calls, tot, avg, pct in rows:
                 f.write("%-34s %6d %14.3f %12.3f %8.3f\n" % (short(name)[:34], calls, tot, avg, pct))
+            # per-launch durations of the dominant kernel, in launch order (the first
+            # launches of a process run on unsettled clocks)
+            if rows:
+                top = rows[0][0]
+                durs = [d / 1e3 for (d,) in c.execute(
+                    "select duration from kernels where name = ? order by start", (top,))]
+                f.write("# %s per launch, us: %s\n" % (short(top)[:34],
+                                                       " ".join("%.1f" % d for d in durs)))
         c.close()
     pmc = {}
     for sub, db in (("pmc_fetch", "fetch_results.db"), ("pmc_write", "write_results.db"),
