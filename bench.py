@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--isolates", type=int, default=None, help="override N (shape experiments)")
     ap.add_argument("--traits", type=int, default=None, help="override T (shape experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exercise-exchange", action="store_true",
+                    help="run the RCCL exchange step even at world size 1 (launched under "
+                         "torch.distributed.run with one rank): a 1-GPU check of the N>1 code path")
     ap.add_argument("--kernel", default="auto", choices=["auto", "dense", "lists"],
                     help="permutation kernel: dense (k_permute_reg/chunked) or list-driven")
     ap.add_argument("--cpu-seconds", type=float, default=10.0,
@@ -114,13 +117,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    sharded = world > 1 or (args.exercise_exchange and "RANK" in os.environ)
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if sharded:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from scoary_amd import synth
@@ -158,7 +162,7 @@ def main():
     # gather has completed before the closing barrier of the timed region.
     pending = []
     recv_bufs = [None, None]
-    if world > 1 and rank == 0:
+    if sharded and rank == 0:
         recv_bufs = [torch.empty((world, T, G, sdist.REC_WORDS), dtype=torch.int32,
                                  device=eng.device) for _ in range(2)]
     step_no = [0]
@@ -171,7 +175,7 @@ def main():
     def step():
         res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, perm_buffer=perm_buf,
                             use_lists=use_lists)
-        if world > 1:
+        if sharded:
             drain(keep=1)
             rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
             if exchange[0] == "gather":
@@ -191,7 +195,7 @@ def main():
 
     def barrier():
         drain()
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,7 +216,7 @@ def main():
     kernel_ms = {k: eng.kernel_ms(k) for k in names}
     eng.set_timing(False)
 
-    if world > 1:
+    if sharded:
         tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -251,7 +255,7 @@ def main():
                                    % (args.config, G, N, T, P),
                        "genes_per_gpu": G, "isolates": N, "traits": T, "permutations": P,
                        "parallelism": "gene-shard x%d" % world,
-                       "exchange": ("rccl %s of per-gene records" % exchange[0]) if world > 1
+                       "exchange": ("rccl %s of per-gene records" % exchange[0]) if sharded
                        else "none (single GPU)"},
             "roofline": {
                 "bound": "hbm",
@@ -277,7 +281,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(genes, traits, N, seed, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
