@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 LISTS_DEFAULT = True         # list-driven kernel: 9.5 ms vs 16.2 ms (dense) on the headline config
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (upper bound)
+INT_VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9   # integer/logic ops: 16 lanes/clk/SIMD (profiles/r01_valu_peak.txt)
 
 
 def parse():
@@ -63,7 +64,7 @@ def load_traffic(config, default_sizes, kernel="k_permute"):
     command).  None when no summary matches the workload being run."""
     import glob
     if not default_sizes:
-        return None, None
+        return None, None, None
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
         try:
@@ -77,8 +78,9 @@ def load_traffic(config, default_sizes, kernel="k_permute"):
             is_lists = k.startswith("k_permute_lists")
             if k.startswith("k_permute") and is_lists == (kernel == "k_permute_lists") \
                     and "hbm_traffic_bytes_per_launch" in v:
-                best = (v["hbm_traffic_bytes_per_launch"], os.path.relpath(path, ROOT))
-    return best if best else (None, None)
+                best = (v["hbm_traffic_bytes_per_launch"], os.path.relpath(path, ROOT),
+                        v.get("SQ_INSTS_VALU"))
+    return best if best else (None, None, None)
 
 
 def cpu_baseline(genes, traits, N, seed, target_s):
@@ -232,7 +234,7 @@ def main():
             launches_per_step = 1
         alg_bytes = 16.0 * W64 * tests_per_launch        # 16*W bytes / test
         achieved = alg_bytes / (k3_ms * 1e-3) / 1e9
-        traffic, traffic_src = load_traffic(
+        traffic, traffic_src, valu_insts = load_traffic(
             args.config, args.genes is None and args.permutations is None
             and args.isolates is None and args.traits is None, k3_name)
         w32 = -(-N // 32)
@@ -248,7 +250,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 bit-words (AND + popcount), f64 for Fisher p",
+            "dtype": "u32 bit-words (bit-sliced adders / AND + popcount), f64 for Fisher p",
             "data": "synthetic",
             "config": {"workload": "%s: %d genes x %d isolates x %d traits, --permute %d per GPU; "
                                    "counts + Fisher + label permutations + exceedance counts"
@@ -275,6 +277,17 @@ def main():
                 "tests_per_s_kernel": tests_per_launch / (k3_ms * 1e-3),
                 "dense_model_valu_frac_of_2.4GHz_simd32_peak":
                     None if use_lists else valu_ops / (k3_ms * 1e-3) / VALU_LANE_OPS_PER_S,
+                # what actually binds: integer-VALU issue (figure iii).  Instruction
+                # count from the committed SQ_INSTS_VALU pass, duration measured live; the
+                # ceiling is tools/valu_peak.hip's measured 4.0e13 lane-ops/s
+                # (= 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz for v_and/v_bcnt/v_bitop3).
+                "valu": None if not valu_insts else {
+                    "wave_insts_per_launch": valu_insts,
+                    "ops_per_test": valu_insts * 64.0 / tests_per_launch,
+                    "lane_ops_per_s": valu_insts * 64.0 / (k3_ms * 1e-3),
+                    "peak_lane_ops_per_s": INT_VALU_LANE_OPS_PER_S,
+                    "frac": valu_insts * 64.0 / (k3_ms * 1e-3) / INT_VALU_LANE_OPS_PER_S,
+                    "source": traffic_src},
             },
             "kernel_ms": kernel_ms,
         }

@@ -1132,6 +1132,7 @@ def main(**kwargs):
                     upgmatree = T.prune_missing(upgmatree, [i for i in members if i not in keepset])
             log.info("Reading traits file")
             traitsdic, prunedic = Csv_to_dic(traits, args.delimiter, allowed, strains)
+        t_loaded = _time.time()
         log.info("Finished loading files into memory.\n\n")
         log.info("==== Performing statistics ====")
         for line in filtrationoptions(cutoffs, args.collapse):
@@ -1142,6 +1143,7 @@ def main(**kwargs):
         # in the pairwise stage like the reference does.
         res = Setup_results(genedic, traitsdic, args.collapse,
                             permutations=args.permute if args.no_pairwise else 0, seed=seed)
+        t_stats = _time.time()
         if args.upgma_tree and upgmatree is not None and rank == 0:
             StoreUPGMAtreeToFile(upgmatree, args.outdir, time=stamp)
         if rank == 0:           # every rank holds the gathered results; one writes
@@ -1149,6 +1151,8 @@ def main(**kwargs):
                          res["Gene_trait_combinations"], prunedic, args.outdir, args.permute,
                          args.threads, args.no_pairwise, genedic, gd["Extracols"],
                          gd["Firstcolnames"], time=stamp, delimiter=args.delimiter, seed=seed)
+        log.info("Stage seconds: load (+tree) %.2f, association (+permutations) %.2f, pairwise stage and "
+                 "output %.2f" % (t_loaded - start, t_stats - t_loaded, _time.time() - t_stats))
         log.info("\n")
         log.info("==== Finished ====")
         log.info("Checked a total of %d genes for associations to %d trait(s). Total time "

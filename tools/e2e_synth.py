@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--traits", type=int, default=5)
     ap.add_argument("--permute", type=int, default=1000)
     ap.add_argument("--pairwise", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="run the CLI under cProfile")
     a = ap.parse_args()
     rng = np.random.default_rng(3)
     d = tempfile.mkdtemp()
@@ -52,7 +53,9 @@ def main():
             f.write(iso[i] + "," + ",".join("1" if lab[t, i] else "0" for t in range(T)) + "\n")
     print("wrote inputs (%.0f MB) in %.1f s" % (os.path.getsize(gpa) / 1e6, time.time() - t0))
     out = os.path.join(d, "out")
-    cmd = [sys.executable, "-m", "scoary_amd", "-g", gpa, "-t", tr, "-o", out, "--no-time",
+    prof = os.path.join(d, "cli.prof")
+    cmd = [sys.executable] + (["-m", "cProfile", "-o", prof] if a.profile else []) + [
+        "-m", "scoary_amd", "-g", gpa, "-t", tr, "-o", out, "--no-time",
            "-e", str(a.permute), "-p", "0.05"]
     if not a.pairwise:
         cmd.append("--no_pairwise")
@@ -63,6 +66,9 @@ def main():
     print("\n".join(r.stdout.splitlines()[-12:]))
     if r.returncode:
         print(r.stderr[-2000:])
+    if a.profile and os.path.exists(prof):
+        import pstats
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(35)
     for fn in sorted(os.listdir(out)):
         p = os.path.join(out, fn)
         print(fn, os.path.getsize(p), "bytes")
