@@ -558,6 +558,114 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
   }
 }
 
+// The same tiles from a workgroup per 64 permutations, for launches with fewer
+// wavefronts than the chip has SIMDs (few traits x permutations, long rows): the
+// sampling is serial over the isolates only in `needed` (two dependent VALU ops
+// per isolate) while the Philox draws are not, so kGenProducers wavefronts
+// compute the draws one 64-isolate chunk ahead into LDS (lane = permutation in
+// every wavefront) and ONE selection wavefront walks the chunk; its compare
+// mask over the 64 lanes IS the tile row of that isolate.
+constexpr int kGenProducers = 7;
+constexpr int kGenSplitBelow = 1;  // workgroup variant below this many wavefronts per SIMD
+constexpr int kGenChunk = 64;      // isolates per LDS buffer = 16 Philox counters
+// Philox counters (of the 16 per chunk) each producer wavefront computes.  A
+// workgroup's wavefronts go to the SIMDs cyclically, so wavefront 4 shares the
+// selection wavefront's SIMD and is given nothing.
+__constant__ const int8_t kGenWork[kGenProducers][3] = {
+    {0, 6, 12}, {1, 7, 13}, {2, 8, 14}, {-1, -1, -1}, {3, 9, 15}, {4, 10, -1}, {5, 11, -1}};
+
+// v[LANE] = value (wave-uniform); hipcc has no builtin for v_writelane_b32, and
+// its lane select must be an inline constant next to an SGPR value.
+template <int LANE>
+__device__ __forceinline__ void write_lane(uint32_t& v, uint32_t value) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(value), "n"(LANE));
+}
+// Spec-S4 selection for isolates II.. of a chunk: u = the lane's draws, rem0 =
+// valid isolates left at the chunk's start, mw = its validity bits (both
+// wave-uniform; ALLVALID: mw is all ones), livemask = lanes whose permutation exists.
+template <int II, bool ALLVALID>
+__device__ __forceinline__ void select_rows(const uint32_t (&u)[kGenChunk], uint32_t rem0,
+                                            uint64_t mw, uint64_t livemask, uint32_t& needed,
+                                            uint32_t& lo, uint32_t& hi) {
+  if constexpr (II < kGenChunk) {
+    uint64_t b = 0;
+    if (ALLVALID || ((mw >> II) & 1u)) {               // wave-uniform
+      const uint32_t rem =
+          ALLVALID ? rem0 - II : rem0 - (uint32_t)__popcll(mw & (((uint64_t)1 << II) - 1));
+      const bool hit = __umulhi(u[II], rem) < needed;
+      needed -= hit ? 1u : 0u;
+      b = __builtin_amdgcn_ballot_w64(hit) & livemask;
+    }
+    write_lane<II>(lo, (uint32_t)b);                 // lane l: the row of isolate l of the chunk
+    write_lane<II>(hi, (uint32_t)(b >> 32));
+    select_rows<II + 1, ALLVALID>(u, rem0, mw, livemask, needed, lo, hi);
+  }
+}
+
+template <int LG>
+__global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_tiles_wg(
+    const uint32_t* __restrict__ masks, const int32_t* __restrict__ margins, int N, int Wp,
+    int64_t P, int64_t perm_base, int trait_base, uint32_t k0, uint32_t k1, int ntiles,
+    uint32_t* __restrict__ tiles) {
+  __shared__ uint32_t draws[2][kGenChunk][kWave];
+  const int t = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1), role = threadIdx.x / kWave;   // 0: selection
+  const int64_t wave = blockIdx.x;                    // 64 permutations each
+  const int64_t pl = wave * kWave + lane;
+  const bool live = pl < P;
+  const uint32_t pi = (uint32_t)(perm_base + pl);
+  const int waves_per_tile = LG / 2;
+  const int tile = (int)(wave / waves_per_tile);
+  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
+  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG) + col;
+  uint32_t needed = (uint32_t)margins[2 * t];
+  uint32_t remaining = (uint32_t)__builtin_amdgcn_readfirstlane(margins[2 * t + 1]);
+  const uint32_t* mrow = masks + (int64_t)t * Wp;     // Wp >= 2*nchunks words, zero padded
+  const int nchunks = (N + kGenChunk - 1) / kGenChunk;
+  const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
+  if (role == 0) __builtin_amdgcn_s_setprio(3);       // the serial wavefront goes first
+  for (int c = 0; c <= nchunks; ++c) {
+    if (role > 0) {
+      if (c < nchunks) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int jj = kGenWork[role - 1][k];
+          if (jj < 0) break;
+          uint32_t r[4];
+          philox4x32_10((uint32_t)(c * (kGenChunk / 4) + jj), pi, (uint32_t)(trait_base + t),
+                        kPermDomain, k0, k1, r);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) draws[c & 1][4 * jj + q][lane] = r[q];
+        }
+      }
+    } else if (c > 0) {
+      const int cc = c - 1;
+      const uint64_t mw = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * cc]) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * cc + 1]) << 32;
+      const uint32_t rem0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)remaining);
+      uint32_t u[kGenChunk];
+#pragma unroll
+      for (int ii = 0; ii < kGenChunk; ++ii) u[ii] = draws[cc & 1][ii][lane];
+      uint32_t lo = 0u, hi = 0u;
+      if (mw == ~(uint64_t)0)
+        select_rows<0, true>(u, rem0, mw, livemask, needed, lo, hi);
+      else
+        select_rows<0, false>(u, rem0, mw, livemask, needed, lo, hi);
+      remaining -= (uint32_t)__popcll(mw);
+      const int row = cc * kGenChunk + lane;
+      if (row < N) {
+        base[(int64_t)row * LG] = lo;
+        base[(int64_t)row * LG + 1] = hi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {  // the all-zero row that list padding points at
+    base[(int64_t)N * LG] = 0u;
+    base[(int64_t)N * LG + 1] = 0u;
+  }
+}
+
 // Per (trait, list slot): the rejection region in terms of the LIST count u
 // (u = a for a ones-list, npos - a for a zeros-list), modulo M = 2^KD:
 //   in region  <=>  always | ((((u - base) mod M) >= span) ^ invert)
@@ -1619,11 +1727,20 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
   const dim3 grid((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T);
   KernelTimer kt(h, s, "k_perm_generate_tiles");
-#define GEN_TILES(LGV)                                                                              \
-  hipLaunchKernelGGL((k_perm_generate_tiles<LGV>), grid, dim3(kWave), 0, s, d_masks, d_margins, (int)N, \
-                     (int)scoary_row_words(N), P, perm_base, (int)trait_base, (uint32_t)seed,        \
-                     (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
-  if (LG == 16) GEN_TILES(16); else if (LG == 8) GEN_TILES(8); else GEN_TILES(4);
+  // one wavefront per 64 permutations when there are enough of them to fill the
+  // chip; otherwise a workgroup each, with the Philox draws spread over more lanes
+  const bool wg = (int64_t)grid.x * grid.y < (int64_t)h->num_cu * 4 * kGenSplitBelow;
+#define GEN_TILES(LGV)                                                                            \
+  if (wg)                                                                                         \
+    hipLaunchKernelGGL((k_perm_generate_tiles_wg<LGV>), grid, dim3(kWave * (1 + kGenProducers)),  \
+                       0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P, perm_base,  \
+                       (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles,      \
+                       d_tiles);                                                                  \
+  else                                                                                            \
+    hipLaunchKernelGGL((k_perm_generate_tiles<LGV>), grid, dim3(kWave), 0, s, d_masks, d_margins, \
+                       (int)N, (int)scoary_row_words(N), P, perm_base, (int)trait_base,           \
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
+  if (LG == 16) { GEN_TILES(16); } else if (LG == 8) { GEN_TILES(8); } else { GEN_TILES(4); }
 #undef GEN_TILES
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;

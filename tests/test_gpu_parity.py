@@ -360,14 +360,17 @@ def test_permute_lists_b32_variant(eng, orc, monkeypatch, G, N, T, P):
     assert np.array_equal(got.view(np.uint32), want)
 
 
-@pytest.mark.parametrize("N", [333, 2700, 6000])
-def test_perm_tiles_are_the_transposed_row_labels(eng, N):
+@pytest.mark.parametrize("N,T,P", [(333, 2, 700), (2700, 2, 700), (6000, 2, 700), (64, 1, 64),
+                                   (333, 4, 17000)])
+def test_perm_tiles_are_the_transposed_row_labels(eng, N, T, P):
     """k_perm_generate_tiles writes the same spec-S4 labels as k_perm_generate,
-    isolate-major in tiles of 512 permutations, zero row + zero ragged tail."""
+    isolate-major in tiles of 512 / 256 / 128 permutations, zero row + zero ragged
+    tail.  Few (trait, 64-permutation) wavefronts -> the workgroup variant with
+    Philox producer wavefronts; >= 1024 of them (last case) -> one wavefront each."""
     rng = np.random.default_rng(2)
-    T, P, base = 2, 700, 40
+    base = 40
     traits = (rng.random((T, N)) < 0.4).astype(np.uint8)
-    traits[1, rng.random(N) < 0.1] = 2
+    traits[T - 1, rng.random(N) < 0.1] = 2
     tb, mb = _bits(eng, traits)
     masks, trv = eng.vecrows(mb, N), eng.vecrows(tb, N)
     _, margins = eng.counts(eng.pack_dense(np.ones((1, N), dtype=np.uint8)), trv, masks)
