@@ -1,0 +1,520 @@
+// scoary_assoc.hip -- gfx950 (MI355X / CDNA4) kernels + C-ABI for Scoary's
+// association hot path.  See include/scoary_hip.h for the contract and
+// DESIGN.md for layouts, byte models and the specs S1-S5 shared with the CPU
+// oracle.
+//
+// Design in one paragraph: the gene presence/absence matrix lives in HBM as
+// 32-bit words in "word-quad-major" order, so ONE LANE OWNS ONE GENE: a
+// wavefront's gene loads are 1 KiB coalesced dwordx4, while the other operand
+// of every AND -- a trait / mask / permuted-label word -- is wave-uniform and
+// is fetched through the SCALAR cache into SGPRs.  The inner loop is therefore
+// exactly two VALU ops per 32 isolates per (gene, vector) pair:
+//     v_and_b32  tmp, s_vec, v_gene ;  v_bcnt_u32_b32  acc, tmp, acc
+// with no LDS traffic and no cross-lane reduction.  There is no MFMA: CDNA4
+// has no AND-popcount matrix mode, and this is integer/bit work.
+#include "scoary_common.hpp"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// a1: packing
+// ----------------------------------------------------------------------------
+// One thread per (gene, 32-bit word): 32 presence bytes -> one word.
+__global__ __launch_bounds__(256) void k_pack_dense(const uint8_t* __restrict__ dense,
+                                                    int64_t G, int64_t N, int64_t Gp,
+                                                    int64_t Qp, uint32_t* __restrict__ tiled) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t k = blockIdx.y;  // 32-bit word index, < 4*Qp
+  if (g >= Gp) return;
+  uint32_t word = 0;
+  if (g < G) {
+    const int64_t i0 = k * 32;
+    const uint8_t* row = dense + g * N;
+    for (int b = 0; b < 32; ++b) {
+      const int64_t i = i0 + b;
+      if (i < N && row[i] != 0) word |= 1u << b;
+    }
+  }
+  tiled[((k >> 2) * Gp + g) * 4 + (k & 3)] = word;
+}
+
+// One thread per (gene, quad): 16 bytes of a row-major bit row -> its tile slot.
+__global__ __launch_bounds__(256) void k_tile_rows(const uint32_t* __restrict__ rows32,
+                                                   int64_t G, int64_t W32, int64_t Gp,
+                                                   uint4* __restrict__ tiled) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t q = blockIdx.y;
+  if (g >= Gp) return;
+  uint32_t w[4] = {0, 0, 0, 0};
+  if (g < G) {
+    const uint32_t* row = rows32 + g * W32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < W32) w[j] = row[q * 4 + j];
+  }
+  tiled[q * Gp + g] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ----------------------------------------------------------------------------
+// a3: contingency counts
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_margins(const uint32_t* __restrict__ traits,
+                                                const uint32_t* __restrict__ masks, int Wp,
+                                                int32_t* __restrict__ margins) {
+  const int t = blockIdx.x;
+  int npos = 0, nval = 0;
+  for (int k = threadIdx.x; k < Wp; k += kWave) {
+    npos += __popc(traits[(int64_t)t * Wp + k]);
+    nval += __popc(masks[(int64_t)t * Wp + k]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    npos += __shfl_down(npos, off);
+    nval += __shfl_down(nval, off);
+  }
+  if (threadIdx.x == 0) {
+    margins[2 * t] = npos;
+    margins[2 * t + 1] = nval;
+  }
+}
+
+__device__ __forceinline__ int popc4(const uint4 a, const uint4 b) {
+  return __popc(a.x & b.x) + __popc(a.y & b.y) + __popc(a.z & b.z) + __popc(a.w & b.w);
+}
+
+// Lane = gene; blockIdx.y = group of TB traits.  Gene quads stream once per
+// trait group (coalesced 16 B / lane); trait and mask quads are wave-uniform
+// (scalar loads).
+template <int TB>
+__global__ __launch_bounds__(256) void k_counts(const uint4* __restrict__ tiled,
+                                                const uint32_t* __restrict__ traits,
+                                                const uint32_t* __restrict__ masks,
+                                                const int32_t* __restrict__ margins, int G,
+                                                int Gp, int Qp, int T, int4* __restrict__ counts) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int t0 = blockIdx.y * TB;
+  const int Wp = Qp * 4;
+  int a[TB], m[TB];
+  const uint4* trow[TB];
+  const uint4* mrow[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    a[j] = 0;
+    m[j] = 0;
+    const int t = min(t0 + j, T - 1);
+    trow[j] = reinterpret_cast<const uint4*>(traits + (int64_t)t * Wp);
+    mrow[j] = reinterpret_cast<const uint4*>(masks + (int64_t)t * Wp);
+  }
+  for (int q = 0; q < Qp; ++q) {
+    const uint4 gw = tiled[(int64_t)q * Gp + g];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      a[j] += popc4(gw, trow[j][q]);
+      m[j] += popc4(gw, mrow[j][q]);
+    }
+  }
+  if (g >= G) return;
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {
+    const int t = t0 + j;
+    if (t < T) {
+      const int npos = margins[2 * t], nval = margins[2 * t + 1];
+      counts[(int64_t)t * G + g] =
+          make_int4(a[j], npos - a[j], m[j] - a[j], nval - npos - m[j] + a[j]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// a5: two-sided Fisher exact test (spec S3)
+// ----------------------------------------------------------------------------
+// Hypergeometric weights by the exact ratio recurrence, normalised at the
+// mode; same operation order as the oracle's hg_weights so the weights (and
+// hence the rejection regions) are bit-identical on both sides.
+__device__ __forceinline__ double w_up(double w, int x, int n1, int n2, int n) {
+  return w * ((double)(n1 - x) * (double)(n - x)) / ((double)(x + 1) * (double)(n2 - n + x + 1));
+}
+__device__ __forceinline__ double w_down(double w, int x, int n1, int n2, int n) {
+  return w * ((double)x * (double)(n2 - n + x)) / ((double)(n1 - x + 1) * (double)(n - x + 1));
+}
+
+__global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, int64_t M,
+                                               double* __restrict__ p_out,
+                                               double* __restrict__ or_out,
+                                               uint2* __restrict__ crit) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M) return;
+  const int4 c = tables[idx];
+  const int a = c.x, b = c.y, cc = c.z, d = c.w;
+  const int n1 = a + b, n2 = cc + d, n = a + cc;
+  if (n1 == 0 || n2 == 0 || n == 0 || b + d == 0) {
+    p_out[idx] = 1.0;
+    or_out[idx] = __longlong_as_double(0x7ff8000000000000LL);
+    if (crit) crit[idx] = make_uint2(0u, 0u);
+    return;
+  }
+  or_out[idx] = (cc > 0 && b > 0) ? ((double)a * (double)d) / ((double)cc * (double)b)
+                                  : __longlong_as_double(0x7ff0000000000000LL);
+  const int lo = max(0, n - n2), hi = min(n, n1);
+  int mode = (int)(((double)(n + 1) * (double)(n1 + 1)) / (double)(n1 + n2 + 2));
+  mode = min(max(mode, lo), hi);
+
+  double w = 1.0;
+  if (a > mode)
+    for (int x = mode; x < a; ++x) w = w_up(w, x, n1, n2, n);
+  else
+    for (int x = mode; x > a; --x) w = w_down(w, x, n1, n2, n);
+  const double thr = w * (1.0 + kTie);
+
+  // Both walks stop once a term is inside the rejection region AND below
+  // 2^-90 of the observed table's weight: what is left of the
+  // (super-geometrically decaying) tail is < 1e-26 of the included sum, so p
+  // keeps its RELATIVE accuracy even when it is 1e-200, and the region
+  // boundary has already been passed, so (L, H) are exact.
+  const double tiny = 8.077935669463161e-28 * (thr < 1.0 ? thr : 1.0);   // 2^-90 * w_obs
+  double tot = 0.0, inc = 0.0;
+  int H = hi + 1, L = lo - 1;
+  w = 1.0;
+  for (int x = mode; x <= hi; ++x) {
+    tot += w;
+    if (w <= thr) {
+      inc += w;
+      if (H > hi) H = x;
+      if (w < tiny) break;
+    }
+    w = w_up(w, x, n1, n2, n);
+  }
+  w = 1.0;
+  for (int x = mode; x > lo; --x) {
+    w = w_down(w, x, n1, n2, n);  // weight of x-1
+    tot += w;
+    if (w <= thr) {
+      inc += w;
+      if (L < lo) L = x - 1;
+      if (w < tiny) break;
+    }
+  }
+  const bool all = (H == mode);
+  const double p = all ? 1.0 : inc / tot;
+  p_out[idx] = p < 1.0 ? p : 1.0;
+  if (crit) crit[idx] = all ? make_uint2(0u, 0u) : make_uint2((uint32_t)(L + 1), (uint32_t)(H - L - 1));
+}
+
+// ----------------------------------------------------------------------------
+// a8: label permutations (spec S4)
+// ----------------------------------------------------------------------------
+
+// One thread per (trait, permutation): sequential selection sampling over the
+// isolates, 32 at a time; the validity word is wave-uniform (blockIdx.y =
+// trait), the 32-bit draws come from Philox keyed by (isolate>>2, pi, trait).
+__global__ __launch_bounds__(64) void k_perm_generate(const uint32_t* __restrict__ masks,
+                                                      const int32_t* __restrict__ margins, int N,
+                                                      int Wp, int64_t P, int64_t perm_base,
+                                                      int trait_base, uint32_t k0, uint32_t k1,
+                                                      uint32_t* __restrict__ perms) {
+  const int t = blockIdx.y;
+  const int64_t pl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl >= P) return;
+  const uint32_t pi = (uint32_t)(perm_base + pl);
+  uint32_t needed = (uint32_t)margins[2 * t], remaining = (uint32_t)margins[2 * t + 1];
+  const uint32_t* mrow = masks + (int64_t)t * Wp;
+  uint32_t* out = perms + ((int64_t)t * P + pl) * Wp;
+  const int nw = (N + 31) / 32;
+  for (int k = 0; k < nw; ++k) {
+    const uint32_t mw = mrow[k];
+    uint32_t word = 0;
+#pragma unroll 4
+    for (int jj = 0; jj < 8; ++jj) {             // one Philox call = four isolates
+      uint32_t r[4];
+      philox4x32_10((uint32_t)(k * 8 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int bit = 4 * jj + q;
+        if ((mw >> bit) & 1u) {
+          if (__umulhi(r[q], remaining) < needed) {
+            word |= 1u << bit;
+            --needed;
+          }
+          --remaining;
+        }
+      }
+    }
+    out[k] = word;
+  }
+  for (int k = nw; k < Wp; ++k) out[k] = 0u;
+}
+
+// ----------------------------------------------------------------------------
+// a7: permutation exceedance counts
+// ----------------------------------------------------------------------------
+// Register-resident variant: a lane keeps GL whole gene rows (RQ quads each)
+// in VGPRs and walks a chunk of permuted label rows, which arrive as scalar
+// loads.  Work per (gene, permutation): 8*RQ VALU ops + 3 for the region test.
+// grid = (Gp / (64*GL), perm chunks, T), block = one wavefront.
+template <int RQ, int GL>
+__global__ __launch_bounds__(64) void k_permute_reg(const uint4* __restrict__ tiled,
+                                                    const uint32_t* __restrict__ perms,
+                                                    const uint2* __restrict__ crit, int G, int Gp,
+                                                    int64_t P, int pchunk,
+                                                    uint32_t* __restrict__ r) {
+  const int t = blockIdx.z;
+  const int lane = threadIdx.x;
+  const int g0 = blockIdx.x * (kWave * GL) + lane;
+  const int64_t p0 = (int64_t)blockIdx.y * pchunk;
+  const int np = (int)min((int64_t)pchunk, P - p0);
+
+  uint4 gw[GL][RQ];
+  uint32_t base[GL], span[GL], cnt[GL];
+#pragma unroll
+  for (int gl = 0; gl < GL; ++gl) {
+    const int g = g0 + gl * kWave;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) gw[gl][q] = tiled[(int64_t)q * Gp + g];
+    const uint2 cr = (g < G) ? crit[(int64_t)t * G + g] : make_uint2(0u, 0u);
+    base[gl] = cr.x;
+    span[gl] = cr.y;
+    cnt[gl] = 0;
+  }
+
+  const uint4* prow = reinterpret_cast<const uint4*>(perms + ((int64_t)t * P + p0) * (RQ * 4));
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+  for (int i = 0; i < np; ++i, prow += RQ) {
+    uint32_t acc[GL][4];
+#pragma unroll
+    for (int gl = 0; gl < GL; ++gl) acc[gl][0] = acc[gl][1] = acc[gl][2] = acc[gl][3] = 0;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const uint4 s = prow[q];  // wave-uniform address -> s_load
+#pragma unroll
+      for (int gl = 0; gl < GL; ++gl) {
+        bcnt_acc(acc[gl][0], gw[gl][q].x & s.x);
+        bcnt_acc(acc[gl][1], gw[gl][q].y & s.y);
+        bcnt_acc(acc[gl][2], gw[gl][q].z & s.z);
+        bcnt_acc(acc[gl][3], gw[gl][q].w & s.w);
+      }
+    }
+#pragma unroll
+    for (int gl = 0; gl < GL; ++gl) {
+      const uint32_t a = (acc[gl][0] + acc[gl][1]) + (acc[gl][2] + acc[gl][3]);
+      cnt[gl] += ((a - base[gl]) >= span[gl]) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int gl = 0; gl < GL; ++gl) {
+    const int g = g0 + gl * kWave;
+    if (g < G && cnt[gl]) atomicAdd(&r[(int64_t)t * G + g], cnt[gl]);
+  }
+}
+
+// General variant for rows too long to keep in registers: CQ-quad register
+// chunks of the gene row, PB permutations accumulated per pass.
+template <int CQ, int PB>
+__global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict__ tiled,
+                                                        const uint32_t* __restrict__ perms,
+                                                        const uint2* __restrict__ crit, int G,
+                                                        int Gp, int Qp, int64_t P, int pchunk,
+                                                        uint32_t* __restrict__ r) {
+  const int t = blockIdx.z;
+  const int g = blockIdx.x * kWave + threadIdx.x;
+  const int64_t p0 = (int64_t)blockIdx.y * pchunk;
+  const int np = (int)min((int64_t)pchunk, P - p0);
+  const uint2 cr = (g < G) ? crit[(int64_t)t * G + g] : make_uint2(0u, 0u);
+  const int nchunks = Qp / CQ;
+  uint32_t cnt = 0;
+  const uint4* pbase = reinterpret_cast<const uint4*>(perms + ((int64_t)t * P + p0) * ((int64_t)Qp * 4));
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+  for (int i0 = 0; i0 < np; i0 += PB) {
+    uint32_t acc[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[j] = 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int c = 0; c < nchunks; ++c) {
+      uint4 gw[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) gw[q] = tiled[(int64_t)(c * CQ + q) * Gp + g];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const int i = min(i0 + j, np - 1);
+        const uint4* pr = pbase + (int64_t)i * Qp + c * CQ;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+          const uint4 s = pr[q];  // wave-uniform -> s_load
+          bcnt_acc(acc[j], gw[q].x & s.x);
+          bcnt_acc(acc[j], gw[q].y & s.y);
+          bcnt_acc(acc[j], gw[q].z & s.z);
+          bcnt_acc(acc[j], gw[q].w & s.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j)
+      if (i0 + j < np) cnt += ((acc[j] - cr.x) >= cr.y) ? 1u : 0u;
+  }
+  if (g < G && cnt) atomicAdd(&r[(int64_t)t * G + g], cnt);
+}
+
+template <int RQ, int GL>
+void launch_permute_reg(dim3 grid, hipStream_t s, const uint32_t* tiled, const uint32_t* perms,
+                        const uint32_t* crit, int G, int Gp, int64_t P, int pchunk, uint32_t* r) {
+  hipLaunchKernelGGL((k_permute_reg<RQ, GL>), grid, dim3(kWave), 0, s,
+                     reinterpret_cast<const uint4*>(tiled), perms,
+                     reinterpret_cast<const uint2*>(crit), G, Gp, P, pchunk, r);
+}
+
+}  // namespace
+
+extern "C" {
+
+int scoary_pack_dense(scoary_handle h, const uint8_t* d_dense, int64_t G, int64_t N,
+                      uint32_t* d_tiled, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_dense || !d_tiled || G < 1 || N < 1) return fail(h, SCOARY_ERR_ARG, "scoary_pack_dense: bad argument");
+  DeviceGuard guard(h->device);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_pack_dense");
+  hipLaunchKernelGGL(k_pack_dense, dim3((unsigned)(Gp / 256), (unsigned)(Qp * 4)), dim3(256), 0, s,
+                     d_dense, G, N, Gp, Qp, d_tiled);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_tile_rows(scoary_handle h, const uint64_t* d_rows64, int64_t G, int64_t N,
+                     uint32_t* d_tiled, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_rows64 || !d_tiled || G < 1 || N < 1) return fail(h, SCOARY_ERR_ARG, "scoary_tile_rows: bad argument");
+  DeviceGuard guard(h->device);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+  const int64_t W32 = 2 * ((N + 63) / 64);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_tile_rows");
+  hipLaunchKernelGGL(k_tile_rows, dim3((unsigned)(Gp / 256), (unsigned)Qp), dim3(256), 0, s,
+                     reinterpret_cast<const uint32_t*>(d_rows64), G, W32, Gp,
+                     reinterpret_cast<uint4*>(d_tiled));
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_counts(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_traits,
+                  const uint32_t* d_masks, int64_t G, int64_t T, int64_t N, int32_t* d_counts,
+                  int32_t* d_margins, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_traits || !d_masks || !d_counts || !d_margins || G < 1 || T < 1 || N < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_counts: bad argument");
+  if (G > (int64_t)1 << 30 || T > 65535 * 8) return fail(h, SCOARY_ERR_SIZE, "scoary_counts: G or T too large");
+  DeviceGuard guard(h->device);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    KernelTimer kt(h, s, "k_margins");
+    hipLaunchKernelGGL(k_margins, dim3((unsigned)T), dim3(kWave), 0, s, d_traits, d_masks,
+                       (int)(Qp * 4), d_margins);
+  }
+  constexpr int TB = 4;
+  {
+    KernelTimer kt(h, s, "k_counts");
+    hipLaunchKernelGGL((k_counts<TB>), dim3((unsigned)(Gp / 256), (unsigned)((T + TB - 1) / TB)),
+                       dim3(256), 0, s, reinterpret_cast<const uint4*>(d_tiled), d_traits, d_masks,
+                       d_margins, (int)G, (int)Gp, (int)Qp, (int)T, reinterpret_cast<int4*>(d_counts));
+  }
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_fisher(scoary_handle h, const int32_t* d_tables, int64_t M, double* d_p, double* d_or,
+                  uint32_t* d_crit, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tables || !d_p || !d_or || M < 1) return fail(h, SCOARY_ERR_ARG, "scoary_fisher: bad argument");
+  if ((M + kWave - 1) / kWave > 0x7fffffffLL) return fail(h, SCOARY_ERR_SIZE, "scoary_fisher: M too large");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_fisher");
+  hipLaunchKernelGGL(k_fisher, dim3((unsigned)((M + kWave - 1) / kWave)), dim3(kWave), 0, s,
+                     reinterpret_cast<const int4*>(d_tables), M, d_p, d_or,
+                     reinterpret_cast<uint2*>(d_crit));
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_perm_generate(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
+                         int64_t T, int64_t N, int64_t P, int64_t perm_base, int64_t trait_base,
+                         uint64_t seed,
+                         uint32_t* d_perms, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_masks || !d_margins || !d_perms || T < 1 || N < 1 || P < 1 || perm_base < 0 ||
+      trait_base < 0)
+    return fail(h, SCOARY_ERR_ARG, "scoary_perm_generate: bad argument");
+  if (T > 65535 || trait_base + T > 0x7fffffffLL || perm_base + P > 0xffffffffLL)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate: T > 65535 or permutation index >= 2^32");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_perm_generate");
+  hipLaunchKernelGGL(k_perm_generate, dim3((unsigned)((P + kWave - 1) / kWave), (unsigned)T),
+                     dim3(kWave), 0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P,
+                     perm_base, (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), d_perms);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_permute(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_perms,
+                   const uint32_t* d_crit, int64_t G, int64_t T, int64_t N, int64_t P,
+                   uint32_t* d_r, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_perms || !d_crit || !d_r || G < 1 || T < 1 || N < 1 || P < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_permute: bad argument");
+  if (T > 65535 || G > (int64_t)1 << 30) return fail(h, SCOARY_ERR_SIZE, "scoary_permute: T > 65535 or G > 2^30");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+
+  // Enough independent wave-tasks to fill 256 CUs x 4 SIMDs several times
+  // over: split the permutation range when there are few gene-waves.
+  const int GL = 1;
+  const int64_t gene_waves = Gp / (kWave * GL);
+  const int64_t want_tasks = (int64_t)h->num_cu * 4 * 32;
+  int64_t nch = (want_tasks + gene_waves * T - 1) / (gene_waves * T);
+  const int64_t max_ch = (P + 63) / 64;  // keep >= 64 permutations per task
+  if (nch > max_ch) nch = max_ch;
+  if (nch < 1) nch = 1;
+  if (nch > 65535) nch = 65535;
+  const int pchunk = (int)((P + nch - 1) / nch);
+  nch = (P + pchunk - 1) / pchunk;
+  dim3 grid((unsigned)gene_waves, (unsigned)nch, (unsigned)T);
+
+  // Tuning knob (experiments only): SCOARY_PERMUTE_VARIANT=reg|c8x8|c8x16|c4x16|c8x4
+  const char* variant = std::getenv("SCOARY_PERMUTE_VARIANT");
+  const bool force_chunk = variant && variant[0] == 'c';
+  const bool use_reg = Qp <= kMaxRegQuads && !force_chunk && (Qp <= kAutoRegQuads || (variant && variant[0] == 'r'));
+  KernelTimer kt(h, s, "k_permute");
+  if (use_reg) {
+    switch (Qp) {
+#define CASE_RQ(RQ)                                                                          \
+  case RQ:                                                                                   \
+    launch_permute_reg<RQ, 1>(grid, s, d_tiled, d_perms, d_crit, (int)G, (int)Gp, P, pchunk, d_r); \
+    break;
+      CASE_RQ(1) CASE_RQ(2) CASE_RQ(4) CASE_RQ(6) CASE_RQ(8) CASE_RQ(12) CASE_RQ(16) CASE_RQ(20)
+      CASE_RQ(24) CASE_RQ(32) CASE_RQ(40) CASE_RQ(48)
+#undef CASE_RQ
+      default:
+        return fail(h, SCOARY_ERR_SIZE, "scoary_permute: unsupported tiled row size");
+    }
+  } else {
+    const uint4* t4 = reinterpret_cast<const uint4*>(d_tiled);
+    const uint2* c2 = reinterpret_cast<const uint2*>(d_crit);
+    const std::string v = variant ? variant : "";
+#define LAUNCH_CHUNK(CQ, PB)                                                                  \
+  hipLaunchKernelGGL((k_permute_chunked<CQ, PB>), grid, dim3(kWave), 0, s, t4, d_perms, c2, (int)G, \
+                     (int)Gp, (int)Qp, P, pchunk, d_r)
+    if (v == "c8x16" && Qp % 8 == 0) LAUNCH_CHUNK(8, 16);
+    else if (v == "c4x16" && Qp % 4 == 0) LAUNCH_CHUNK(4, 16);
+    else if (v == "c8x4" && Qp % 8 == 0) LAUNCH_CHUNK(8, 4);
+    else if (Qp % 8 == 0) LAUNCH_CHUNK(8, 8);
+    else if (Qp % 4 == 0) LAUNCH_CHUNK(4, 16);
+    else if (Qp % 2 == 0) LAUNCH_CHUNK(2, 16);
+    else LAUNCH_CHUNK(1, 16);
+#undef LAUNCH_CHUNK
+  }
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// scoary_common.hpp -- shared by the translation units of libscoary_hip.so: the
+// handle, error / timing helpers, layout constants and the Philox generator of
+// spec S4.  Everything here is internal; the contract is include/scoary_hip.h.
+#ifndef SCOARY_COMMON_HPP
+#define SCOARY_COMMON_HPP
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "scoary_hip.h"
+
+struct scoary_ctx {
+  int device = 0;
+  int num_cu = 256;
+  std::string err;
+  bool timing = false;
+  int lists_lds_optin = 0;   // k_permute_lists variants (by LG) with the 160 KB LDS opt-in done
+  struct Timed {
+    std::string name;
+    hipEvent_t start, stop;
+  };
+  std::vector<Timed> timed;
+};
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kGeneAlign = 256;
+constexpr double kTie = 1e-10;             // spec S3: relative tie window
+constexpr uint32_t kPermDomain = 0x53434F41u;  // "SCOA", spec S4
+
+// Row sizes (in quads of four 32-bit words) for which a gene row is held
+// entirely in VGPRs by k_permute_reg.
+constexpr int kRegQuads[] = {1, 2, 4, 6, 8, 12, 16, 20, 24, 32, 40, 48};
+constexpr int kMaxRegQuads = 48;
+constexpr int kAutoRegQuads = 24;  // longer rows: the chunked kernel wins (measured 1.39x at N=5000)
+constexpr int kChunkQuads = 8;  // k_permute_chunked: quads per register chunk
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+inline int64_t tiled_quads(int64_t N) {
+  int64_t q = (((N + 31) / 32) + 3) / 4;
+  if (q < 1) q = 1;
+  for (int r : kRegQuads)
+    if (r >= q) return r;
+  return round_up(q, kChunkQuads);
+}
+
+int fail(scoary_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(h, SCOARY_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// Sets the handle's device for the duration of a call and restores the
+// caller's (torch's) current device afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+struct KernelTimer {
+  scoary_handle h;
+  hipStream_t s;
+  hipEvent_t start = nullptr, stop = nullptr;
+  KernelTimer(scoary_handle h_, hipStream_t s_, const char* name) : h(h_), s(s_) {
+    if (!h->timing) return;
+    if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) {
+      start = stop = nullptr;
+      return;
+    }
+    (void)hipEventRecord(start, s);
+    h->timed.push_back({name, start, stop});
+  }
+  ~KernelTimer() {
+    if (stop) (void)hipEventRecord(stop, s);
+  }
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    // one 32x32->64 multiply per product (v_mad_u64_u32) instead of hi + lo
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+    const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
+    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0;
+    c1 = l1;
+    c2 = n2;
+    c3 = l0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0;
+  out[1] = c1;
+  out[2] = c2;
+  out[3] = c3;
+}
+
+// acc += popcount(x) as ONE v_bcnt_u32_b32 (its second operand is the
+// accumulator).  Opaque to the optimiser on purpose: left to itself LLVM
+// reassociates the accumulate chain into short chains joined by v_add3_u32,
+// ~15 % more VALU work in the permutation inner loop.
+__device__ __forceinline__ void bcnt_acc(uint32_t& acc, uint32_t x) {
+  asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+}
+
+}  // namespace
+#endif

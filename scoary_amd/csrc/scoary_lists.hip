@@ -1,0 +1,792 @@
+// scoary_lists.hip -- the list-driven permutation path: label tiles, minority-list
+// kernels and their C-ABI (scoary_perm_generate_tiles, scoary_permute_lists).
+#include "scoary_common.hpp"
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// a7 (list-driven variant): permutation exceedance counts from minority lists
+// ----------------------------------------------------------------------------
+// The dense kernel (k_permute_reg) pays 2 VALU ops per 32 isolates whatever the
+// gene looks like.  Here the roles are swapped: a gene is the ascending list of
+// isolates carrying its MINORITY value (scoary_lists_build), the permuted
+// labels are stored isolate-major in tiles of LG*32 permutations that live in
+// LDS, and a gene's overlap count with 32 permutations at once is a
+// bit-sliced ("vertical") counter: every listed isolate adds one LDS row word
+// into KC counter planes through v_bitop3 full adders (sum = a^b^c,
+// carry = maj(a,b,c)).  Cost ~3.5 VALU ops per listed isolate per 32
+// permutations instead of 2 ops per 32 isolates per permutation, i.e.
+// ~0.11 * |list| ops per test versus 0.0625 * N * 2: a gene present in 26 %
+// of 2000 isolates costs 57 ops per test instead of 137, a rare variant ~20x less.
+// A wavefront = 64/LG lane groups = 64/LG genes of similar list length.
+// LG = lanes (32-permutation words) per gene: 16 while a tile of 512
+// permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
+// N <= 5119, 4 (tiles of 128) up to N <= 10239.  One wavefront processes 64/LG
+// genes; the 32/LG lane groups of a 32-lane half read LDS in lockstep.
+// LDS row stride in dwords.  No padding: with a 16-dword stride a row starts at
+// bank 0 or 16 by the PARITY of its isolate index, and the list builder orders
+// the two genes that share a 32-lane half so that one walks its even rows while
+// the other walks its odd rows (scoary_lists_build) -- conflict-free except where
+// their even/odd counts differ.
+__host__ __device__ constexpr int list_lg(int64_t N) {
+  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : 0));
+}
+// index entries held per lane and step: LG = 16 spreads the 32 entries of a step
+// over the group's 16 lanes (row_newbcast); LG = 8 / 4 give every QUAD of the
+// group its own copy, 8 entries per lane (quad_perm broadcast)
+__host__ __device__ constexpr int list_epl(int LG) { return LG == 16 ? 2 : 8; }
+// dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
+__host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int LG) {
+  return ((N + 1) * LG + 3) / 4 * 4;
+}
+
+__device__ __forceinline__ uint32_t bit_xor3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t bit_maj(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe8" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// majority(~a, b, c): the borrow of a - b - c
+__device__ __forceinline__ uint32_t bit_majn(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x8e" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// Bit-sliced rejection-region test (spec S5) on KC counter planes: bit j of the
+// result = ((count_j - base) mod 2^KD) < span.  Three LUT ops per plane.
+template <int KC, int KD>
+__device__ __forceinline__ uint32_t region_lt(const uint32_t (&c)[16], uint32_t base,
+                                              uint32_t span) {
+  uint32_t borrow = 0u, lt = 0u;   // d = u - base ; lt = (d < span)
+#pragma unroll
+  for (int k = 0; k < KD; ++k) {
+    const uint32_t bk = (uint32_t)__builtin_amdgcn_sbfe((int)base, k, 1);   // 0 / ~0
+    const uint32_t sk = (uint32_t)__builtin_amdgcn_sbfe((int)span, k, 1);
+    uint32_t dk;
+    if (k < KC) {
+      dk = bit_xor3(c[k], bk, borrow);
+      borrow = bit_majn(c[k], bk, borrow);
+    } else {
+      dk = bk ^ borrow;
+      borrow |= bk;
+    }
+    lt = bit_majn(dk, sk, lt);
+  }
+  return lt;
+}
+// c += x + y at bit-plane weight 1: returns the carry (weight 2)
+__device__ __forceinline__ uint32_t full_add(uint32_t& c, uint32_t x, uint32_t y) {
+  const uint32_t carry = bit_maj(c, x, y);
+  c = bit_xor3(c, x, y);
+  return carry;
+}
+
+// Isolate-major label tiles: tiles[t][tile][row 0..N][LG] dwords, row N all
+// zero; dword j of a row = labels of permutations tile*LG*32 + 32j .. +31.
+// One wavefront generates 64 consecutive permutations (spec S4, same draws as
+// k_perm_generate) and transposes them with ballots.
+template <int LG>
+__global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __restrict__ masks,
+                                                            const int32_t* __restrict__ margins,
+                                                            int N, int Wp, int64_t P,
+                                                            int64_t perm_base, int trait_base,
+                                                            uint32_t k0, uint32_t k1, int ntiles,
+                                                            uint32_t* __restrict__ tiles) {
+  const int t = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int64_t wave = blockIdx.x;                    // 64 permutations each
+  const int64_t pl = wave * kWave + lane;
+  const bool live = pl < P;
+  const uint32_t pi = (uint32_t)(perm_base + pl);
+  const int waves_per_tile = LG / 2;
+  const int tile = (int)(wave / waves_per_tile);
+  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
+  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG) + col;
+  uint32_t needed = (uint32_t)margins[2 * t], remaining = (uint32_t)margins[2 * t + 1];
+  const uint32_t* mrow = masks + (int64_t)t * Wp;
+  const int nw = (N + 31) / 32;
+  uint64_t mine = 0;
+  for (int k = 0; k < nw; ++k) {
+    const uint32_t mw = mrow[k];
+#pragma unroll 2
+    for (int jj = 0; jj < 8; ++jj) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)(k * 8 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int bit = 4 * jj + q;
+        bool sel = false;
+        if ((mw >> bit) & 1u) {
+          if (__umulhi(r[q], remaining) < needed) {
+            sel = live;
+            --needed;
+          }
+          --remaining;
+        }
+        const uint64_t b = __ballot(sel);
+        const int iso = k * 32 + bit;
+        if ((iso & 63) == lane) mine = b;
+        if ((iso & 63) == 63 || iso == nw * 32 - 1) {  // 64 isolates collected: one row per lane
+          const int row = (iso & ~63) + lane;
+          if (row < N) {
+            base[(int64_t)row * LG] = (uint32_t)mine;
+            base[(int64_t)row * LG + 1] = (uint32_t)(mine >> 32);
+          }
+          mine = 0;
+        }
+      }
+    }
+  }
+  if (lane == 0) {  // the all-zero row that list padding points at
+    base[(int64_t)N * LG] = 0u;
+    base[(int64_t)N * LG + 1] = 0u;
+  }
+}
+
+// The same tiles from a workgroup per 64 permutations, for launches with fewer
+// wavefronts than the chip has SIMDs (few traits x permutations, long rows): the
+// sampling is serial over the isolates only in `needed` (two dependent VALU ops
+// per isolate) while the Philox draws are not, so kGenProducers wavefronts
+// compute the draws one 64-isolate chunk ahead into LDS (lane = permutation in
+// every wavefront) and ONE selection wavefront walks the chunk; its compare
+// mask over the 64 lanes IS the tile row of that isolate.
+constexpr int kGenProducers = 7;
+constexpr int kGenSplitBelow = 1;  // workgroup variant below this many wavefronts per SIMD
+constexpr int kGenChunk = 64;      // isolates per LDS buffer = 16 Philox counters
+// Philox counters (of the 16 per chunk) each producer wavefront computes.  A
+// workgroup's wavefronts go to the SIMDs cyclically, so wavefront 4 shares the
+// selection wavefront's SIMD and is given nothing.
+__constant__ const int8_t kGenWork[kGenProducers][3] = {
+    {0, 6, 12}, {1, 7, 13}, {2, 8, 14}, {-1, -1, -1}, {3, 9, 15}, {4, 10, -1}, {5, 11, -1}};
+
+// v[LANE] = value (wave-uniform); hipcc has no builtin for v_writelane_b32, and
+// its lane select must be an inline constant next to an SGPR value.
+template <int LANE>
+__device__ __forceinline__ void write_lane(uint32_t& v, uint32_t value) {
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(value), "n"(LANE));
+}
+// Spec-S4 selection for isolates II.. of a chunk: u = the lane's draws, rem0 =
+// valid isolates left at the chunk's start, mw = its validity bits (both
+// wave-uniform; ALLVALID: mw is all ones), livemask = lanes whose permutation exists.
+template <int II, bool ALLVALID>
+__device__ __forceinline__ void select_rows(const uint32_t (&u)[kGenChunk], uint32_t rem0,
+                                            uint64_t mw, uint64_t livemask, uint32_t& needed,
+                                            uint32_t& lo, uint32_t& hi) {
+  if constexpr (II < kGenChunk) {
+    uint64_t b = 0;
+    if (ALLVALID || ((mw >> II) & 1u)) {               // wave-uniform
+      const uint32_t rem =
+          ALLVALID ? rem0 - II : rem0 - (uint32_t)__popcll(mw & (((uint64_t)1 << II) - 1));
+      const bool hit = __umulhi(u[II], rem) < needed;
+      needed -= hit ? 1u : 0u;
+      b = __builtin_amdgcn_ballot_w64(hit) & livemask;
+    }
+    write_lane<II>(lo, (uint32_t)b);                 // lane l: the row of isolate l of the chunk
+    write_lane<II>(hi, (uint32_t)(b >> 32));
+    select_rows<II + 1, ALLVALID>(u, rem0, mw, livemask, needed, lo, hi);
+  }
+}
+
+template <int LG>
+__global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_tiles_wg(
+    const uint32_t* __restrict__ masks, const int32_t* __restrict__ margins, int N, int Wp,
+    int64_t P, int64_t perm_base, int trait_base, uint32_t k0, uint32_t k1, int ntiles,
+    uint32_t* __restrict__ tiles) {
+  __shared__ uint32_t draws[2][kGenChunk][kWave];
+  const int t = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1), role = threadIdx.x / kWave;   // 0: selection
+  const int64_t wave = blockIdx.x;                    // 64 permutations each
+  const int64_t pl = wave * kWave + lane;
+  const bool live = pl < P;
+  const uint32_t pi = (uint32_t)(perm_base + pl);
+  const int waves_per_tile = LG / 2;
+  const int tile = (int)(wave / waves_per_tile);
+  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
+  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG) + col;
+  uint32_t needed = (uint32_t)margins[2 * t];
+  uint32_t remaining = (uint32_t)__builtin_amdgcn_readfirstlane(margins[2 * t + 1]);
+  const uint32_t* mrow = masks + (int64_t)t * Wp;     // Wp >= 2*nchunks words, zero padded
+  const int nchunks = (N + kGenChunk - 1) / kGenChunk;
+  const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
+  if (role == 0) __builtin_amdgcn_s_setprio(3);       // the serial wavefront goes first
+  for (int c = 0; c <= nchunks; ++c) {
+    if (role > 0) {
+      if (c < nchunks) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int jj = kGenWork[role - 1][k];
+          if (jj < 0) break;
+          uint32_t r[4];
+          philox4x32_10((uint32_t)(c * (kGenChunk / 4) + jj), pi, (uint32_t)(trait_base + t),
+                        kPermDomain, k0, k1, r);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) draws[c & 1][4 * jj + q][lane] = r[q];
+        }
+      }
+    } else if (c > 0) {
+      const int cc = c - 1;
+      const uint64_t mw = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * cc]) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * cc + 1]) << 32;
+      const uint32_t rem0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)remaining);
+      uint32_t u[kGenChunk];
+#pragma unroll
+      for (int ii = 0; ii < kGenChunk; ++ii) u[ii] = draws[cc & 1][ii][lane];
+      uint32_t lo = 0u, hi = 0u;
+      if (mw == ~(uint64_t)0)
+        select_rows<0, true>(u, rem0, mw, livemask, needed, lo, hi);
+      else
+        select_rows<0, false>(u, rem0, mw, livemask, needed, lo, hi);
+      remaining -= (uint32_t)__popcll(mw);
+      const int row = cc * kGenChunk + lane;
+      if (row < N) {
+        base[(int64_t)row * LG] = lo;
+        base[(int64_t)row * LG + 1] = hi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {  // the all-zero row that list padding points at
+    base[(int64_t)N * LG] = 0u;
+    base[(int64_t)N * LG + 1] = 0u;
+  }
+}
+
+// Per (trait, list slot): the rejection region in terms of the LIST count u
+// (u = a for a ones-list, npos - a for a zeros-list), modulo M = 2^KD:
+//   in region  <=>  always | ((((u - base) mod M) >= span) ^ invert)
+// out[t][slot] = { base, span | invert << 30 | always << 31 }.
+__global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ crit,
+                                                    const int32_t* __restrict__ margins,
+                                                    const int32_t* __restrict__ order,
+                                                    const uint8_t* __restrict__ flipped, int G,
+                                                    int KD, uint2* __restrict__ out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (k >= G) return;
+  const int g = order[k];
+  const uint2 c = crit[(int64_t)t * G + g];
+  const uint32_t M = 1u << KD;
+  uint2 o;
+  if (c.y == 0u) {
+    o = make_uint2(0u, 1u << 31);
+  } else if (!flipped[g]) {
+    o = make_uint2(c.x & (M - 1), c.y);
+  } else {
+    const uint32_t npos = (uint32_t)margins[2 * t];
+    o = make_uint2((npos - c.x + 1u) & (M - 1), (M - c.y) | (1u << 30));
+  }
+  out[(int64_t)t * G + k] = o;
+}
+
+// Entry J (0..31) of a gene's 32-entry index vector -> every lane of its group,
+// plus the lane's column offset, as ONE v_add_u32_dpp:
+//   LG = 16: a DPP row is a group; entries sit two per lane -> row_newbcast:J/2
+//   LG < 16: every quad of the group holds all 32 entries, eight per lane
+//            -> quad_perm:[s,s,s,s] with s = J/8
+template <int LG, int J>
+__device__ __forceinline__ uint32_t entry_addr(const uint32_t (&e)[list_epl(LG)], uint32_t col4) {
+  constexpr int EPL = list_epl(LG);
+  const int v = (int)e[J % EPL];
+  if constexpr (LG == 16) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x150 + J / EPL, 0xf, 0xf, false) + col4;
+  } else {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, v, (J / EPL) * 0x55, 0xf, 0xf, false) + col4;
+  }
+}
+__device__ __forceinline__ uint32_t lds_at(const uint32_t* lds, uint32_t byte_off) {
+  return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + byte_off);
+}
+
+// Issue the 8 LDS reads of entries 8J..8J+7 into x[8J..8J+7].
+template <int LG, int J>
+__device__ __forceinline__ void read8(uint32_t (&x)[32], const uint32_t* __restrict__ lds,
+                                      const uint32_t (&e)[list_epl(LG)], uint32_t col4) {
+  x[8 * J + 0] = lds_at(lds, entry_addr<LG, 8 * J + 0>(e, col4));
+  x[8 * J + 1] = lds_at(lds, entry_addr<LG, 8 * J + 1>(e, col4));
+  x[8 * J + 2] = lds_at(lds, entry_addr<LG, 8 * J + 2>(e, col4));
+  x[8 * J + 3] = lds_at(lds, entry_addr<LG, 8 * J + 3>(e, col4));
+  x[8 * J + 4] = lds_at(lds, entry_addr<LG, 8 * J + 4>(e, col4));
+  x[8 * J + 5] = lds_at(lds, entry_addr<LG, 8 * J + 5>(e, col4));
+  x[8 * J + 6] = lds_at(lds, entry_addr<LG, 8 * J + 6>(e, col4));
+  x[8 * J + 7] = lds_at(lds, entry_addr<LG, 8 * J + 7>(e, col4));
+}
+// 8 row words -> counter planes 0..2, returns the carry of weight 8
+__device__ __forceinline__ uint32_t sum8(uint32_t (&c)[16], const uint32_t* x) {
+  const uint32_t a1 = full_add(c[0], x[0], x[1]);
+  const uint32_t a2 = full_add(c[0], x[2], x[3]);
+  const uint32_t b1 = full_add(c[1], a1, a2);
+  const uint32_t a3 = full_add(c[0], x[4], x[5]);
+  const uint32_t a4 = full_add(c[0], x[6], x[7]);
+  const uint32_t b2 = full_add(c[1], a3, a4);
+  return full_add(c[2], b1, b2);
+}
+
+template <int LG, int KC, int KD>
+__global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
+                                                        const uint32_t* __restrict__ lidx,
+                                                        const int32_t* __restrict__ lstart,
+                                                        const int32_t* __restrict__ lngroups,
+                                                        const int32_t* __restrict__ lorder,
+                                                        const uint2* __restrict__ lcrit, int G,
+                                                        int N, int64_t P, int ntiles,
+                                                        int quads_per_block,
+                                                        uint32_t* __restrict__ r) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
+  // blockIdx.x = (trait, tile) fastest, blockIdx.y = gene chunk: the blocks that
+  // run together walk the SAME chunk of index lists against different label
+  // tiles, so the lists stream from HBM once and are re-read from L2.
+  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int lg = lane / LG, col = lane % LG;
+  constexpr int GPW = kWave / LG;   // genes per wavefront
+  constexpr int EPL = list_epl(LG); // index entries per lane and step
+  constexpr int LPS = 32 / EPL;     // lanes that together hold one step's 32 entries
+
+  // tile -> LDS (contiguous copy, 16 B per lane)
+  const int tile_dwords = (N + 1) * LG;
+  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG);
+  {
+    const uint4* src4 = reinterpret_cast<const uint4*>(src);   // tiles are 16-B aligned per tile
+    uint4* dst4 = reinterpret_cast<uint4*>(tile_lds);
+    const int n4 = tile_dwords / 4;
+    for (int i = tid; i < n4; i += blockDim.x) dst4[i] = src4[i];
+    for (int i = n4 * 4 + tid; i < tile_dwords; i += blockDim.x) tile_lds[i] = src[i];
+  }
+  __syncthreads();
+
+  // permutations of this lane's word that exist (the last tile may be ragged)
+  const int64_t p_first = ((int64_t)tile * LG + col) * 32;
+  const uint32_t valid = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
+
+  const int nquads = (G + GPW - 1) / GPW;
+  const int q_lo = blockIdx.y * quads_per_block;
+  const int q_hi = min(nquads, q_lo + quads_per_block);
+  for (int q = q_lo + wave; q < q_hi; q += nwaves) {
+    const int slot = min(q * GPW + lg, G - 1);
+    const bool have = q * GPW + lg < G;
+    // every gene of a quad has the same (padded) number of 32-entry groups
+    const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);
+    // 32 list entries (byte offsets of LDS rows) per step, EPL per lane: the
+    // group's 16 lanes (LG = 16) or each of its quads (LG < 16) hold all 32
+    struct alignas(EPL == 2 ? 8 : 16) Ent { uint32_t e[EPL]; };
+    const Ent* lp = reinterpret_cast<const Ent*>(lidx) + (int64_t)lstart[slot] * LPS +
+                    (LG == 16 ? col : (lane & 3));
+    const uint32_t col4 = (uint32_t)col * 4u;
+
+    uint32_t c[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = 0u;
+    auto read32 = [&](uint32_t (&x)[32], const Ent& ix) {
+      read8<LG, 0>(x, tile_lds, ix.e, col4);
+      read8<LG, 1>(x, tile_lds, ix.e, col4);
+      read8<LG, 2>(x, tile_lds, ix.e, col4);
+      read8<LG, 3>(x, tile_lds, ix.e, col4);
+    };
+    auto sum32 = [&](const uint32_t (&x)[32]) -> uint32_t {
+      const uint32_t cA = sum8(c, x);
+      const uint32_t cB = sum8(c, x + 8);
+      const uint32_t e1 = full_add(c[3], cA, cB);               // weight 16
+      const uint32_t cC = sum8(c, x + 16);
+      const uint32_t cD = sum8(c, x + 24);
+      const uint32_t e2 = full_add(c[3], cC, cD);
+      return full_add(c[4], e1, e2);                            // weight 32
+    };
+    // Software pipeline: index vectors are fetched four steps ahead (2 VGPRs per
+    // step), the 32 LDS row reads of step s+1 are in flight while step s is summed.
+    const int last = max(nsuper - 1, 0);
+    Ent b0 = lp[0], b1 = lp[(int64_t)min(1, last) * LPS], b2 = lp[(int64_t)min(2, last) * LPS],
+        b3 = lp[(int64_t)min(3, last) * LPS];
+    uint32_t xa[32], xb[32];
+    if (nsuper > 0) read32(xa, b0);
+    for (int sg = 0; sg < nsuper; sg += 4) {
+      // four steps (128 rows) per trip; their weight-32 carries are paired up
+      // the tree before the (short) half-adder ripple
+      uint32_t f1 = 0u, f2 = 0u, f3 = 0u;
+      b0 = lp[(int64_t)min(sg + 4, last) * LPS];
+      if (sg + 1 < nsuper) read32(xb, b1);
+      const uint32_t f0 = sum32(xa);
+      b1 = lp[(int64_t)min(sg + 5, last) * LPS];
+      if (sg + 2 < nsuper) read32(xa, b2);
+      if (sg + 1 < nsuper) f1 = sum32(xb);
+      b2 = lp[(int64_t)min(sg + 6, last) * LPS];
+      if (sg + 3 < nsuper) read32(xb, b3);
+      if (sg + 2 < nsuper) f2 = sum32(xa);
+      b3 = lp[(int64_t)min(sg + 7, last) * LPS];
+      if (sg + 4 < nsuper) read32(xa, b0);
+      if (sg + 3 < nsuper) f3 = sum32(xb);
+      const uint32_t g0 = full_add(c[5], f0, f1);               // weight 64
+      const uint32_t g1 = full_add(c[5], f2, f3);
+      uint32_t carry = full_add(c[6], g0, g1);                  // weight 128
+#pragma unroll
+      for (int k = 7; k < KC; ++k) {                            // ripple (half adders)
+        const uint32_t nc = c[k] & carry;
+        c[k] ^= carry;
+        carry = nc;
+      }
+    }
+    // region test, bit-sliced against this lane group's constants
+    const uint2 cr = lcrit[(int64_t)t * G + slot];
+    const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
+    const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
+    const uint32_t always = (cr.y >> 31) ? 0xffffffffu : 0u;
+    const uint32_t lt = region_lt<KC, KD>(c, base, span);
+    uint32_t ex = ((~lt) ^ inv) | always;
+    ex &= valid;
+    int cnt = have ? __popc(ex) : 0;
+#pragma unroll
+    for (int off = LG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (have && col == 0 && cnt) atomicAdd(&r[(int64_t)t * G + lorder[slot]], (uint32_t)cnt);
+  }
+}
+
+
+
+// 128 permutations per lane: 4 lanes per gene read the 16-dword tile rows with
+// ds_read_b128, 16 genes per wavefront.  One address add serves four words
+// (~2.2 VALU ops per listed isolate and 32 permutations).  ds_read_b128 is served
+// in the lane groups {0-3,12-15,20-27} ...: with slot k starting at residue
+// class k mod 4 (scoary_lists_build) each group's four genes sit on distinct
+// 64-byte bank slots.
+__device__ __forceinline__ uint4 lds128_at(const uint32_t* lds, uint32_t byte_off) {
+  return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds) + byte_off);
+}
+struct Rows4 { uint32_t w0[4], w1[4], w2[4], w3[4]; };   // 4 tile rows x 4 permutation words
+// The 4 entries held by lane H of every LPG-lane gene group -> 4 ds_read_b128.
+template <int LPG, int H>
+__device__ __forceinline__ void read4x4(Rows4& x, const uint32_t* __restrict__ lds,
+                                        const uint32_t (&e)[4], uint32_t colb) {
+  // quad_perm broadcast of lane H of the group: [H,H,H,H] or [H,H,2+H,2+H]
+  constexpr int kCtrl = LPG == 4 ? H * 0x55 : 0xA0 + H * 0x55;
+#define RD(J)                                                                                      \
+  {                                                                                                \
+    uint32_t a;                                                                                    \
+    if constexpr (LPG == 1)                                                                        \
+      a = e[J];                                                                                    \
+    else                                                                                           \
+      a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e[J], kCtrl, 0xf, 0xf, false) + colb;      \
+    const uint4 v = lds128_at(lds, a);                                                             \
+    x.w0[J] = v.x;                                                                                 \
+    x.w1[J] = v.y;                                                                                 \
+    x.w2[J] = v.z;                                                                                 \
+    x.w3[J] = v.w;                                                                                 \
+  }
+  RD(0) RD(1) RD(2) RD(3)
+#undef RD
+}
+// 4 row words -> counter planes 0..1, returns the carry of weight 4
+__device__ __forceinline__ uint32_t sum4(uint32_t (&c)[16], const uint32_t (&x)[4]) {
+  const uint32_t a1 = full_add(c[0], x[0], x[1]);
+  const uint32_t a2 = full_add(c[0], x[2], x[3]);
+  return full_add(c[1], a1, a2);
+}
+struct Carry4 { uint32_t w[4]; };
+
+// LPG lanes per gene (4, 2, 1 for 16-, 8-, 4-dword tile rows), 64/LPG genes per
+// wavefront.  Lists are walked in sub-steps of 4 entries: lane j of a gene group
+// holds entries 4j..4j+3 of each 4*LPG-entry piece.
+template <int LPG, int KC, int KD>
+__global__ __launch_bounds__(1024) void k_permute_lists128(const uint32_t* __restrict__ tiles,
+                                                           const uint32_t* __restrict__ lidx,
+                                                           const int32_t* __restrict__ lstart,
+                                                           const int32_t* __restrict__ lngroups,
+                                                           const int32_t* __restrict__ lorder,
+                                                           const uint2* __restrict__ lcrit, int G,
+                                                           int N, int64_t P, int ntiles,
+                                                           int quads_per_block,
+                                                           uint32_t* __restrict__ r) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
+  constexpr int TW = 4 * LPG;        // tile row, dwords
+  constexpr int GPW = kWave / LPG;   // genes per wavefront
+  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int lg = lane / LPG, col = lane % LPG;
+
+  const int tile_dwords = (N + 1) * TW;
+  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW);
+  {
+    const uint4* src4 = reinterpret_cast<const uint4*>(src);
+    uint4* dst4 = reinterpret_cast<uint4*>(tile_lds);
+    const int n4 = tile_dwords / 4;
+    for (int i = tid; i < n4; i += blockDim.x) dst4[i] = src4[i];
+  }
+  __syncthreads();
+
+  uint32_t valid[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int64_t p_first = ((int64_t)tile * TW + 4 * col + w) * 32;
+    valid[w] = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
+  }
+
+  const int nquads = (G + GPW - 1) / GPW;
+  const int q_lo = blockIdx.y * quads_per_block;
+  const int q_hi = min(nquads, q_lo + quads_per_block);
+  for (int q = q_lo + wave; q < q_hi; q += nwaves) {
+    const int slot = min(q * GPW + lg, G - 1);
+    const bool have = q * GPW + lg < G;
+    const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);   // 32-entry steps
+    // interleaved lists (piece = TW entries): the wavefront's 64 lanes read 64
+    // consecutive 16-byte index vectors per piece
+    struct alignas(16) Ent { uint32_t e[4]; };
+    const Ent* lp = reinterpret_cast<const Ent*>(lidx) +
+                    (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 8 + lane;
+    const uint32_t colb = (uint32_t)col * 16u;
+
+    uint32_t c0[16], c1[16], c2[16], c3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c0[k] = c1[k] = c2[k] = c3[k] = 0u;
+    Rows4 xa, xb;
+    auto s4 = [&](const Rows4& x) -> Carry4 {
+      Carry4 b;
+      b.w[0] = sum4(c0, x.w0);
+      b.w[1] = sum4(c1, x.w1);
+      b.w[2] = sum4(c2, x.w2);
+      b.w[3] = sum4(c3, x.w3);
+      return b;
+    };
+    auto fa = [&](int plane, const Carry4& a, const Carry4& b) -> Carry4 {
+      Carry4 o;
+      o.w[0] = full_add(c0[plane], a.w[0], b.w[0]);
+      o.w[1] = full_add(c1[plane], a.w[1], b.w[1]);
+      o.w[2] = full_add(c2[plane], a.w[2], b.w[2]);
+      o.w[3] = full_add(c3[plane], a.w[3], b.w[3]);
+      return o;
+    };
+    // pieces of 4*LPG entries; the index loads run three pieces ahead.  Reads past
+    // the end of the list re-read its last piece (valid rows, never summed).
+    const int last = max(nsuper * (8 / LPG) - 1, 0);
+    int piece = 0;
+    Ent cur = lp[0], nxt = lp[(int64_t)min(1, last) * kWave], nn = lp[(int64_t)min(2, last) * kWave];
+    read4x4<LPG, 0>(xa, tile_lds, cur.e, colb);
+    // sub-step S of a step: issue the reads of sub-step S+1 into `other`, sum `mine`
+#define SUBSTEP(S, MINE, OTHER)                                        \
+  [&]() -> Carry4 {                                                    \
+    constexpr int Hn = ((S) + 1) % LPG;                                \
+    if constexpr (Hn == 0) {                                           \
+      cur = nxt;                                                       \
+      nxt = nn;                                                        \
+      ++piece;                                                         \
+      nn = lp[(int64_t)min(piece + 2, last) * kWave];                  \
+    }                                                                  \
+    read4x4<LPG, Hn>(OTHER, tile_lds, cur.e, colb);                    \
+    return s4(MINE);                                                   \
+  }()
+    for (int sg = 0; sg < nsuper; sg += 4) {
+      const Carry4 zero = {{0u, 0u, 0u, 0u}};
+      auto step = [&](int k) -> Carry4 {                    // 32 listed isolates
+        if (sg + k >= nsuper) return zero;
+        const Carry4 b0 = SUBSTEP(0, xa, xb);
+        const Carry4 b1 = SUBSTEP(1, xb, xa);
+        const Carry4 d0 = fa(2, b0, b1);
+        const Carry4 b2 = SUBSTEP(2, xa, xb);
+        const Carry4 b3 = SUBSTEP(3, xb, xa);
+        const Carry4 d1 = fa(2, b2, b3);
+        const Carry4 e0 = fa(3, d0, d1);
+        const Carry4 b4 = SUBSTEP(4, xa, xb);
+        const Carry4 b5 = SUBSTEP(5, xb, xa);
+        const Carry4 d2 = fa(2, b4, b5);
+        const Carry4 b6 = SUBSTEP(6, xa, xb);
+        const Carry4 b7 = SUBSTEP(7, xb, xa);
+        const Carry4 d3 = fa(2, b6, b7);
+        const Carry4 e1 = fa(3, d2, d3);
+        return fa(4, e0, e1);                               // weight 32
+      };
+      const Carry4 f0 = step(0), f1 = step(1);
+      const Carry4 g0 = fa(5, f0, f1);
+      const Carry4 f2 = step(2), f3 = step(3);
+      const Carry4 g1 = fa(5, f2, f3);
+      Carry4 carry = fa(6, g0, g1);
+#pragma unroll
+      for (int k = 7; k < KC; ++k) {
+#define RIPPLE(C, W)                         \
+  {                                          \
+    const uint32_t nc = C[k] & carry.w[W];   \
+    C[k] ^= carry.w[W];                      \
+    carry.w[W] = nc;                         \
+  }
+        RIPPLE(c0, 0) RIPPLE(c1, 1) RIPPLE(c2, 2) RIPPLE(c3, 3)
+#undef RIPPLE
+      }
+    }
+#undef SUBSTEP
+    const uint2 cr = lcrit[(int64_t)t * G + slot];
+    const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
+    const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
+    const uint32_t always = (cr.y >> 31) ? 0xffffffffu : 0u;
+    int cnt = 0;
+    cnt += __popc((((~region_lt<KC, KD>(c0, base, span)) ^ inv) | always) & valid[0]);
+    cnt += __popc((((~region_lt<KC, KD>(c1, base, span)) ^ inv) | always) & valid[1]);
+    cnt += __popc((((~region_lt<KC, KD>(c2, base, span)) ^ inv) | always) & valid[2]);
+    cnt += __popc((((~region_lt<KC, KD>(c3, base, span)) ^ inv) | always) & valid[3]);
+    if (!have) cnt = 0;
+#pragma unroll
+    for (int off = LPG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (have && col == 0 && cnt) atomicAdd(&r[(int64_t)t * G + lorder[slot]], (uint32_t)cnt);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
+  const int LG = list_lg(N);
+  if (!LG) return 0;
+  const int64_t tile_perms = LG * 32;
+  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
+  return T * ntiles * list_tile_dwords(N, LG);
+}
+int64_t scoary_list_tile_words(int64_t N) { return list_lg(N) ? list_tile_dwords(N, list_lg(N)) : 0; }
+int64_t scoary_list_max_isolates(void) { return 10239; }
+// Words (32 permutations each) per lane: 4 = k_permute_lists128 (the default), 1 =
+// k_permute_lists, the ds_read_b32 kernel it replaced, kept for A/B measurements
+// and selected with SCOARY_LISTS_WPL=1 in the environment.
+static int lists_wpl(int64_t) {
+  const char* e = std::getenv("SCOARY_LISTS_WPL");
+  return e && e[0] == '1' && !e[1] ? 1 : 4;
+}
+int scoary_list_params(int64_t N, int64_t* out5) {
+  if (!out5) return SCOARY_ERR_ARG;
+  const int LG = list_lg(N);
+  const int wpl = lists_wpl(N);
+  out5[0] = LG;                            /* tile row width in dwords (0: N too large for LDS tiles) */
+  out5[1] = LG * 4;                        /* LDS / tile row stride in bytes */
+  out5[2] = LG ? kWave / LG * wpl : 0;     /* genes per wavefront: lists padded to equal length */
+  out5[3] = LG ? (wpl == 4 ? 64 : 32) / LG : 0;   /* residue classes of the isolate index:
+                                              ds_read_b128 is banked over 256 B, ds_read_b32 over 128 B */
+  out5[4] = LG && wpl == 4 ? LG : 0;       /* interleave piece, entries (0: contiguous lists) */
+  return LG ? SCOARY_OK : SCOARY_ERR_SIZE;
+}
+
+int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
+                               int64_t T, int64_t N, int64_t P, int64_t perm_base,
+                               int64_t trait_base, uint64_t seed, uint32_t* d_tiles,
+                               scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_masks || !d_margins || !d_tiles || T < 1 || N < 1 || P < 1 || perm_base < 0 || trait_base < 0)
+    return fail(h, SCOARY_ERR_ARG, "scoary_perm_generate_tiles: bad argument");
+  if (T > 65535 || perm_base + P > 0xffffffffLL)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: T > 65535 or permutation index >= 2^32");
+  const int LG = list_lg(N);
+  if (!LG) return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: N too large for LDS tiles");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t tile_perms = LG * 32;
+  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
+  const dim3 grid((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T);
+  KernelTimer kt(h, s, "k_perm_generate_tiles");
+  // one wavefront per 64 permutations when there are enough of them to fill the
+  // chip; otherwise a workgroup each, with the Philox draws spread over more lanes
+  const bool wg = (int64_t)grid.x * grid.y < (int64_t)h->num_cu * 4 * kGenSplitBelow;
+#define GEN_TILES(LGV)                                                                            \
+  if (wg)                                                                                         \
+    hipLaunchKernelGGL((k_perm_generate_tiles_wg<LGV>), grid, dim3(kWave * (1 + kGenProducers)),  \
+                       0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P, perm_base,  \
+                       (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles,      \
+                       d_tiles);                                                                  \
+  else                                                                                            \
+    hipLaunchKernelGGL((k_perm_generate_tiles<LGV>), grid, dim3(kWave), 0, s, d_masks, d_margins, \
+                       (int)N, (int)scoary_row_words(N), P, perm_base, (int)trait_base,           \
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
+  if (LG == 16) { GEN_TILES(16); } else if (LG == 8) { GEN_TILES(8); } else { GEN_TILES(4); }
+#undef GEN_TILES
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+extern "C++" {
+template <int LG, int KC, int KD, int WPL = 1>
+static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* d_tiles,
+                                const uint32_t* d_lidx, const int32_t* d_lstart,
+                                const int32_t* d_lngroups, const int32_t* d_lorder,
+                                const uint8_t* d_lflipped, const uint32_t* d_crit,
+                                const int32_t* d_margins, uint32_t* d_lcrit, int64_t G, int64_t T,
+                                int64_t N, int64_t P, uint32_t* d_r) {
+  {
+    KernelTimer kt(h, s, "k_lists_crit");
+    hipLaunchKernelGGL(k_lists_crit, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                       reinterpret_cast<const uint2*>(d_crit), d_margins, d_lorder, d_lflipped,
+                       (int)G, KD, reinterpret_cast<uint2*>(d_lcrit));
+  }
+  const int64_t tile_perms = LG * 32;
+  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
+  constexpr int GPW = kWave / LG * WPL;
+  const int64_t nquads = (G + GPW - 1) / GPW;
+  // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index
+  // lists (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the
+  // chunk run; each chunk a multiple of 16 wave-groups
+  int64_t chunks = ((int64_t)h->num_cu * 16 + ntiles * T - 1) / (ntiles * T);
+  const int64_t by_l2 = (G * N / 4 * 4 + (2 << 20) - 1) / (2 << 20);   // ~N/4 entries x 4 B per gene
+  if (chunks < by_l2) chunks = by_l2;
+  if (chunks > 65535) chunks = 65535;
+  if (chunks < 1) chunks = 1;
+  int64_t qpb = (nquads + chunks - 1) / chunks;
+  qpb = (qpb + 15) / 16 * 16;
+  chunks = (nquads + qpb - 1) / qpb;
+  const size_t lds = (size_t)(N + 1) * LG * sizeof(uint32_t);
+  constexpr int kFlag = WPL == 4 ? 64 * LG : LG;
+  const void* fn;
+  if constexpr (WPL == 4) fn = reinterpret_cast<const void*>(&k_permute_lists128<LG / 4, KC, KD>);
+  else fn = reinterpret_cast<const void*>(&k_permute_lists<LG, KC, KD>);
+  if (!(h->lists_lds_optin & kFlag)) {   // once per handle (= per device) and kernel variant
+    HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    h->lists_lds_optin |= kFlag;
+  }
+  KernelTimer kt(h, s, "k_permute_lists");
+  const dim3 grid((unsigned)(ntiles * T), (unsigned)chunks);
+  const uint2* lcrit2 = reinterpret_cast<const uint2*>(d_lcrit);
+  if constexpr (WPL == 4)
+    hipLaunchKernelGGL((k_permute_lists128<LG / 4, KC, KD>), grid, dim3(1024), lds, s, d_tiles, d_lidx,
+                       d_lstart, d_lngroups, d_lorder, lcrit2, (int)G, (int)N, P, (int)ntiles,
+                       (int)qpb, d_r);
+  else
+    hipLaunchKernelGGL((k_permute_lists<LG, KC, KD>), grid, dim3(1024), lds, s, d_tiles, d_lidx,
+                       d_lstart, d_lngroups, d_lorder, lcrit2, (int)G, (int)N, P, (int)ntiles,
+                       (int)qpb, d_r);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+}  // extern "C++"
+
+int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_t* d_lidx,
+                         const int32_t* d_lstart, const int32_t* d_lngroups,
+                         const int32_t* d_lorder, const uint8_t* d_lflipped,
+                         const uint32_t* d_crit, const int32_t* d_margins, uint32_t* d_lcrit,
+                         int64_t G, int64_t T, int64_t N, int64_t P, uint32_t* d_r,
+                         scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiles || !d_lidx || !d_lstart || !d_lngroups || !d_lorder || !d_lflipped || !d_crit ||
+      !d_margins || !d_lcrit || !d_r || G < 1 || T < 1 || N < 1 || P < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_permute_lists: bad argument");
+  const int LG = list_lg(N);
+  if (!LG)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: label tile does not fit in LDS for this N");
+  if (T > 65535) return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: T > 65535");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // counter planes KC: lists hold <= N/2 entries; compare planes KD: 2N+3 <= 2^KD
+  const int wpl = lists_wpl(N);
+  if (LG == 16 && wpl == 4)
+    return launch_permute_lists<16, 11, 13, 4>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                               d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  if (LG == 16)
+    return launch_permute_lists<16, 11, 13>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                            d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  if (LG == 8 && wpl == 4)
+    return launch_permute_lists<8, 12, 14, 4>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                              d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  if (LG == 4 && wpl == 4)
+    return launch_permute_lists<4, 13, 15, 4>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                              d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  if (LG == 8)
+    return launch_permute_lists<8, 12, 14>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                           d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  return launch_permute_lists<4, 13, 15>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                         d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+}
+
+}  // extern "C"

@@ -1,7 +1,7 @@
 """Device-side association engine: thin Python over the C-ABI.
 
 PyTorch-ROCm is used for device memory and streams only; every computation of
-the hot path happens in libscoary_hip.so (scoary_amd/csrc/scoary_hip.hip).
+the hot path happens in libscoary_hip.so (scoary_amd/csrc/scoary_*.hip).
 """
 import ctypes
 

@@ -275,6 +275,8 @@ def test_headline_config_properties(eng, orc):
       * a gene's complement has the same p and the same r (the test is
         symmetric under relabelling present/absent);
       * duplicated genes get identical results (idempotence across lanes);
+      * the list-driven kernel (the bench default) and the dense kernel give the
+        same r for all 500 000 (gene, trait) pairs;
       * a subsample of genes is checked bit-exactly against the oracle."""
     from scoary_amd import synth
     genes, traits, P_full, seed = synth.make_config("cfg3")
@@ -284,8 +286,14 @@ def test_headline_config_properties(eng, orc):
     genes[101] = genes[100]                 # duplicate
     genes[103] = 1 - genes[102]             # complement
     tb, mb = _bits(eng, traits)
-    res = eng.associate(eng.pack_dense(genes), eng.vecrows(tb, N), eng.vecrows(mb, N),
-                        permutations=P, seed=seed)
+    from scoary_amd.engine import pack_bits_rows
+    gm = eng.pack_dense(genes)
+    res = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=seed,
+                        use_lists=False)
+    eng.build_lists(gm, pack_bits_rows(genes))
+    res_l = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=seed,
+                          use_lists=True)
+    assert np.array_equal(res_l["r"].cpu().numpy(), res["r"].cpu().numpy())
     counts = res["counts"].cpu().numpy()
     r = res["r"].cpu().numpy().view(np.uint32)
     p = res["p"].cpu().numpy()
