@@ -64,7 +64,7 @@ def test_no_gpu_means_loud_failure():
 def test_product_package_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "scoary_amd")):
         for fn in files:
-            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+            if fn.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 with open(os.path.join(dirpath, fn)) as f:
                     src = f.read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
