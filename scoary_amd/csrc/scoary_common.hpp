@@ -20,7 +20,7 @@ struct scoary_ctx {
   int num_cu = 256;
   std::string err;
   bool timing = false;
-  int lists_lds_optin = 0;   // k_permute_lists variants (by LG) with the 160 KB LDS opt-in done
+  int lists_lds_optin = 0;   // k_permute_lists instances (by tile width) with the 160 KB LDS opt-in done
   struct Timed {
     std::string name;
     hipEvent_t start, stop;

@@ -8,33 +8,24 @@ namespace {
 // a7 (list-driven variant): permutation exceedance counts from minority lists
 // ----------------------------------------------------------------------------
 // The dense kernel (k_permute_reg) pays 2 VALU ops per 32 isolates whatever the
-// gene looks like.  Here the roles are swapped: a gene is the ascending list of
-// isolates carrying its MINORITY value (scoary_lists_build), the permuted
-// labels are stored isolate-major in tiles of LG*32 permutations that live in
-// LDS, and a gene's overlap count with 32 permutations at once is a
-// bit-sliced ("vertical") counter: every listed isolate adds one LDS row word
-// into KC counter planes through v_bitop3 full adders (sum = a^b^c,
-// carry = maj(a,b,c)).  Cost ~3.5 VALU ops per listed isolate per 32
-// permutations instead of 2 ops per 32 isolates per permutation, i.e.
-// ~0.11 * |list| ops per test versus 0.0625 * N * 2: a gene present in 26 %
-// of 2000 isolates costs 57 ops per test instead of 137, a rare variant ~20x less.
-// A wavefront = 64/LG lane groups = 64/LG genes of similar list length.
-// LG = lanes (32-permutation words) per gene: 16 while a tile of 512
+// gene looks like.  Here the roles are swapped: a gene is the list of isolates
+// carrying its MINORITY value (scoary_lists_build), the permuted labels are
+// stored isolate-major in tiles of TW*32 permutations that live in LDS, and a
+// gene's overlap count with 32 permutations at once is a bit-sliced
+// ("vertical") counter: every listed isolate adds one LDS row word into KC
+// counter planes through v_bitop3 full adders (sum = a^b^c, carry = maj(a,b,c)).
+// A lane handles 128 permutations (one ds_read_b128 per listed isolate), so the
+// cost is ~2.2 VALU ops per listed isolate per 32 permutations instead of 2 ops
+// per 32 isolates per permutation: a gene present in 26 % of 2000 isolates
+// costs 41 ops per test instead of 137, a rare variant ~20x less.
+//
+// TW = tile row width in dwords (32 permutations each): 16 while a tile of 512
 // permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
-// N <= 5119, 4 (tiles of 128) up to N <= 10239.  One wavefront processes 64/LG
-// genes; the 32/LG lane groups of a 32-lane half read LDS in lockstep.
-// LDS row stride in dwords.  No padding: with a 16-dword stride a row starts at
-// bank 0 or 16 by the PARITY of its isolate index, and the list builder orders
-// the two genes that share a 32-lane half so that one walks its even rows while
-// the other walks its odd rows (scoary_lists_build) -- conflict-free except where
-// their even/odd counts differ.
+// N <= 5119, 4 (tiles of 128) up to N <= 10239.  A gene takes TW/4 lanes and a
+// wavefront 256/TW genes of similar list length.
 __host__ __device__ constexpr int list_lg(int64_t N) {
   return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : 0));
 }
-// index entries held per lane and step: LG = 16 spreads the 32 entries of a step
-// over the group's 16 lanes (row_newbcast); LG = 8 / 4 give every QUAD of the
-// group its own copy, 8 entries per lane (quad_perm broadcast)
-__host__ __device__ constexpr int list_epl(int LG) { return LG == 16 ? 2 : 8; }
 // dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
 __host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int LG) {
   return ((N + 1) * LG + 3) / 4 * 4;
@@ -282,175 +273,11 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
   out[(int64_t)t * G + k] = o;
 }
 
-// Entry J (0..31) of a gene's 32-entry index vector -> every lane of its group,
-// plus the lane's column offset, as ONE v_add_u32_dpp:
-//   LG = 16: a DPP row is a group; entries sit two per lane -> row_newbcast:J/2
-//   LG < 16: every quad of the group holds all 32 entries, eight per lane
-//            -> quad_perm:[s,s,s,s] with s = J/8
-template <int LG, int J>
-__device__ __forceinline__ uint32_t entry_addr(const uint32_t (&e)[list_epl(LG)], uint32_t col4) {
-  constexpr int EPL = list_epl(LG);
-  const int v = (int)e[J % EPL];
-  if constexpr (LG == 16) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x150 + J / EPL, 0xf, 0xf, false) + col4;
-  } else {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, v, (J / EPL) * 0x55, 0xf, 0xf, false) + col4;
-  }
-}
-__device__ __forceinline__ uint32_t lds_at(const uint32_t* lds, uint32_t byte_off) {
-  return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + byte_off);
-}
-
-// Issue the 8 LDS reads of entries 8J..8J+7 into x[8J..8J+7].
-template <int LG, int J>
-__device__ __forceinline__ void read8(uint32_t (&x)[32], const uint32_t* __restrict__ lds,
-                                      const uint32_t (&e)[list_epl(LG)], uint32_t col4) {
-  x[8 * J + 0] = lds_at(lds, entry_addr<LG, 8 * J + 0>(e, col4));
-  x[8 * J + 1] = lds_at(lds, entry_addr<LG, 8 * J + 1>(e, col4));
-  x[8 * J + 2] = lds_at(lds, entry_addr<LG, 8 * J + 2>(e, col4));
-  x[8 * J + 3] = lds_at(lds, entry_addr<LG, 8 * J + 3>(e, col4));
-  x[8 * J + 4] = lds_at(lds, entry_addr<LG, 8 * J + 4>(e, col4));
-  x[8 * J + 5] = lds_at(lds, entry_addr<LG, 8 * J + 5>(e, col4));
-  x[8 * J + 6] = lds_at(lds, entry_addr<LG, 8 * J + 6>(e, col4));
-  x[8 * J + 7] = lds_at(lds, entry_addr<LG, 8 * J + 7>(e, col4));
-}
-// 8 row words -> counter planes 0..2, returns the carry of weight 8
-__device__ __forceinline__ uint32_t sum8(uint32_t (&c)[16], const uint32_t* x) {
-  const uint32_t a1 = full_add(c[0], x[0], x[1]);
-  const uint32_t a2 = full_add(c[0], x[2], x[3]);
-  const uint32_t b1 = full_add(c[1], a1, a2);
-  const uint32_t a3 = full_add(c[0], x[4], x[5]);
-  const uint32_t a4 = full_add(c[0], x[6], x[7]);
-  const uint32_t b2 = full_add(c[1], a3, a4);
-  return full_add(c[2], b1, b2);
-}
-
-template <int LG, int KC, int KD>
-__global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
-                                                        const uint32_t* __restrict__ lidx,
-                                                        const int32_t* __restrict__ lstart,
-                                                        const int32_t* __restrict__ lngroups,
-                                                        const int32_t* __restrict__ lorder,
-                                                        const uint2* __restrict__ lcrit, int G,
-                                                        int N, int64_t P, int ntiles,
-                                                        int quads_per_block,
-                                                        uint32_t* __restrict__ r) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
-  // blockIdx.x = (trait, tile) fastest, blockIdx.y = gene chunk: the blocks that
-  // run together walk the SAME chunk of index lists against different label
-  // tiles, so the lists stream from HBM once and are re-read from L2.
-  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int lg = lane / LG, col = lane % LG;
-  constexpr int GPW = kWave / LG;   // genes per wavefront
-  constexpr int EPL = list_epl(LG); // index entries per lane and step
-  constexpr int LPS = 32 / EPL;     // lanes that together hold one step's 32 entries
-
-  // tile -> LDS (contiguous copy, 16 B per lane)
-  const int tile_dwords = (N + 1) * LG;
-  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG);
-  {
-    const uint4* src4 = reinterpret_cast<const uint4*>(src);   // tiles are 16-B aligned per tile
-    uint4* dst4 = reinterpret_cast<uint4*>(tile_lds);
-    const int n4 = tile_dwords / 4;
-    for (int i = tid; i < n4; i += blockDim.x) dst4[i] = src4[i];
-    for (int i = n4 * 4 + tid; i < tile_dwords; i += blockDim.x) tile_lds[i] = src[i];
-  }
-  __syncthreads();
-
-  // permutations of this lane's word that exist (the last tile may be ragged)
-  const int64_t p_first = ((int64_t)tile * LG + col) * 32;
-  const uint32_t valid = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
-
-  const int nquads = (G + GPW - 1) / GPW;
-  const int q_lo = blockIdx.y * quads_per_block;
-  const int q_hi = min(nquads, q_lo + quads_per_block);
-  for (int q = q_lo + wave; q < q_hi; q += nwaves) {
-    const int slot = min(q * GPW + lg, G - 1);
-    const bool have = q * GPW + lg < G;
-    // every gene of a quad has the same (padded) number of 32-entry groups
-    const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);
-    // 32 list entries (byte offsets of LDS rows) per step, EPL per lane: the
-    // group's 16 lanes (LG = 16) or each of its quads (LG < 16) hold all 32
-    struct alignas(EPL == 2 ? 8 : 16) Ent { uint32_t e[EPL]; };
-    const Ent* lp = reinterpret_cast<const Ent*>(lidx) + (int64_t)lstart[slot] * LPS +
-                    (LG == 16 ? col : (lane & 3));
-    const uint32_t col4 = (uint32_t)col * 4u;
-
-    uint32_t c[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) c[k] = 0u;
-    auto read32 = [&](uint32_t (&x)[32], const Ent& ix) {
-      read8<LG, 0>(x, tile_lds, ix.e, col4);
-      read8<LG, 1>(x, tile_lds, ix.e, col4);
-      read8<LG, 2>(x, tile_lds, ix.e, col4);
-      read8<LG, 3>(x, tile_lds, ix.e, col4);
-    };
-    auto sum32 = [&](const uint32_t (&x)[32]) -> uint32_t {
-      const uint32_t cA = sum8(c, x);
-      const uint32_t cB = sum8(c, x + 8);
-      const uint32_t e1 = full_add(c[3], cA, cB);               // weight 16
-      const uint32_t cC = sum8(c, x + 16);
-      const uint32_t cD = sum8(c, x + 24);
-      const uint32_t e2 = full_add(c[3], cC, cD);
-      return full_add(c[4], e1, e2);                            // weight 32
-    };
-    // Software pipeline: index vectors are fetched four steps ahead (2 VGPRs per
-    // step), the 32 LDS row reads of step s+1 are in flight while step s is summed.
-    const int last = max(nsuper - 1, 0);
-    Ent b0 = lp[0], b1 = lp[(int64_t)min(1, last) * LPS], b2 = lp[(int64_t)min(2, last) * LPS],
-        b3 = lp[(int64_t)min(3, last) * LPS];
-    uint32_t xa[32], xb[32];
-    if (nsuper > 0) read32(xa, b0);
-    for (int sg = 0; sg < nsuper; sg += 4) {
-      // four steps (128 rows) per trip; their weight-32 carries are paired up
-      // the tree before the (short) half-adder ripple
-      uint32_t f1 = 0u, f2 = 0u, f3 = 0u;
-      b0 = lp[(int64_t)min(sg + 4, last) * LPS];
-      if (sg + 1 < nsuper) read32(xb, b1);
-      const uint32_t f0 = sum32(xa);
-      b1 = lp[(int64_t)min(sg + 5, last) * LPS];
-      if (sg + 2 < nsuper) read32(xa, b2);
-      if (sg + 1 < nsuper) f1 = sum32(xb);
-      b2 = lp[(int64_t)min(sg + 6, last) * LPS];
-      if (sg + 3 < nsuper) read32(xb, b3);
-      if (sg + 2 < nsuper) f2 = sum32(xa);
-      b3 = lp[(int64_t)min(sg + 7, last) * LPS];
-      if (sg + 4 < nsuper) read32(xa, b0);
-      if (sg + 3 < nsuper) f3 = sum32(xb);
-      const uint32_t g0 = full_add(c[5], f0, f1);               // weight 64
-      const uint32_t g1 = full_add(c[5], f2, f3);
-      uint32_t carry = full_add(c[6], g0, g1);                  // weight 128
-#pragma unroll
-      for (int k = 7; k < KC; ++k) {                            // ripple (half adders)
-        const uint32_t nc = c[k] & carry;
-        c[k] ^= carry;
-        carry = nc;
-      }
-    }
-    // region test, bit-sliced against this lane group's constants
-    const uint2 cr = lcrit[(int64_t)t * G + slot];
-    const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
-    const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
-    const uint32_t always = (cr.y >> 31) ? 0xffffffffu : 0u;
-    const uint32_t lt = region_lt<KC, KD>(c, base, span);
-    uint32_t ex = ((~lt) ^ inv) | always;
-    ex &= valid;
-    int cnt = have ? __popc(ex) : 0;
-#pragma unroll
-    for (int off = LG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if (have && col == 0 && cnt) atomicAdd(&r[(int64_t)t * G + lorder[slot]], (uint32_t)cnt);
-  }
-}
-
-
-
-// 128 permutations per lane: 4 lanes per gene read the 16-dword tile rows with
-// ds_read_b128, 16 genes per wavefront.  One address add serves four words
-// (~2.2 VALU ops per listed isolate and 32 permutations).  ds_read_b128 is served
-// in the lane groups {0-3,12-15,20-27} ...: with slot k starting at residue
-// class k mod 4 (scoary_lists_build) each group's four genes sit on distinct
-// 64-byte bank slots.
+// 128 permutations per lane: LPG = TW/4 lanes per gene read the tile rows with
+// ds_read_b128, 64/LPG genes per wavefront; one address add serves four words.
+// ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, ... over the full
+// 256-byte bank row: with slot k starting at residue class k mod (64/TW)
+// (scoary_lists_build) the genes of a group sit on distinct 4*TW-byte slots.
 __device__ __forceinline__ uint4 lds128_at(const uint32_t* lds, uint32_t byte_off) {
   return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds) + byte_off);
 }
@@ -489,15 +316,15 @@ struct Carry4 { uint32_t w[4]; };
 // wavefront.  Lists are walked in sub-steps of 4 entries: lane j of a gene group
 // holds entries 4j..4j+3 of each 4*LPG-entry piece.
 template <int LPG, int KC, int KD>
-__global__ __launch_bounds__(1024) void k_permute_lists128(const uint32_t* __restrict__ tiles,
-                                                           const uint32_t* __restrict__ lidx,
-                                                           const int32_t* __restrict__ lstart,
-                                                           const int32_t* __restrict__ lngroups,
-                                                           const int32_t* __restrict__ lorder,
-                                                           const uint2* __restrict__ lcrit, int G,
-                                                           int N, int64_t P, int ntiles,
-                                                           int quads_per_block,
-                                                           uint32_t* __restrict__ r) {
+__global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
+                                                        const uint32_t* __restrict__ lidx,
+                                                        const int32_t* __restrict__ lstart,
+                                                        const int32_t* __restrict__ lngroups,
+                                                        const int32_t* __restrict__ lorder,
+                                                        const uint2* __restrict__ lcrit, int G,
+                                                        int N, int64_t P, int ntiles,
+                                                        int groups_per_block,
+                                                        uint32_t* __restrict__ r) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
   constexpr int TW = 4 * LPG;        // tile row, dwords
   constexpr int GPW = kWave / LPG;   // genes per wavefront
@@ -522,9 +349,9 @@ __global__ __launch_bounds__(1024) void k_permute_lists128(const uint32_t* __res
     valid[w] = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
   }
 
-  const int nquads = (G + GPW - 1) / GPW;
-  const int q_lo = blockIdx.y * quads_per_block;
-  const int q_hi = min(nquads, q_lo + quads_per_block);
+  const int ngroups = (G + GPW - 1) / GPW;         // wave groups of GPW genes
+  const int q_lo = blockIdx.y * groups_per_block;
+  const int q_hi = min(ngroups, q_lo + groups_per_block);
   for (int q = q_lo + wave; q < q_hi; q += nwaves) {
     const int slot = min(q * GPW + lg, G - 1);
     const bool have = q * GPW + lg < G;
@@ -642,24 +469,15 @@ int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
 }
 int64_t scoary_list_tile_words(int64_t N) { return list_lg(N) ? list_tile_dwords(N, list_lg(N)) : 0; }
 int64_t scoary_list_max_isolates(void) { return 10239; }
-// Words (32 permutations each) per lane: 4 = k_permute_lists128 (the default), 1 =
-// k_permute_lists, the ds_read_b32 kernel it replaced, kept for A/B measurements
-// and selected with SCOARY_LISTS_WPL=1 in the environment.
-static int lists_wpl(int64_t) {
-  const char* e = std::getenv("SCOARY_LISTS_WPL");
-  return e && e[0] == '1' && !e[1] ? 1 : 4;
-}
 int scoary_list_params(int64_t N, int64_t* out5) {
   if (!out5) return SCOARY_ERR_ARG;
-  const int LG = list_lg(N);
-  const int wpl = lists_wpl(N);
-  out5[0] = LG;                            /* tile row width in dwords (0: N too large for LDS tiles) */
-  out5[1] = LG * 4;                        /* LDS / tile row stride in bytes */
-  out5[2] = LG ? kWave / LG * wpl : 0;     /* genes per wavefront: lists padded to equal length */
-  out5[3] = LG ? (wpl == 4 ? 64 : 32) / LG : 0;   /* residue classes of the isolate index:
-                                              ds_read_b128 is banked over 256 B, ds_read_b32 over 128 B */
-  out5[4] = LG && wpl == 4 ? LG : 0;       /* interleave piece, entries (0: contiguous lists) */
-  return LG ? SCOARY_OK : SCOARY_ERR_SIZE;
+  const int TW = list_lg(N);
+  out5[0] = TW;                     /* tile row width in dwords (0: N too large for LDS tiles) */
+  out5[1] = TW * 4;                 /* LDS / tile row stride in bytes */
+  out5[2] = TW ? 4 * kWave / TW : 0;   /* genes per wavefront: lists padded to equal length */
+  out5[3] = TW ? 64 / TW : 0;       /* residue classes of the isolate index (256-byte bank row) */
+  out5[4] = TW;                     /* interleave piece, entries */
+  return TW ? SCOARY_OK : SCOARY_ERR_SIZE;
 }
 
 int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
@@ -699,7 +517,7 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
 }
 
 extern "C++" {
-template <int LG, int KC, int KD, int WPL = 1>
+template <int TW, int KC, int KD>
 static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* d_tiles,
                                 const uint32_t* d_lidx, const int32_t* d_lstart,
                                 const int32_t* d_lngroups, const int32_t* d_lorder,
@@ -712,41 +530,32 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
                        reinterpret_cast<const uint2*>(d_crit), d_margins, d_lorder, d_lflipped,
                        (int)G, KD, reinterpret_cast<uint2*>(d_lcrit));
   }
-  const int64_t tile_perms = LG * 32;
+  const int64_t tile_perms = TW * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  constexpr int GPW = kWave / LG * WPL;
-  const int64_t nquads = (G + GPW - 1) / GPW;
+  constexpr int GPW = 4 * kWave / TW;           // genes per wavefront
+  const int64_t ngroups = (G + GPW - 1) / GPW;
   // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index
   // lists (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the
-  // chunk run; each chunk a multiple of 16 wave-groups
+  // chunk run; each chunk a multiple of 16 wave groups
   int64_t chunks = ((int64_t)h->num_cu * 16 + ntiles * T - 1) / (ntiles * T);
   const int64_t by_l2 = (G * N / 4 * 4 + (2 << 20) - 1) / (2 << 20);   // ~N/4 entries x 4 B per gene
   if (chunks < by_l2) chunks = by_l2;
   if (chunks > 65535) chunks = 65535;
   if (chunks < 1) chunks = 1;
-  int64_t qpb = (nquads + chunks - 1) / chunks;
-  qpb = (qpb + 15) / 16 * 16;
-  chunks = (nquads + qpb - 1) / qpb;
-  const size_t lds = (size_t)(N + 1) * LG * sizeof(uint32_t);
-  constexpr int kFlag = WPL == 4 ? 64 * LG : LG;
-  const void* fn;
-  if constexpr (WPL == 4) fn = reinterpret_cast<const void*>(&k_permute_lists128<LG / 4, KC, KD>);
-  else fn = reinterpret_cast<const void*>(&k_permute_lists<LG, KC, KD>);
-  if (!(h->lists_lds_optin & kFlag)) {   // once per handle (= per device) and kernel variant
-    HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    h->lists_lds_optin |= kFlag;
+  int64_t gpb = (ngroups + chunks - 1) / chunks;
+  gpb = (gpb + 15) / 16 * 16;
+  chunks = (ngroups + gpb - 1) / gpb;
+  const size_t lds = (size_t)(N + 1) * TW * sizeof(uint32_t);
+  if (!(h->lists_lds_optin & TW)) {   // once per handle (= per device) and tile width
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_permute_lists<TW / 4, KC, KD>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    h->lists_lds_optin |= TW;
   }
   KernelTimer kt(h, s, "k_permute_lists");
-  const dim3 grid((unsigned)(ntiles * T), (unsigned)chunks);
-  const uint2* lcrit2 = reinterpret_cast<const uint2*>(d_lcrit);
-  if constexpr (WPL == 4)
-    hipLaunchKernelGGL((k_permute_lists128<LG / 4, KC, KD>), grid, dim3(1024), lds, s, d_tiles, d_lidx,
-                       d_lstart, d_lngroups, d_lorder, lcrit2, (int)G, (int)N, P, (int)ntiles,
-                       (int)qpb, d_r);
-  else
-    hipLaunchKernelGGL((k_permute_lists<LG, KC, KD>), grid, dim3(1024), lds, s, d_tiles, d_lidx,
-                       d_lstart, d_lngroups, d_lorder, lcrit2, (int)G, (int)N, P, (int)ntiles,
-                       (int)qpb, d_r);
+  hipLaunchKernelGGL((k_permute_lists<TW / 4, KC, KD>), dim3((unsigned)(ntiles * T), (unsigned)chunks),
+                     dim3(1024), lds, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                     reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P, (int)ntiles,
+                     (int)gpb, d_r);
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }
@@ -762,27 +571,17 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   if (!d_tiles || !d_lidx || !d_lstart || !d_lngroups || !d_lorder || !d_lflipped || !d_crit ||
       !d_margins || !d_lcrit || !d_r || G < 1 || T < 1 || N < 1 || P < 1)
     return fail(h, SCOARY_ERR_ARG, "scoary_permute_lists: bad argument");
-  const int LG = list_lg(N);
-  if (!LG)
+  const int TW = list_lg(N);
+  if (!TW)
     return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: label tile does not fit in LDS for this N");
   if (T > 65535) return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: T > 65535");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   // counter planes KC: lists hold <= N/2 entries; compare planes KD: 2N+3 <= 2^KD
-  const int wpl = lists_wpl(N);
-  if (LG == 16 && wpl == 4)
-    return launch_permute_lists<16, 11, 13, 4>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                                               d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  if (LG == 16)
+  if (TW == 16)
     return launch_permute_lists<16, 11, 13>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                             d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  if (LG == 8 && wpl == 4)
-    return launch_permute_lists<8, 12, 14, 4>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                                              d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  if (LG == 4 && wpl == 4)
-    return launch_permute_lists<4, 13, 15, 4>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                                              d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  if (LG == 8)
+  if (TW == 8)
     return launch_permute_lists<8, 12, 14>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                            d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
   return launch_permute_lists<4, 13, 15>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,

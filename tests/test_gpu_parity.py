@@ -349,25 +349,6 @@ def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     assert np.array_equal(lists.view(np.uint32), want)
 
 
-@pytest.mark.parametrize("G,N,T,P", [(300, 100, 2, 512), (500, 2000, 2, 1030), (130, 3000, 2, 260),
-                                     (70, 10000, 1, 130)])
-def test_permute_lists_b32_variant(eng, orc, monkeypatch, G, N, T, P):
-    """SCOARY_LISTS_WPL=1 selects k_permute_lists (one 32-permutation word per
-    lane, contiguous lists) -- the A/B baseline of k_permute_lists128; same r."""
-    monkeypatch.setenv("SCOARY_LISTS_WPL", "1")
-    assert eng.list_params(N)[4] == 0                           # contiguous lists
-    rng = np.random.default_rng(G + N)
-    genes, traits = _random_case(rng, G, N, T)
-    tb, mb = _bits(eng, traits)
-    from scoary_amd.engine import pack_bits_rows
-    gm = eng.pack_dense(genes)
-    eng.build_lists(gm, pack_bits_rows(genes))
-    got = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=3,
-                        use_lists=True)["r"].cpu().numpy()
-    want = orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, 3).T
-    assert np.array_equal(got.view(np.uint32), want)
-
-
 @pytest.mark.parametrize("N,T,P", [(333, 2, 700), (2700, 2, 700), (6000, 2, 700), (64, 1, 64),
                                    (333, 4, 17000)])
 def test_perm_tiles_are_the_transposed_row_labels(eng, N, T, P):
