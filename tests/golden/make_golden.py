@@ -24,6 +24,11 @@ Fixtures written (all consumed by tests/ and by oracle pinning):
                                    margins
   permute_tree_seeded.json         seeded reference Permute() (tree statistic;
                                    SURVEY D1 -- pinned for the "next" row)
+  synth2/*                         a second, synthetic data set (clade-structured
+                                   genes, NA / absent isolates, "0" and "-" cells,
+                                   quoted cells) with the reference's CSVs for
+                                   --no_pairwise, default mode, --collapse and the
+                                   tree it builds
 """
 import contextlib
 import gzip
@@ -301,9 +306,77 @@ def tree_goldens(gd, td, prune, res, manifest):
         json.dump(out, f, indent=0)
 
 
+def synth2(manifest):
+    """Second data set: 260 genes x 52 isolates in 4 clades, 3 traits with NA /
+    missing isolates.  Inputs are generated here (numpy seed below) and stored
+    next to the reference's outputs."""
+    rng = np.random.default_rng(20260928)
+    G, N = 260, 52
+    clade = np.repeat(np.arange(4), N // 4)
+    base = rng.beta(0.35, 0.35, size=(G, 1))                       # U-shaped frequencies
+    shift = rng.normal(0, 0.25, size=(G, 4))[:, clade]             # clade structure
+    dense = rng.random((G, N)) < np.clip(base + shift, 0.0, 1.0)
+    dense[3] = dense[2]                                            # identical patterns (--collapse)
+    dense[11] = dense[2]
+    dense[20] = ~dense[19]                                         # complement
+    dense[30] = True                                               # core gene   (skip rule)
+    dense[31] = False                                              # absent gene (skip rule)
+    iso = ["iso_%02d" % i for i in range(N)]
+    meta = ["Gene", "Non-unique Gene name", "Annotation", "No. isolates", "No. sequences",
+            "Avg sequences per isolate", "Genome Fragment", "Order within Fragment",
+            "Accessory Fragment", "Accessory Order with Fragment", "QC", "Min group size nuc",
+            "Max group size nuc", "Avg group size nuc"]
+    lines = [",".join('"%s"' % h for h in meta + iso)]
+    for g in range(G):
+        cells = []
+        for i in range(N):
+            if dense[g, i]:
+                cells.append('"%s_%05d"' % (iso[i], g) if (g + i) % 7 else "%s_%05d" % (iso[i], g))
+            else:
+                cells.append(["", "", '""', "0", "-"][(g * 3 + i) % 5])   # all absent spellings
+        lines.append(",".join(['"group_%d"' % g, '"nm%d"' % g if g % 3 else '""',
+                               '"hypothetical, protein %d"' % g] + ['"1"'] * 11 + cells))
+    gpa_text = "\n".join(lines) + "\n"
+    t0 = dense[5] ^ (rng.random(N) < 0.08)                         # gene-driven
+    t1 = (clade >= 2) ^ (rng.random(N) < 0.15)                     # clade-driven
+    t2 = rng.random(N) < 0.3
+    rows = [",driven,lineage,sparse"]
+    for i in range(N):
+        if i == 17:
+            continue                                               # isolate absent from the traits file
+        v = [str(int(t0[i])), str(int(t1[i])), str(int(t2[i]))]
+        if i in (4, 9, 33, 40):
+            v[1] = "NA"
+        if i == 50:
+            v[2] = "NA"
+        rows.append(iso[i] + "," + ",".join(v))
+    tr_text = "\n".join(rows) + "\n"
+    tmp = tempfile.mkdtemp()
+    gpa, tr = os.path.join(tmp, "gpa.csv"), os.path.join(tmp, "traits.csv")
+    with open(gpa, "w") as f:
+        f.write(gpa_text)
+    with open(tr, "w") as f:
+        f.write(tr_text)
+    gz_write(gpa_text, os.path.join(HERE, "synth2", "gpa.csv.gz"))
+    gz_write(tr_text, os.path.join(HERE, "synth2", "traits.csv.gz"))
+    for sub, extra in (("no_pairwise", ["--no_pairwise", "-p", "1.0"]),
+                       ("collapse", ["--no_pairwise", "--collapse", "-c", "I", "B", "-p", "0.5", "1.0"]),
+                       ("pairwise", ["-u", "-c", "I", "EPW", "-p", "0.3", "1.0"])):
+        od = tempfile.mkdtemp()
+        files = run_cli(["-g", gpa, "-t", tr] + extra, od)
+        assert len(files) == 3, files.keys()
+        for fn, text in files.items():
+            gz_write(text, os.path.join(HERE, "synth2", sub, fn + ".gz"))
+            manifest.setdefault("synth2_rows", {})[sub + "/" + fn] = text.count("\n") - 1
+        if "-u" in extra:
+            with open(os.path.join(od, "Tree.nwk")) as f:
+                gz_write(f.read(), os.path.join(HERE, "synth2", "Tree.nwk.gz"))
+
+
 def main():
     os.makedirs(HERE, exist_ok=True)
     manifest = {}
+    synth2(manifest)
 
     # -- inputs the reference's own tests ship --------------------------------
     for fn in ("Gene_presence_absence.csv", "Tetracycline_resistance.csv",

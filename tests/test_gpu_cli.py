@@ -268,3 +268,45 @@ def test_cli_custom_newick_tree_equals_upgma_run(exampledir, tmp_path):
         assert fa[k] == fb[k]
     top = list(csv.reader(io.StringIO(fb["Tetracycline_resistance.results.csv"])))[1]
     assert top[0] == "TetRCG" and [int(x) for x in top[13:16]] == [25, 25, 1]
+
+
+@pytest.fixture(scope="module")
+def synth2dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("synth2")
+    for fn in ("gpa.csv", "traits.csv"):
+        with open(os.path.join(d, fn), "w", newline="") as f:
+            f.write(golden_text("synth2/%s.gz" % fn))
+    return str(d)
+
+
+@pytest.mark.parametrize("sub,extra", [
+    ("no_pairwise", ["--no_pairwise", "-p", "1.0"]),
+    ("collapse", ["--no_pairwise", "--collapse", "-c", "I", "B", "-p", "0.5", "1.0"]),
+    ("pairwise", ["-u", "-c", "I", "EPW", "-p", "0.3", "1.0"]),
+])
+def test_cli_second_dataset_vs_reference(synth2dir, tmp_path, sub, extra):
+    """tests/golden/synth2: clade-structured genes, NA / absent isolates, quoted
+    cells; --no_pairwise, --collapse and default (pairwise) mode against the CSVs
+    and the Tree.nwk the reference wrote for the same files."""
+    files = run_cli(["-g", os.path.join(synth2dir, "gpa.csv"),
+                     "-t", os.path.join(synth2dir, "traits.csv")] + extra, tmp_path)
+    assert sorted(files) == ["driven.results.csv", "lineage.results.csv", "sparse.results.csv"]
+    if "-u" in extra:
+        with open(os.path.join(tmp_path, "Tree.nwk")) as f:
+            assert f.read().strip() == golden_text("synth2/Tree.nwk.gz").strip()
+    for fn, text in files.items():
+        want = golden_text("synth2/%s/%s.gz" % (sub, fn))
+        if sub != "pairwise":
+            _assert_csv_equal(text, want)
+            continue
+        g = list(csv.reader(io.StringIO(text)))
+        w = list(csv.reader(io.StringIO(want)))
+        assert g[0] == w[0] and len(g) == len(w), (fn, len(g), len(w))
+        wi = {r[0]: r for r in w[1:]}
+        for r in g[1:]:
+            x = wi[r[0]]
+            assert r[:7] == x[:7] and r[13:16] == x[13:16], r[0]   # counts and pair counts: exact
+            for k in (7, 8, 9, 10, 11, 12, 16, 17):
+                if r[k] != x[k]:
+                    assert abs(float(r[k]) - float(x[k])) <= 1e-9 * abs(float(x[k])) + 1e-12 * 300, \
+                        (r[0], g[0][k], r[k], x[k])

@@ -318,6 +318,36 @@ def test_native_and_python_readers_build_the_same_table(exampledir, monkeypatch)
     assert np.array_equal(c["Roarydic"].rows64, d["Roarydic"].rows64)
 
 
+def test_readers_on_synth2_quoted_cells(tmp_path, monkeypatch):
+    """Second data set: quoted headers, quoted cells with commas, `""`, "0" and "-"
+    absent spellings -- native and Python readers agree with the test suite's own
+    minimal reader."""
+    from conftest import golden_text, read_dense
+    from scoary_amd import methods as m
+    from scoary_amd.engine import pack_bits_rows
+    path = tmp_path / "gpa.csv"
+    path.write_text(golden_text("synth2/gpa.csv.gz"))
+    ids, strains, genes, _names, _traits = read_dense(golden_text("synth2/gpa.csv.gz"),
+                                                      golden_text("synth2/traits.csv.gz"))
+    tables = []
+    for py in (False, True):
+        if py:
+            monkeypatch.setenv("SCOARY_PY_CSV", "1")
+        with open(path) as f:
+            tables.append(m.Csv_to_dic_Roary(f, ",", [], startcol=14))
+    for gd in tables:
+        t = gd["Roarydic"]
+        assert t.ids == ids and gd["Strains"] == strains
+        assert np.array_equal(t.rows64, pack_bits_rows(genes))
+        assert t.annotation[7] == "hypothetical, protein 7" and t.nugn[3] == "" and t.nugn[4] == "nm4"
+    with open(tmp_path / "traits.csv", "w") as f:
+        f.write(golden_text("synth2/traits.csv.gz"))
+    with open(tmp_path / "traits.csv") as f:
+        td, prune = m.Csv_to_dic(f, ",", None, strains)
+    assert sorted(x for x in prune["lineage"] if x) == ["iso_04", "iso_09", "iso_17", "iso_33", "iso_40"]
+    assert [x for x in prune["driven"] if x] == ["iso_17"]
+
+
 def test_io_library_exports_every_declared_symbol():
     from scoary_amd import io_native
     with open(os.path.join(ROOT, "include", "scoary_io.h")) as f:

@@ -128,3 +128,29 @@ def test_pairwise_columns_of_reference_csv():
                 best, worst = worst, best
             assert abs(best - float(d[16])) <= 1e-12 * float(d[16])
             assert abs(worst - float(d[17])) <= 1e-12 * float(d[17])
+
+
+def test_synth2_tree_and_pairwise_columns():
+    """Second data set: the oracle's UPGMA tree is the reference's Tree.nwk, and the
+    pairwise columns of its default-mode CSVs are reproduced (pruned trees for
+    the traits with NA / absent isolates)."""
+    ids, strains, genes, names, traits = read_dense(golden_text("synth2/gpa.csv.gz"),
+                                                    golden_text("synth2/traits.csv.gz"))
+    var = (genes.sum(1) > 0) & (genes.sum(1) < len(strains))
+    tree = orc.upgma(genes[var].T, strains)
+    assert orc.newick(tree) == golden_text("synth2/Tree.nwk.gz").strip()
+    index_of = {s: i for i, s in enumerate(strains)}
+    checked = 0
+    for ti, trait in enumerate(names):
+        rows = list(csv.reader(io.StringIO(
+            golden_text("synth2/pairwise/%s.results.csv.gz" % trait))))
+        missing = [s for i, s in enumerate(strains) if traits[ti, i] == 2]
+        ptree = orc.prune_for_missing(tree, missing + [None]) if missing else tree
+        ops, tips = orc.tree_program(ptree, index_of)
+        for d in rows[1:]:
+            g = ids.index(d[0])
+            st = np.array([(0 if genes[g, i] else 2) + (0 if traits[ti, i] == 1 else 1)
+                           for i in tips], dtype=np.uint8)
+            assert orc.tree_dp(ops, st) == (int(d[13]), int(d[14]), int(d[15])), (trait, d[0])
+            checked += 1
+    assert checked > 150
