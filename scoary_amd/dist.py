@@ -83,7 +83,9 @@ def init_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # SCOARY_EXERCISE_DIST=1 under torchrun with one rank: still join a group and go
+    # through the exchange step (a 1-GPU check of the N>1 code path)
+    if world > 1 or (os.environ.get("SCOARY_EXERCISE_DIST") == "1" and "RANK" in os.environ):
         torch = _torch()
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -153,12 +155,24 @@ def gather_genes(rec_local, G, dst=0, group=None, async_op=False, recv=None):
     return work, finish
 
 
+def shutdown():
+    """Leave the process group (if any) before the interpreter exits."""
+    if _initialized():
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def _initialized():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def associate_sharded(local_compute, G, group=None):
     """Run ``local_compute(start, stop) -> int32 records [T, stop-start, 9]`` on
     this rank's gene shard and gather the records of all ranks (every rank gets
     the full result: the host-side B/BH needs the globally sorted p)."""
     world, rank = world_rank()
-    if world == 1:
+    if world == 1 and not _initialized():
         return local_compute(0, G)
     a, b = shard_bounds(G, world)[rank]
     return all_gather_genes(local_compute(a, b), G, group)

@@ -1161,6 +1161,7 @@ def main(**kwargs):
         log.exception("CRITICAL:")
         for hnd in (logfile, console, counts):
             log.removeHandler(hnd)
+        dist.shutdown()
         sys.exit(e.code)
     if counts.n.get("CRITICAL", 0):
         log.info("Scoary finished successfully, but with CRITICAL ERRORS. Please check your log file.")
@@ -1173,6 +1174,7 @@ def main(**kwargs):
     for hnd in (logfile, console, counts):
         log.removeHandler(hnd)
     logfile.close()
+    dist.shutdown()
     sys.exit(0)
 
 
