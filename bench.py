@@ -33,14 +33,15 @@ if ROOT not in sys.path:
 LISTS_DEFAULT = True         # list-driven kernel: 9.5 ms vs 16.2 ms (dense) on the headline config
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (upper bound)
-INT_VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9   # integer/logic ops: 16 lanes/clk/SIMD (profiles/r01_valu_peak.txt)
+INT_VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9   # integer/logic ops: 16 lanes/clk/SIMD at the nominal
+                                                 # 2.4 GHz (profiles/r01_valu_peak.txt measures 3.8-4.1e13)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4"])
     ap.add_argument("--genes", type=int, default=None, help="override G (per GPU)")
     ap.add_argument("--permutations", type=int, default=None, help="override P")
