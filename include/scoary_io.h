@@ -77,6 +77,22 @@ void scoary_lists_build(const uint64_t *rows64, int64_t G, int64_t N, int64_t ro
                         int64_t genes_per_wave, int64_t classes, int64_t piece, uint32_t *idx,
                         int32_t *start, int32_t *ngroups, int32_t *order, uint8_t *flipped);
 
+/* ---- vcf2scoary record lines (scoary/vcf2scoary.py:170-214) -------------------
+ * Converts the variant lines of a VCF -- everything from byte `offset`, i.e. after
+ * the #CHROM header line -- to rows of the Roary/Scoary-style table and APPENDS
+ * them to out_path: one row per ALT allele, the nine fixed columns, DUMMY
+ * ("False", or "True" for rows split out of a multi-allelic site), one genotype
+ * cell per sample (first ':'-field; at multi-allelic sites "1" if it names this
+ * allele, else "0", "." -> "0"), every cell in double quotes.  types: NULL, or
+ * a comma-separated list of INFO TYPE= values to keep.
+ * Returns the number of rows written; -1 on an I/O error; -2 if the file needs
+ * the general reader (quote characters, lone carriage returns, short lines,
+ * genotypes that are not plain digits, missing TYPE=): the caller then discards
+ * the output and runs the Python implementation, which reproduces the
+ * reference's behaviour for those inputs. */
+int64_t scoary_vcf_convert(const char *vcf_path, int64_t offset, const char *out_path,
+                           const char *types);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,8 +10,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 struct scoary_gpa {
@@ -367,6 +369,179 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
       if (j == genes_per_wave - 1) pos += genes_per_wave * L;
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// vcf2scoary record lines (scoary/vcf2scoary.py:170-214): the per-variant loop
+// ---------------------------------------------------------------------------
+namespace {
+// Output rows are assembled in one flat buffer; reserve() before every row keeps
+// the cell writers free of bounds checks.
+struct OutBuf {
+  FILE* f;
+  std::vector<char> buf;
+  size_t len = 0;
+  explicit OutBuf(FILE* f_) : f(f_), buf(1 << 23) {}
+  bool reserve(size_t need) {
+    if (len + need <= buf.size()) return true;
+    if (len && fwrite(buf.data(), 1, len, f) != len) return false;
+    len = 0;
+    if (need > buf.size()) buf.resize(need);
+    return true;
+  }
+  inline void put(char c) { buf[len++] = c; }
+  inline void cell(const char* p, size_t n, bool first) {
+    if (!first) put(',');
+    put('"');
+    memcpy(buf.data() + len, p, n);
+    len += n;
+    put('"');
+  }
+  bool finish() { return !len || fwrite(buf.data(), 1, len, f) == len; }
+};
+inline bool is_word(char c) {
+  return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_';
+}
+}  // namespace
+
+int64_t scoary_vcf_convert(const char* vcf_path, int64_t offset, const char* out_path,
+                           const char* types) {
+  const int fd = open(vcf_path, O_RDONLY);
+  if (fd < 0) return -1;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || offset < 0 || offset > st.st_size) {
+    close(fd);
+    return -1;
+  }
+  const size_t n = (size_t)st.st_size;
+  const char* d = n ? (const char*)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : "";
+  if (n && d == MAP_FAILED) {
+    close(fd);
+    return -1;
+  }
+  FILE* out = fopen(out_path, "ab");
+  if (!out) {
+    if (n) munmap((void*)d, n);
+    close(fd);
+    return -1;
+  }
+  std::vector<std::string> want;                    // wanted TYPE= values
+  if (types) {
+    const char* t = types;
+    for (;;) {
+      const char* c = strchr(t, ',');
+      want.emplace_back(t, c ? (size_t)(c - t) : strlen(t));
+      if (!c) break;
+      t = c + 1;
+    }
+  }
+  OutBuf ob(out);
+  std::vector<int64_t> gt;                          // genotypes of a multi-allelic line (-1 = ".")
+  int64_t rows = 0, rc = 0;
+  size_t p = (size_t)offset;
+  while (p < n && rc == 0) {
+    const char* nl = (const char*)memchr(d + p, '\n', n - p);
+    size_t end = nl ? (size_t)(nl - d) : n;
+    const size_t next = nl ? end + 1 : n;
+    if (end > p && d[end - 1] == '\r') --end;
+    const char* L = d + p;
+    const size_t len = end - p;
+    p = next;
+    // anything the plain split does not cover goes back to the Python reader:
+    // quote characters, a lone carriage return, fewer than ten columns
+    if (memchr(L, '"', len) || memchr(L, '\r', len)) { rc = -2; break; }
+    size_t fs[10], fe[9];                            // the nine fixed fields; fs[9] = first sample
+    size_t q = 0;
+    int nf = 0;
+    fs[0] = 0;
+    while (nf < 9) {
+      const char* tab = (const char*)memchr(L + q, '\t', len - q);
+      if (!tab) break;
+      fe[nf] = (size_t)(tab - L);
+      q = fe[nf] + 1;
+      fs[++nf] = q;
+    }
+    if (nf < 9) { rc = -2; break; }
+    if (types) {                                    // re.search(r"TYPE=(\w+)", INFO).group(1) in types
+      const char* info = L + fs[7];
+      const size_t il = fe[7] - fs[7];
+      bool found = false, keep = false;
+      for (size_t i = 0; i + 6 <= il && !found; ++i) {
+        if (memcmp(info + i, "TYPE=", 5) == 0 && is_word(info[i + 5])) {
+          size_t e = i + 5;
+          while (e < il && is_word(info[e])) ++e;
+          found = true;
+          for (const auto& w : want)
+            if (w.size() == e - (i + 5) && memcmp(w.data(), info + i + 5, w.size()) == 0) keep = true;
+        }
+      }
+      if (!found) { rc = -2; break; }               // Python raises here
+      if (!keep) continue;
+    }
+    const char* alt = L + fs[4];
+    const size_t al = fe[4] - fs[4];
+    if (!memchr(alt, ',', al)) {
+      if (!ob.reserve(3 * len + 64)) { rc = -1; break; }
+      for (int c = 0; c < 9; ++c) ob.cell(L + fs[c], fe[c] - fs[c], c == 0);
+      ob.cell("False", 5, false);
+      for (size_t i = fs[9];;) {                     // first ':'-field of every sample cell
+        ob.put(',');
+        ob.put('"');
+        while (i < len && L[i] != '\t' && L[i] != ':') ob.put(L[i++]);
+        ob.put('"');
+        while (i < len && L[i] != '\t') ++i;
+        if (i >= len) break;
+        ++i;
+      }
+      ob.put('\n');
+      ++rows;
+      continue;
+    }
+    gt.clear();
+    for (size_t i = fs[9];;) {
+      int64_t v = 0;
+      size_t digits = 0;
+      bool dot = false;
+      while (i < len && L[i] != '\t' && L[i] != ':') {
+        const char ch = L[i++];
+        if (ch >= '0' && ch <= '9') { v = v * 10 + (ch - '0'); ++digits; }
+        else if (ch == '.' && digits == 0 && !dot) dot = true;
+        else rc = -2;                                // int() is laxer: the Python path decides
+      }
+      if (dot ? digits != 0 : (digits == 0 || digits > 9)) rc = -2;
+      gt.push_back(dot ? -1 : v);
+      while (i < len && L[i] != '\t') ++i;
+      if (i >= len) break;
+      ++i;
+    }
+    if (rc) break;
+    int64_t k = 0;
+    for (size_t a0 = 0;;) {
+      const char* c = (const char*)memchr(alt + a0, ',', al - a0);
+      const size_t a1 = c ? (size_t)(c - alt) : al;
+      ++k;
+      if (!ob.reserve(len + 4 * gt.size() + 64)) { rc = -1; break; }
+      for (int cidx = 0; cidx < 4; ++cidx) ob.cell(L + fs[cidx], fe[cidx] - fs[cidx], cidx == 0);
+      ob.cell(alt + a0, a1 - a0, false);
+      for (int cidx = 5; cidx < 9; ++cidx) ob.cell(L + fs[cidx], fe[cidx] - fs[cidx], false);
+      ob.cell("True", 4, false);
+      for (const int64_t g : gt) {
+        ob.put(',');
+        ob.put('"');
+        ob.put(g == k ? '1' : '0');
+        ob.put('"');
+      }
+      ob.put('\n');
+      ++rows;
+      if (!c) break;
+      a0 = a1 + 1;
+    }
+  }
+  if (rc == 0 && !ob.finish()) rc = -1;
+  if (fclose(out) != 0 && rc == 0) rc = -1;
+  if (n) munmap((void*)d, n);
+  close(fd);
+  return rc ? rc : rows;
 }
 
 }  // extern "C"

@@ -41,6 +41,17 @@ def _load():
     return _lib
 
 
+def vcf_convert(vcf_path, offset, out_path, types=None):
+    """Variant lines of a VCF -> appended table rows (scoary_vcf_convert).
+    Returns rows written, -1 on I/O errors, -2 if the file needs the Python loop."""
+    L = _load()
+    L.scoary_vcf_convert.argtypes = [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p,
+                                     ctypes.c_char_p]
+    L.scoary_vcf_convert.restype = ctypes.c_int64
+    t = None if types is None else ",".join(types).encode()
+    return int(L.scoary_vcf_convert(os.fsencode(vcf_path), int(offset), os.fsencode(out_path), t))
+
+
 def build_lists(rows64, N, row_stride, genes_per_wave, classes, piece=0):
     """Minority index lists of every gene row (include/scoary_io.h,
     scoary_lists_build): dict of numpy arrays idx (uint32), start, ngroups,

@@ -8,6 +8,11 @@ rows split out of a multi-allelic site), then one 0/1 genotype cell per sample.
     python -m scoary_amd.vcf2scoary [--out mutations_presence_absence.csv]
                                     [--types snp,ins,del] [--force] input.vcf
 
+The per-variant loop runs in the native reader (scoary_vcf_convert,
+include/scoary_io.h: ~100x the Python loop on a 5000-sample file); files it does
+not cover (quoted fields, odd line ends, short or malformed lines) go through
+the Python loop below, which mirrors the reference line by line.
+
 Kept from the reference, on purpose: a missing genotype "." at a bi-allelic
 site is written through unchanged (and therefore reads as *present* in Scoary,
 whose absence markers are "", "0", "-"), while at multi-allelic sites it
@@ -58,7 +63,43 @@ def allele_row(fields, genotypes, allele):
     return fields + ["True"] + out
 
 
-def convert(vcf_handle, out_handle, types="ALL", log=print):
+def _records_offset(path):
+    """Byte offset of the first variant line (after the #CHROM header line) if the
+    meta / header block is plain (\\n or \\r\\n line ends, no quotes in the header
+    line); None otherwise."""
+    off = 0
+    with open(path, "rb") as f:
+        for line in f:
+            off += len(line)
+            body = line.rstrip(b"\n")
+            if body.endswith(b"\r"):
+                body = body[:-1]
+            if b"\r" in body:
+                return None
+            if body[:2] == b"##":
+                continue
+            return None if (b'"' in body or not body) else off
+    return None
+
+
+def convert_file(vcf_path, out_path, types="ALL", log=print):
+    """vcf_path -> out_path; native record loop when the file allows it."""
+    from . import io_native
+    off = _records_offset(vcf_path) if io_native.available() else None
+    if off is not None:
+        with open(vcf_path, "r", newline=None) as vcf, open(out_path, "w") as out:
+            convert(vcf, out, types, log, header_only=True)
+        n = io_native.vcf_convert(vcf_path, off, out_path, None if types == "ALL" else types)
+        if n >= 0:
+            log("Reached the end of the file")
+            return n
+        if n == -1:
+            sys.exit("ERROR: could not read %s or write %s" % (vcf_path, out_path))
+    with open(vcf_path, "r", newline=None) as vcf, open(out_path, "w") as out:
+        return convert(vcf, out, types, log)
+
+
+def convert(vcf_handle, out_handle, types="ALL", log=print, header_only=False):
     rows = csv.reader(vcf_handle, delimiter="\t", quotechar='"')
     meta = {k: {} for k in STRUCTURED}
     header = None
@@ -85,6 +126,8 @@ def convert(vcf_handle, out_handle, types="ALL", log=print):
         sys.exit("ERROR: Expected a single allele per genotype. Scoary only works for "
                  "haploid organisms.")
     out_handle.write(_quote_row(header[:9] + ["DUMMY"] + header[9:]))
+    if header_only:
+        return 0
     n = 0
     for line in rows:
         if types != "ALL":
@@ -122,8 +165,7 @@ def main(argv=None):
         sys.exit("Outfile already exists. Change name of outfile or run with --force")
     if not os.path.isfile(args.vcf):
         sys.exit("Unable to locate input file %s" % args.vcf)
-    with open(args.vcf, "r", newline=None) as vcf, open(args.out, "w") as out:
-        convert(vcf, out, types)
+    convert_file(args.vcf, args.out, types)
     sys.exit(0)
 
 

@@ -238,6 +238,68 @@ def test_vcf2scoary_matches_reference_output(exampledir, tmp_path):
     assert n == 0 and io_out.getvalue().count("\n") == 1
 
 
+def _vcf_text(rng, V, S, crlf=False, extra=()):
+    nl = "\r\n" if crlf else "\n"
+    lines = ["##fileformat=VCFv4.2",
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+             '##INFO=<ID=TYPE,Number=A,Type=String,Description="type, of variant">',
+             "\t".join(["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"] +
+                       ["s%d" % i for i in range(S)])]
+    kinds = ["snp", "ins", "del", "mnp"]
+    for v in range(V):
+        nalt = 1 + (v % 5 == 0) + (v % 10 == 0)
+        alt = ",".join("ACGT"[a] for a in range(nalt)) if v % 20 else "A,,T"[:2 * nalt - 1]
+        g = rng.integers(0, nalt + 1, S).astype(str)
+        g[rng.random(S) < 0.05] = "."
+        fmt = "GT:DP" if v % 3 else "GT"
+        cells = [x + ":12" if v % 3 else x for x in g]
+        info = ("DP=5;TYPE=%s" % kinds[v % 4]) if v % 7 else ("TYPE=%s;AF=0.5" % kinds[v % 4])
+        lines.append("\t".join(["chr1", str(100 + v), ".", "G", alt, "50", "PASS", info, fmt] + cells))
+    lines.extend(extra)
+    return nl.join(lines) + nl
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_vcf2scoary_native_loop_equals_python_loop(tmp_path, crlf):
+    """scoary_vcf_convert (native record loop) writes exactly what the Python loop
+    (the line-by-line mirror of the reference) writes: bi- and multi-allelic
+    sites, empty ALT alleles, missing genotypes, GT with and without sub-fields,
+    --types filters, \\r\\n files."""
+    from scoary_amd import io_native, vcf2scoary as v
+    rng = np.random.default_rng(4)
+    vcf = tmp_path / "in.vcf"
+    vcf.write_text(_vcf_text(rng, 300, 37, crlf), newline="")
+    assert v._records_offset(str(vcf)) is not None and io_native.available()
+    for types in ("ALL", ["snp"], ["ins", "mnp"], ["nothing"]):
+        py = io.StringIO()
+        with open(vcf, "r", newline=None) as f:
+            n_py = v.convert(f, py, types, log=lambda *a: None)
+        out = tmp_path / "native.csv"
+        n_nat = v.convert_file(str(vcf), str(out), types, log=lambda *a: None)
+        assert n_nat == n_py and out.read_text() == py.getvalue(), types
+    assert n_py == 0
+
+
+@pytest.mark.parametrize("bad", ['chr1\t9\t.\tG\tA\t50\tPASS\tTYPE=snp\tGT\t"0"\t1',   # quoted cell
+                                 "chr1\t9\t.\tG\tA,T\t50\tPASS\tTYPE=snp\tGT\t+1\t2",  # int() accepts "+1"
+                                 "chr1\t9\t.\tG\tA\t50\tPASS\tTYPE=snp\tGT"])           # no sample cells
+def test_vcf2scoary_native_loop_hands_odd_files_to_python(tmp_path, bad):
+    from scoary_amd import io_native, vcf2scoary as v
+    rng = np.random.default_rng(5)
+    vcf = tmp_path / "in.vcf"
+    vcf.write_text(_vcf_text(rng, 12, 2, extra=[bad]), newline="")
+    off = v._records_offset(str(vcf))
+    probe = tmp_path / "probe.csv"
+    probe.write_text("")
+    assert io_native.vcf_convert(str(vcf), off, str(probe)) == -2
+    py = io.StringIO()
+    with open(vcf, "r", newline=None) as f:
+        n_py = v.convert(f, py, "ALL", log=lambda *a: None)
+    out = tmp_path / "out.csv"
+    assert v.convert_file(str(vcf), str(out), "ALL", log=lambda *a: None) == n_py > 12
+    assert out.read_text() == py.getvalue()
+
+
 # ------------------------------------------------------- native GPA reader ---
 def _py_cells(text, delimiter=","):
     import csv
@@ -352,9 +414,9 @@ def test_io_library_exports_every_declared_symbol():
     from scoary_amd import io_native
     with open(os.path.join(ROOT, "include", "scoary_io.h")) as f:
         src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(scoary_gpa_[a-z_]+)\s*\(", src)))
+    names = sorted(set(re.findall(r"\b(scoary_(?:gpa|lists|vcf)_[a-z_]+)\s*\(", src)))
     lib = ctypes.CDLL(io_native.LIB_PATH)
-    assert len(names) == 13
+    assert len(names) == 16 and "scoary_vcf_convert" in names and "scoary_lists_build" in names
     for n in names:
         assert hasattr(lib, n), n
 
