@@ -371,6 +371,52 @@ def synth2(manifest):
         if "-u" in extra:
             with open(os.path.join(od, "Tree.nwk")) as f:
                 gz_write(f.read(), os.path.join(HERE, "synth2", "Tree.nwk.gz"))
+    # -- less common flags: -r/-w (reduced set written), --include_input_columns,
+    #    --delimiter on ';'-separated copies of the same inputs ------------------
+    restrict = os.path.join(tmp, "restrict.csv")
+    keep = [iso[i] for i in range(N) if i % 3 != 1]
+    with open(restrict, "w") as f:
+        f.write(",".join(keep) + "\n")
+    gz_write(",".join(keep) + "\n", os.path.join(HERE, "synth2", "restrict.csv.gz"))
+    od = tempfile.mkdtemp()
+    files = run_cli(["-g", gpa, "-t", tr, "--no_pairwise", "-p", "1.0", "-r", restrict, "-w",
+                     "--include_input_columns", "4,6-7"], od)
+    for fn, text in files.items():
+        gz_write(text, os.path.join(HERE, "synth2", "restrict_w", fn + ".gz"))
+    with open(os.path.join(od, "gene_presence_absence_reduced.csv")) as f:
+        gz_write(f.read(), os.path.join(HERE, "synth2", "restrict_w",
+                                        "gene_presence_absence_reduced.csv.gz"))
+    import csv as _csv
+    semi = {}
+    for name, path in (("gpa", gpa), ("traits", tr)):
+        with open(path, newline="") as f:
+            rows = list(_csv.reader(f))
+        buf = io.StringIO()
+        _csv.writer(buf, delimiter=";", lineterminator="\n").writerows(rows)
+        semi[name] = os.path.join(tmp, name + "_semi.csv")
+        with open(semi[name], "w") as f:
+            f.write(buf.getvalue())
+        gz_write(buf.getvalue(), os.path.join(HERE, "synth2", name + "_semi.csv.gz"))
+    od = tempfile.mkdtemp()
+    files = run_cli(["-g", semi["gpa"], "-t", semi["traits"], "--no_pairwise", "-p", "0.2",
+                     "--delimiter", ";", "-m", "40"], od)
+    for fn, text in files.items():
+        gz_write(text, os.path.join(HERE, "synth2", "semicolon", fn + ".gz"))
+
+
+def vcf_cli(manifest):
+    """The non-Roary path through the command line: vcf2scoary output + `-s`."""
+    tmp = tempfile.mkdtemp()
+    mpa = os.path.join(tmp, "mpa.csv")
+    with gzip.open(os.path.join(HERE, "exampledata", "mutations_presence_absence.csv.gz"), "rt") as f, \
+            open(mpa, "w") as o:
+        o.write(f.read())
+    od = tempfile.mkdtemp()
+    files = run_cli(["-g", mpa, "-t", os.path.join(EX, "ExampleVCFTrait.csv"), "--no_pairwise",
+                     "-p", "1.0", "-s", str(manifest["vcf_startcol_1based"])], od)
+    for fn, text in files.items():
+        gz_write(text, os.path.join(HERE, "csv_vcf_cli", fn + ".gz"))
+    manifest["vcf_cli_files"] = sorted(files)
 
 
 def main():
@@ -474,6 +520,7 @@ def main():
                    "permutations": 100, "empirical_p": emp}, f, indent=1)
 
     tree_goldens(gd, td, prune, res, manifest)
+    vcf_cli(manifest)
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -310,3 +310,61 @@ def test_cli_second_dataset_vs_reference(synth2dir, tmp_path, sub, extra):
                 if r[k] != x[k]:
                     assert abs(float(r[k]) - float(x[k])) <= 1e-9 * abs(float(x[k])) + 1e-12 * 300, \
                         (r[0], g[0][k], r[k], x[k])
+
+
+def test_cli_restrict_write_reduced_and_input_columns(synth2dir, tmp_path):
+    """-r/-w/--include_input_columns: results and the reduced gene table written by
+    -w equal the reference's files."""
+    restrict = os.path.join(synth2dir, "restrict.csv")
+    with open(restrict, "w") as f:
+        f.write(golden_text("synth2/restrict.csv.gz"))
+    files = run_cli(["-g", os.path.join(synth2dir, "gpa.csv"), "-t", os.path.join(synth2dir, "traits.csv"),
+                     "--no_pairwise", "-p", "1.0", "-r", restrict, "-w",
+                     "--include_input_columns", "4,6-7"], tmp_path)
+    for fn, text in files.items():
+        want = golden_text("synth2/restrict_w/%s.gz" % fn)
+        assert text.splitlines()[0] == want.splitlines()[0]         # incl. the three extra columns
+        _assert_csv_equal(text, want)
+    with open(os.path.join(tmp_path, "gene_presence_absence_reduced.csv"), newline="") as f:
+        got = list(csv.reader(f))
+    want = list(csv.reader(io.StringIO(
+        golden_text("synth2/restrict_w/gene_presence_absence_reduced.csv.gz"))))
+    assert got == want
+
+
+def test_cli_semicolon_delimiter_and_max_hits(synth2dir, tmp_path):
+    for name in ("gpa_semi.csv", "traits_semi.csv"):
+        with open(os.path.join(synth2dir, name), "w", newline="") as f:
+            f.write(golden_text("synth2/%s.gz" % name))
+    files = run_cli(["-g", os.path.join(synth2dir, "gpa_semi.csv"),
+                     "-t", os.path.join(synth2dir, "traits_semi.csv"), "--no_pairwise", "-p", "0.2",
+                     "--delimiter", ";", "-m", "40"], tmp_path)
+    assert len(files) == 3
+    for fn, text in files.items():
+        want = golden_text("synth2/semicolon/%s.gz" % fn)
+        assert text.splitlines()[0] == want.splitlines()[0] and '";"' in text.splitlines()[0]
+        g = list(csv.reader(io.StringIO(text), delimiter=";"))
+        w = list(csv.reader(io.StringIO(want), delimiter=";"))
+        assert len(g) == len(w) <= 41 and g[0] == w[0]
+        wi = {r[0]: r for r in w[1:]}               # rows with (near-)equal p may swap places
+        for a in g[1:]:
+            b = wi[a[0]]
+            assert a[:7] == b[:7]
+            for x, y in zip(a[7:], b[7:]):
+                assert x == y or abs(float(x) - float(y)) <= 1e-12 * 300 + 1e-11 * abs(float(y))
+        ps = [float(r[10]) for r in g[1:]]
+        assert all(ps[i] <= ps[i + 1] * (1 + 1e-9) for i in range(len(ps) - 1))
+
+
+def test_cli_vcf_table_with_start_col(exampledir, tmp_path, manifest):
+    """vcf2scoary output through the command line (-s, non-Roary identifiers)."""
+    files = run_cli(["-g", os.path.join(exampledir, "mutations_presence_absence.csv"),
+                     "-t", os.path.join(exampledir, "ExampleVCFTrait.csv"), "--no_pairwise",
+                     "-p", "1.0", "-s", str(manifest["vcf_startcol_1based"])], tmp_path)
+    assert sorted(files) == manifest["vcf_cli_files"]
+    for fn, text in files.items():
+        want = golden_text("csv_vcf_cli/%s.gz" % fn)
+        g, w = text.splitlines(), want.splitlines()
+        assert g[0] == w[0] and len(g) == len(w)
+        # all rows tie at p = 1 / 0.5 here; compare as sets of rows
+        assert sorted(g[1:]) == sorted(w[1:])
