@@ -54,8 +54,9 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
  * back to back in `order`: genes sorted by descending list length, so that the
  * `genes_per_wave` genes a wavefront processes together (slots w*gpw ..) have
  * similar lengths and, after padding, the same number of 32-entry groups.
- * Within a list the positions are grouped by (position mod classes), slot k
- * starting with class k mod classes (LDS bank trick, see the kernel).
+ * Within a list, entry e of slot k is taken from residue class (k + e) mod
+ * classes of the positions, ascending within a class; when a class runs dry the
+ * next non-empty class of the rotation stands in (LDS bank trick, see the kernel).
  * With piece > 0 the lists of one wavefront group are interleaved in pieces of
  * `piece` entries -- entry e of the group's j-th gene sits at
  * group_base + ((e / piece) * genes_per_wave + j) * piece + e % piece -- so that

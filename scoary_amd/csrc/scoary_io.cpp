@@ -322,34 +322,41 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
   const int64_t W = (N + 63) / 64;
   std::vector<int32_t> len, order, padded;
   list_plan(rows64, G, N, genes_per_wave, len, order, padded, flipped);
-  // bit masks of the isolate positions congruent to c modulo `classes` (a power
-  // of two <= 64, so the pattern is the same in every 64-bit word)
-  std::vector<uint64_t> cmask(classes, 0);
-  for (int b = 0; b < 64; ++b) cmask[b % classes] |= (uint64_t)1 << b;
   int64_t pos = 0;          // piece == 0: next free entry; piece > 0: base of the wave group
   std::vector<uint32_t> one;
+  std::vector<std::vector<uint32_t>> byclass(classes);
+  std::vector<int64_t> taken(classes);
   for (int64_t k = 0; k < G; ++k) {
     const int64_t g = order[k];
     order_out[k] = (int32_t)g;
     const uint64_t* r = rows64 + g * W;
     const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
     ngroups[k] = (int32_t)(padded[k] / kListPad);
-    // The `classes` lane groups of a 32-lane half read the LDS label tile in
-    // lockstep, and a row's bank range is fixed by (isolate index mod classes).
-    // Slot k starts with the rows of class (k mod classes) and rotates through
-    // the classes, so the groups of a half hit disjoint banks.
+    // The genes of one LDS lane group read the label tile in lockstep, and a row's
+    // bank range is fixed by (isolate index mod classes).  Entry e of slot k is
+    // taken from residue class (k + e) mod classes -- ascending within a class --
+    // so at every step the genes of a group sit on distinct bank slots; when a
+    // class runs dry the next non-empty one in the rotation stands in.
     one.assign(padded[k], (uint32_t)(N * row_stride));          // padding -> the zero row
-    int64_t n = 0;
-    for (int64_t pass = 0; pass < classes; ++pass) {
-      const uint64_t sel = cmask[(k + pass) % classes];
-      for (int64_t w = 0; w < W; ++w) {
-        uint64_t bits = (r[w] ^ inv) & sel;
-        if (w == W - 1 && (N & 63)) bits &= (((uint64_t)1 << (N & 63)) - 1);
-        while (bits) {
-          const int b = __builtin_ctzll(bits);
-          bits &= bits - 1;
-          one[n++] = (uint32_t)((w * 64 + b) * row_stride);
-        }
+    for (auto& v : byclass) v.clear();
+    for (int64_t w = 0; w < W; ++w) {
+      uint64_t bits = r[w] ^ inv;
+      if (w == W - 1 && (N & 63)) bits &= (((uint64_t)1 << (N & 63)) - 1);
+      while (bits) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const int64_t pos_i = w * 64 + b;
+        byclass[pos_i % classes].push_back((uint32_t)(pos_i * row_stride));
+      }
+    }
+    {
+      int64_t n = 0;
+      const int64_t total_n = len[g];
+      std::fill(taken.begin(), taken.end(), 0);
+      for (int64_t e = 0; n < total_n; ++e) {
+        int64_t c = (k + e) % classes;
+        for (int64_t tries = 0; taken[c] >= (int64_t)byclass[c].size(); ++tries) c = (c + 1) % classes;
+        one[n++] = byclass[c][taken[c]++];
       }
     }
     if (piece <= 0) {                     // gene-contiguous

@@ -428,8 +428,8 @@ def test_io_library_exports_every_declared_symbol():
 def test_minority_lists_builder(gpw, classes, stride, piece):
     """scoary_lists_build (host native): per gene the positions of its minority
     value, padded with N to a multiple of 32 and to the wave group's longest list,
-    genes ordered by descending length, slot k starting with residue class
-    k mod classes (LDS bank trick), entries premultiplied by the row stride;
+    genes ordered by descending length, entry e of slot k from residue class
+    (k + e) mod classes (LDS bank trick), entries premultiplied by the row stride;
     piece > 0: the group's lists interleaved in pieces, last group stored in full."""
     from scoary_amd import io_native
     from scoary_amd.engine import pack_bits_rows
@@ -469,9 +469,9 @@ def test_minority_lists_builder(gpw, classes, stride, piece):
         assert np.all(pos[length[g]:] == N)                         # padding -> zero row
         want = np.nonzero(dense[g] == (0 if flipped[g] else 1))[0]
         assert sorted(real.tolist()) == want.tolist()
-        cls = real % classes                                        # classes in rotation order
-        rot = (cls - k) % classes
-        assert np.all(np.diff(rot) >= 0)
+        cls = real % classes                                        # round-robin over the classes
+        full = classes * min(np.bincount(cls, minlength=classes)) if len(real) else 0
+        assert np.array_equal(cls[:full], (k + np.arange(full)) % classes)
         for c in range(classes):
             sub = real[cls == c]
             assert np.all(np.diff(sub) > 0)                         # ascending within a class
