@@ -335,10 +335,15 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   const int tile_dwords = (N + 1) * TW;
   const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW);
   {
+    // tile -> LDS by LDS-DMA (global_load_lds_dwordx4): a wavefront moves 64 x 16 B
+    // per instruction straight into LDS (destination = wave-uniform base + 16*lane),
+    // no VGPR round trip and no ds_write pass
     const uint4* src4 = reinterpret_cast<const uint4*>(src);
-    uint4* dst4 = reinterpret_cast<uint4*>(tile_lds);
     const int n4 = tile_dwords / 4;
-    for (int i = tid; i < n4; i += blockDim.x) dst4[i] = src4[i];
+    for (int i = wave * kWave; i < n4; i += nwaves * kWave)
+      if (i + lane < n4)
+        __builtin_amdgcn_global_load_lds(src4 + i + lane, tile_lds + (size_t)i * 4, 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0);
   }
   __syncthreads();
 
