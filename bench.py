@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-LISTS_DEFAULT = True         # list-driven kernel: 9.5 ms vs 16.2 ms (dense) on the headline config
+LISTS_DEFAULT = True         # list-driven kernel: 4.9 ms vs 16.1 ms (dense) on the headline config
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (upper bound)
 INT_VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9   # integer/logic ops: 16 lanes/clk/SIMD at the nominal
@@ -112,6 +112,90 @@ def cpu_baseline(genes, traits, N, seed, target_s):
                       "permutations, %d OpenMP threads, %.1f s" % (Gs, N, T, Ps, cores, dt)}
 
 
+class Exchange:
+    """The path's one exchange step: the per-gene records of every shard are
+    gathered on rank 0 over RCCL/xGMI (north_star: "only an RCCL gather of
+    per-gene results").  It is issued asynchronously and drained before its
+    buffers are reused, so step i's gather overlaps step i+1's kernels; every
+    gather has completed before the closing barrier of the timed region."""
+
+    def __init__(self, torch, eng, world, rank, T, G):
+        from scoary_amd import dist as sdist
+        self.sdist, self.world, self.rank, self.G = sdist, world, rank, G
+        self.pending, self.step_no, self.kind = [], 0, "gather"
+        self.recv = [None, None]
+        if rank == 0:
+            self.recv = [torch.empty((world, T, G, sdist.REC_WORDS), dtype=torch.int32,
+                                     device=eng.device) for _ in range(2)]
+
+    def drain(self, keep=0):
+        while len(self.pending) > keep:
+            self.pending.pop(0)()
+
+    def submit(self, res):
+        sdist = self.sdist
+        self.drain(keep=1)
+        rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
+        if self.kind == "gather":
+            try:
+                _, finish = sdist.gather_genes(rec, self.G * self.world, dst=0, async_op=True,
+                                               recv=self.recv[self.step_no % 2])
+                self.pending.append(finish)
+            except (RuntimeError, NotImplementedError) as e:   # backend without gather
+                if self.rank == 0:
+                    print("bench: dist.gather unavailable (%s); using all_gather" % e,
+                          file=sys.stderr)
+                self.kind = "all_gather"
+        if self.kind == "all_gather":
+            res["gathered"] = sdist.all_gather_genes(rec, self.G * self.world)
+        self.step_no += 1
+
+
+def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
+    """The `roofline` object: operand-bandwidth model, measured HBM
+    traffic and VALU instruction count from the committed PMC passes."""
+    W64 = (N + 63) // 64
+    tests_per_launch = G * T * (P if use_lists else min(P, pbatch))
+    launches_per_step = 1 if use_lists else -(-P // pbatch)
+    alg_bytes = 16.0 * W64 * tests_per_launch        # SURVEY 8d: 16*W bytes / test
+    achieved = alg_bytes / (k3_ms * 1e-3) / 1e9
+    default_sizes = (args.genes is None and args.permutations is None
+                     and args.isolates is None and args.traits is None)
+    traffic, traffic_src, valu_insts = load_traffic(args.config, default_sizes, k3_name)
+    w32 = -(-N // 32)
+    valu_ops = tests_per_launch * (2.0 * w32 + 6)     # dense-kernel op model (reference point)
+    return {
+        "bound": "hbm",
+        "kernel": k3_name,
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024",
+        "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "model": "operand bytes 16*ceil(N/64) B per test (SURVEY 8d); frac > 1 means the "
+                 "kernel left the HBM-bound regime (operands reused from VGPR/SGPR)",
+        "kernel_ms": k3_ms,
+        "launches_per_step": launches_per_step,
+        "tests_per_s_kernel": tests_per_launch / (k3_ms * 1e-3),
+        "dense_model_valu_frac_of_2.4GHz_simd32_peak":
+            None if use_lists else valu_ops / (k3_ms * 1e-3) / VALU_LANE_OPS_PER_S,
+        # what actually binds: integer-VALU issue (SURVEY 8d, figure iii).  Instruction
+        # count from the committed SQ_INSTS_VALU pass, duration measured live; the
+        # ceiling is 256 CU x 4 SIMD x 16 lanes/clk x the nominal 2.4 GHz for
+        # v_and / v_bcnt / v_bitop3 (tools/valu_peak.hip measures 3.8-4.1e13).
+        "valu": None if not valu_insts else {
+            "wave_insts_per_launch": valu_insts,
+            "ops_per_test": valu_insts * 64.0 / tests_per_launch,
+            "lane_ops_per_s": valu_insts * 64.0 / (k3_ms * 1e-3),
+            "peak_lane_ops_per_s": INT_VALU_LANE_OPS_PER_S,
+            "frac": valu_insts * 64.0 / (k3_ms * 1e-3) / INT_VALU_LANE_OPS_PER_S,
+            "source": traffic_src},
+    }
+
+
 def main():
     args = parse()
     import torch
@@ -156,49 +240,18 @@ def main():
         eng.build_lists(gm, pack_bits_rows(genes))    # once per dataset, like the packing
     pbatch = eng.perm_batch(T, N, P)
     perm_buf = torch.empty((T, pbatch, eng.row_words(N)), dtype=torch.int32, device=eng.device)
-    from scoary_amd import dist as sdist
-
-    # The path's one exchange step: the per-gene records of every shard are
-    # gathered on rank 0 over RCCL/xGMI (north_star: "only an RCCL gather of
-    # per-gene results").  It is issued asynchronously and drained before its
-    # buffers are reused, so step i's gather overlaps step i+1's kernels; every
-    # gather has completed before the closing barrier of the timed region.
-    pending = []
-    recv_bufs = [None, None]
-    if sharded and rank == 0:
-        recv_bufs = [torch.empty((world, T, G, sdist.REC_WORDS), dtype=torch.int32,
-                                 device=eng.device) for _ in range(2)]
-    step_no = [0]
-    exchange = ["gather"]
-
-    def drain(keep=0):
-        while len(pending) > keep:
-            pending.pop(0)()
+    exchange = Exchange(torch, eng, world, rank, T, G) if sharded else None
 
     def step():
         res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, perm_buffer=perm_buf,
                             use_lists=use_lists)
-        if sharded:
-            drain(keep=1)
-            rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
-            if exchange[0] == "gather":
-                try:
-                    _, finish = sdist.gather_genes(rec, G * world, dst=0, async_op=True,
-                                                   recv=recv_bufs[step_no[0] % 2])
-                    pending.append(finish)
-                except (RuntimeError, NotImplementedError) as e:   # backend without gather
-                    if rank == 0:
-                        print("bench: dist.gather unavailable (%s); using all_gather" % e,
-                              file=sys.stderr)
-                    exchange[0] = "all_gather"
-            if exchange[0] == "all_gather":
-                res["gathered"] = sdist.all_gather_genes(rec, G * world)
-            step_no[0] += 1
+        if exchange:
+            exchange.submit(res)
         return res
 
     def barrier():
-        drain()
-        if sharded:
+        if exchange:
+            exchange.drain()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -208,7 +261,7 @@ def main():
     eng.set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        step()
     barrier()
     dt = time.perf_counter() - t0
     k3_name = "k_permute_lists" if use_lists else "k_permute"
@@ -219,30 +272,15 @@ def main():
     kernel_ms = {k: eng.kernel_ms(k) for k in names}
     eng.set_timing(False)
 
-    if sharded:
+    if sharded:                                      # MAX over ranks
         tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    tests_per_step = G * T * P * world
-    value = tests_per_step * args.steps / dt
-
     if rank == 0:
-        W64 = (N + 63) // 64
-        launches_per_step = -(-P // pbatch)
-        tests_per_launch = G * T * (P if use_lists else min(P, pbatch))
-        if use_lists:
-            launches_per_step = 1
-        alg_bytes = 16.0 * W64 * tests_per_launch        # 16*W bytes / test
-        achieved = alg_bytes / (k3_ms * 1e-3) / 1e9
-        traffic, traffic_src, valu_insts = load_traffic(
-            args.config, args.genes is None and args.permutations is None
-            and args.isolates is None and args.traits is None, k3_name)
-        w32 = -(-N // 32)
-        valu_ops = tests_per_launch * (2.0 * w32 + 6)     # dense-kernel op model (reference point)
         out = {
             "metric": "gene x permutation Fisher tests/sec",
-            "value": value,
+            "value": G * T * P * world * args.steps / dt,
             "unit": "tests/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -258,38 +296,9 @@ def main():
                                    % (args.config, G, N, T, P),
                        "genes_per_gpu": G, "isolates": N, "traits": T, "permutations": P,
                        "parallelism": "gene-shard x%d" % world,
-                       "exchange": ("rccl %s of per-gene records" % exchange[0]) if sharded
+                       "exchange": ("rccl %s of per-gene records" % exchange.kind) if exchange
                        else "none (single GPU)"},
-            "roofline": {
-                "bound": "hbm",
-                "kernel": k3_name,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024",
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "model": "operand bytes 16*ceil(N/64) B per test (SURVEY 8d); frac > 1 means the "
-                         "kernel left the HBM-bound regime (operands reused from VGPR/SGPR)",
-                "kernel_ms": k3_ms,
-                "launches_per_step": launches_per_step,
-                "tests_per_s_kernel": tests_per_launch / (k3_ms * 1e-3),
-                "dense_model_valu_frac_of_2.4GHz_simd32_peak":
-                    None if use_lists else valu_ops / (k3_ms * 1e-3) / VALU_LANE_OPS_PER_S,
-                # what actually binds: integer-VALU issue (figure iii).  Instruction
-                # count from the committed SQ_INSTS_VALU pass, duration measured live; the
-                # ceiling is tools/valu_peak.hip's measured 4.0e13 lane-ops/s
-                # (= 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz for v_and/v_bcnt/v_bitop3).
-                "valu": None if not valu_insts else {
-                    "wave_insts_per_launch": valu_insts,
-                    "ops_per_test": valu_insts * 64.0 / tests_per_launch,
-                    "lane_ops_per_s": valu_insts * 64.0 / (k3_ms * 1e-3),
-                    "peak_lane_ops_per_s": INT_VALU_LANE_OPS_PER_S,
-                    "frac": valu_insts * 64.0 / (k3_ms * 1e-3) / INT_VALU_LANE_OPS_PER_S,
-                    "source": traffic_src},
-            },
+            "roofline": roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms),
             "kernel_ms": kernel_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
