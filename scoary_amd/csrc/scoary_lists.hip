@@ -347,13 +347,6 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   }
   __syncthreads();
 
-  uint32_t valid[4];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const int64_t p_first = ((int64_t)tile * TW + 4 * col + w) * 32;
-    valid[w] = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
-  }
-
   const int ngroups = (G + GPW - 1) / GPW;         // wave groups of GPW genes
   const int q_lo = blockIdx.y * groups_per_block;
   const int q_hi = min(ngroups, q_lo + groups_per_block);
@@ -449,6 +442,12 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
     const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
     const uint32_t always = (cr.y >> 31) ? 0xffffffffu : 0u;
+    uint32_t valid[4];                                // permutations of this tile that exist
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int64_t p_first = ((int64_t)tile * TW + 4 * col + w) * 32;
+      valid[w] = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
+    }
     int cnt = 0;
     cnt += __popc((((~region_lt<KC, KD>(c0, base, span)) ^ inv) | always) & valid[0]);
     cnt += __popc((((~region_lt<KC, KD>(c1, base, span)) ^ inv) | always) & valid[1]);
