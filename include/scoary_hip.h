@@ -131,10 +131,11 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
 
 /* ---- a7/a8, list-driven variant -------------------------------------------
  * Same result as scoary_perm_generate + scoary_permute (d_r is bit-identical),
- * different data flow: genes as ascending lists of the isolates that carry
- * their minority value (built once per dataset by scoary_lists_build,
- * include/scoary_io.h), permuted labels as isolate-major tiles of 512
- * permutations that live in LDS, overlap counts as bit-sliced counters.  Cost
+ * different data flow: genes as lists of the isolates that carry their
+ * minority value (built once per dataset by scoary_lists_build,
+ * include/scoary_io.h), permuted labels as isolate-major tiles of 512 / 256 /
+ * 128 permutations (N <= 2559 / 5119 / 10239) that live in LDS, overlap
+ * counts as bit-sliced counters, 128 permutations per lane.  Cost
  * is proportional to the list length, so sparse (or near-core) genes are
  * cheap.  Available while a tile fits in LDS: N <= scoary_list_max_isolates().
  *   d_tiles : uint32 [scoary_list_tiles_words(N, P, T)]
