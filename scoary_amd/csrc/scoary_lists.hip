@@ -142,9 +142,9 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
 // wavefronts than the chip has SIMDs (few traits x permutations, long rows): the
 // sampling is serial over the isolates only in `needed` (two dependent VALU ops
 // per isolate) while the Philox draws are not, so kGenProducers wavefronts
-// compute the draws one 64-isolate chunk ahead into LDS (lane = permutation in
-// every wavefront) and ONE selection wavefront walks the chunk; its compare
-// mask over the 64 lanes IS the tile row of that isolate.
+// compute umulhi(draw, valid isolates left) one 64-isolate chunk ahead into LDS
+// (lane = permutation in every wavefront) and ONE selection wavefront walks the
+// chunk; its compare mask over the 64 lanes IS the tile row of that isolate.
 constexpr int kGenProducers = 7;
 constexpr int kGenSplitBelow = 1;  // workgroup variant below this many wavefronts per SIMD
 constexpr int kGenChunk = 64;      // isolates per LDS buffer = 16 Philox counters
@@ -160,25 +160,26 @@ template <int LANE>
 __device__ __forceinline__ void write_lane(uint32_t& v, uint32_t value) {
   asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(value), "n"(LANE));
 }
-// Spec-S4 selection for isolates II.. of a chunk: u = the lane's draws, rem0 =
-// valid isolates left at the chunk's start, mw = its validity bits (both
-// wave-uniform; ALLVALID: mw is all ones), livemask = lanes whose permutation exists.
+// Spec-S4 selection for isolates II.. of a chunk: x[i] = umulhi(draw, valid isolates
+// left at i) as the producers stored it, mw = the chunk's validity bits
+// (wave-uniform; ALLVALID: all ones), livemask = lanes whose permutation exists.
+// The AND with livemask also makes the written value the result of a SALU op:
+// v_writelane_b32 sits in inline asm, where the compiler cannot see (and pad) the
+// gfx950 wait states between a VALU compare writing an SGPR and a VALU reading it.
 template <int II, bool ALLVALID>
-__device__ __forceinline__ void select_rows(const uint32_t (&u)[kGenChunk], uint32_t rem0,
-                                            uint64_t mw, uint64_t livemask, uint32_t& needed,
-                                            uint32_t& lo, uint32_t& hi) {
+__device__ __forceinline__ void select_rows(const uint32_t (&x)[kGenChunk], uint64_t mw,
+                                            uint64_t livemask, uint32_t& needed, uint32_t& lo,
+                                            uint32_t& hi) {
   if constexpr (II < kGenChunk) {
     uint64_t b = 0;
     if (ALLVALID || ((mw >> II) & 1u)) {               // wave-uniform
-      const uint32_t rem =
-          ALLVALID ? rem0 - II : rem0 - (uint32_t)__popcll(mw & (((uint64_t)1 << II) - 1));
-      const bool hit = __umulhi(u[II], rem) < needed;
+      const bool hit = x[II] < needed;
       needed -= hit ? 1u : 0u;
       b = __builtin_amdgcn_ballot_w64(hit) & livemask;
     }
     write_lane<II>(lo, (uint32_t)b);                 // lane l: the row of isolate l of the chunk
     write_lane<II>(hi, (uint32_t)(b >> 32));
-    select_rows<II + 1, ALLVALID>(u, rem0, mw, livemask, needed, lo, hi);
+    select_rows<II + 1, ALLVALID>(x, mw, livemask, needed, lo, hi);
   }
 }
 
@@ -199,14 +200,22 @@ __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_til
   const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
   uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG) + col;
   uint32_t needed = (uint32_t)margins[2 * t];
+  const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
+  // valid isolates left at the start of the chunk this wavefront works on
+  // (producers run one chunk ahead of the selection wavefront)
   uint32_t remaining = (uint32_t)__builtin_amdgcn_readfirstlane(margins[2 * t + 1]);
   const uint32_t* mrow = masks + (int64_t)t * Wp;     // Wp >= 2*nchunks words, zero padded
   const int nchunks = (N + kGenChunk - 1) / kGenChunk;
-  const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
+  auto chunk_mask = [&](int c) -> uint64_t {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * c]) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * c + 1]) << 32;
+  };
   if (role == 0) __builtin_amdgcn_s_setprio(3);       // the serial wavefront goes first
   for (int c = 0; c <= nchunks; ++c) {
     if (role > 0) {
       if (c < nchunks) {
+        const uint64_t mw = chunk_mask(c);
+        const uint32_t rem0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)remaining);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const int jj = kGenWork[role - 1][k];
@@ -215,23 +224,25 @@ __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_til
           philox4x32_10((uint32_t)(c * (kGenChunk / 4) + jj), pi, (uint32_t)(trait_base + t),
                         kPermDomain, k0, k1, r);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) draws[c & 1][4 * jj + q][lane] = r[q];
+          for (int q = 0; q < 4; ++q) {             // the quarter-rate multiply moves here too
+            const int ii = 4 * jj + q;
+            const uint32_t rem = rem0 - (uint32_t)__popcll(mw & (((uint64_t)1 << ii) - 1));
+            draws[c & 1][ii][lane] = __umulhi(r[q], rem);
+          }
         }
+        remaining -= (uint32_t)__popcll(mw);
       }
     } else if (c > 0) {
       const int cc = c - 1;
-      const uint64_t mw = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * cc]) |
-                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * cc + 1]) << 32;
-      const uint32_t rem0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)remaining);
-      uint32_t u[kGenChunk];
+      const uint64_t mw = chunk_mask(cc);
+      uint32_t x[kGenChunk];
 #pragma unroll
-      for (int ii = 0; ii < kGenChunk; ++ii) u[ii] = draws[cc & 1][ii][lane];
+      for (int ii = 0; ii < kGenChunk; ++ii) x[ii] = draws[cc & 1][ii][lane];
       uint32_t lo = 0u, hi = 0u;
       if (mw == ~(uint64_t)0)
-        select_rows<0, true>(u, rem0, mw, livemask, needed, lo, hi);
+        select_rows<0, true>(x, mw, livemask, needed, lo, hi);
       else
-        select_rows<0, false>(u, rem0, mw, livemask, needed, lo, hi);
-      remaining -= (uint32_t)__popcll(mw);
+        select_rows<0, false>(x, mw, livemask, needed, lo, hi);
       const int row = cc * kGenChunk + lane;
       if (row < N) {
         base[(int64_t)row * LG] = lo;
