@@ -322,58 +322,78 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
   const int64_t W = (N + 63) / 64;
   std::vector<int32_t> len, order, padded;
   list_plan(rows64, G, N, genes_per_wave, len, order, padded, flipped);
-  int64_t pos = 0;          // piece == 0: next free entry; piece > 0: base of the wave group
-  std::vector<uint32_t> one;
-  std::vector<std::vector<uint32_t>> byclass(classes);
-  std::vector<int64_t> taken(classes);
-  for (int64_t k = 0; k < G; ++k) {
-    const int64_t g = order[k];
-    order_out[k] = (int32_t)g;
-    const uint64_t* r = rows64 + g * W;
-    const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
-    ngroups[k] = (int32_t)(padded[k] / kListPad);
-    // The genes of one LDS lane group read the label tile in lockstep, and a row's
-    // bank range is fixed by (isolate index mod classes).  Entry e of slot k is
-    // taken from residue class (k + e) mod classes -- ascending within a class --
-    // so at every step the genes of a group sit on distinct bank slots; when a
-    // class runs dry the next non-empty one in the rotation stands in.
-    one.assign(padded[k], (uint32_t)(N * row_stride));          // padding -> the zero row
-    for (auto& v : byclass) v.clear();
-    for (int64_t w = 0; w < W; ++w) {
-      uint64_t bits = r[w] ^ inv;
-      if (w == W - 1 && (N & 63)) bits &= (((uint64_t)1 << (N & 63)) - 1);
-      while (bits) {
-        const int b = __builtin_ctzll(bits);
-        bits &= bits - 1;
-        const int64_t pos_i = w * 64 + b;
-        byclass[pos_i % classes].push_back((uint32_t)(pos_i * row_stride));
+  // first entry of every slot (piece == 0) or of every wave group (piece > 0)
+  const int64_t nwg = (G + genes_per_wave - 1) / genes_per_wave;
+  std::vector<int64_t> base(piece > 0 ? nwg + 1 : G + 1, 0);
+  if (piece > 0)
+    for (int64_t q = 0; q < nwg; ++q) base[q + 1] = base[q] + genes_per_wave * padded[q * genes_per_wave];
+  else
+    for (int64_t k = 0; k < G; ++k) base[k + 1] = base[k] + padded[k];
+  const uint32_t zero_row = (uint32_t)(N * row_stride);
+  const int64_t cmask = classes - 1;                 // classes is a power of two
+#pragma omp parallel
+  {
+    std::vector<uint32_t> tmp(N + 1), sorted(N + 1), one;   // positions: ascending / by class / as emitted
+    std::vector<int64_t> first(classes + 1), taken(classes);
+#pragma omp for schedule(dynamic, 8)
+    for (int64_t q = 0; q < nwg; ++q) {
+      for (int64_t j = 0; j < genes_per_wave; ++j) {
+        const int64_t k = q * genes_per_wave + j;
+        if (k >= G) {                                 // missing genes of the last group: all padding
+          if (piece > 0) {
+            const int64_t L = padded[q * genes_per_wave];
+            for (int64_t pc = 0; pc < L / piece; ++pc)
+              for (int64_t x = 0; x < piece; ++x)
+                idx[base[q] + (pc * genes_per_wave + j) * piece + x] = zero_row;
+          }
+          continue;
+        }
+        const int64_t g = order[k];
+        order_out[k] = (int32_t)g;
+        ngroups[k] = (int32_t)(padded[k] / kListPad);
+        start[k] = (int32_t)((piece > 0 ? base[q] : base[k]) / kListPad);
+        const uint64_t* r = rows64 + g * W;
+        const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
+        // The genes of one LDS lane group read the label tile in lockstep, and a
+        // row's bank range is fixed by (isolate index mod classes).  Entry e of
+        // slot k is taken from residue class (k + e) mod classes -- ascending
+        // within a class -- so at every step the genes of a group sit on distinct
+        // bank slots; when a class runs dry the next non-empty one stands in.
+        std::fill(first.begin(), first.end(), 0);     // counting sort by class
+        int64_t nt = 0;
+        for (int64_t w = 0; w < W; ++w) {
+          uint64_t bits = r[w] ^ inv;
+          if (w == W - 1 && (N & 63)) bits &= (((uint64_t)1 << (N & 63)) - 1);
+          while (bits) {
+            const int b = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const uint32_t pos_i = (uint32_t)(w * 64 + b);
+            tmp[nt++] = pos_i;
+            ++first[(pos_i & cmask) + 1];
+          }
+        }
+        for (int64_t c = 0; c < classes; ++c) first[c + 1] += first[c];
+        std::copy(first.begin(), first.begin() + classes, taken.begin());
+        for (int64_t i = 0; i < nt; ++i)
+          sorted[taken[tmp[i] & cmask]++] = (uint32_t)(tmp[i] * row_stride);
+        const int64_t total_n = len[g], L = padded[k];
+        one.assign(L, zero_row);                      // padding -> the zero row
+        std::copy(first.begin(), first.begin() + classes, taken.begin());
+        int64_t c = k & cmask;
+        for (int64_t n = 0; n < total_n; ++n) {
+          int64_t cc = c;
+          while (taken[cc] >= first[cc + 1]) cc = (cc + 1) & cmask;
+          one[n] = sorted[taken[cc]++];
+          c = (c + 1) & cmask;
+        }
+        if (piece <= 0) {                             // gene-contiguous
+          std::memcpy(idx + base[k], one.data(), (size_t)L * sizeof(uint32_t));
+        } else {                                      // pieces of the group's genes interleaved
+          for (int64_t pc = 0; pc < L / piece; ++pc)
+            std::memcpy(idx + base[q] + (pc * genes_per_wave + j) * piece, one.data() + pc * piece,
+                        (size_t)piece * sizeof(uint32_t));
+        }
       }
-    }
-    {
-      int64_t n = 0;
-      const int64_t total_n = len[g];
-      std::fill(taken.begin(), taken.end(), 0);
-      for (int64_t e = 0; n < total_n; ++e) {
-        int64_t c = (k + e) % classes;
-        for (int64_t tries = 0; taken[c] >= (int64_t)byclass[c].size(); ++tries) c = (c + 1) % classes;
-        one[n++] = byclass[c][taken[c]++];
-      }
-    }
-    if (piece <= 0) {                     // gene-contiguous
-      start[k] = (int32_t)(pos / kListPad);
-      std::memcpy(idx + pos, one.data(), one.size() * sizeof(uint32_t));
-      pos += padded[k];
-    } else {                              // pieces of the group's genes interleaved
-      const int64_t j = k % genes_per_wave, L = padded[k];
-      start[k] = (int32_t)(pos / kListPad);
-      for (int64_t e = 0; e < L; ++e)
-        idx[pos + ((e / piece) * genes_per_wave + j) * piece + e % piece] = one[e];
-      if (k == G - 1)                     // missing genes of the last group: all padding
-        for (int64_t jj = j + 1; jj < genes_per_wave; ++jj)
-          for (int64_t e = 0; e < L; ++e)
-            idx[pos + ((e / piece) * genes_per_wave + jj) * piece + e % piece] =
-                (uint32_t)(N * row_stride);
-      if (j == genes_per_wave - 1) pos += genes_per_wave * L;
     }
   }
 }
