@@ -26,6 +26,10 @@ typedef struct scoary_gpa *scoary_gpa_t;
  * Return 0 or a negative error; message via scoary_gpa_error. */
 int scoary_gpa_open(const char *path, char delimiter, int64_t startcol, scoary_gpa_t *out);
 int scoary_gpa_parse(scoary_gpa_t g, const uint8_t *keep);
+/* The same with an explicit thread count and minimum bytes per thread: the body is cut at
+ * line ends into ranges parsed in parallel; if a cut turns out to lie inside a quoted
+ * cell (a range does not stop where the next one starts) the body is parsed in one piece. */
+int scoary_gpa_parse_mt(scoary_gpa_t g, const uint8_t *keep, int64_t threads, int64_t min_chunk);
 void scoary_gpa_close(scoary_gpa_t g);
 const char *scoary_gpa_error(scoary_gpa_t g);
 

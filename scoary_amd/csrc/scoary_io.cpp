@@ -10,6 +10,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -37,8 +40,14 @@ namespace {
 // unquoted content of every cell.  Returns false at end of input.  A state
 // machine equivalent to CPython's _csv reader for the excel dialect with
 // skipinitialspace (text mode: \r\n and \r read as \n, also inside quotes).
+struct Cursor {
+  const char* data;
+  size_t size, pos;
+  char delim;
+};
+
 template <class Sink>
-bool read_record(scoary_gpa* g, std::string& scratch, Sink&& sink) {
+bool read_record(Cursor* g, std::string& scratch, Sink&& sink) {
   const char* d = g->data;
   const size_t n = g->size;
   size_t p = g->pos;
@@ -173,7 +182,11 @@ int scoary_gpa_open(const char* path, char delimiter, int64_t startcol, scoary_g
   madvise(m, g->size, MADV_SEQUENTIAL);
   g->data = static_cast<const char*>(m);
   std::string scratch;
-  if (!read_record(g, scratch, [&](int64_t, const char* p, size_t n) { g->header.emplace_back(p, n); })) {
+  Cursor cur{g->data, g->size, g->pos, g->delim};
+  const bool got_header =
+      read_record(&cur, scratch, [&](int64_t, const char* p, size_t n) { g->header.emplace_back(p, n); });
+  g->pos = cur.pos;
+  if (!got_header) {
     g->err = "no header";
     return -3;
   }
@@ -184,7 +197,74 @@ int scoary_gpa_open(const char* path, char delimiter, int64_t startcol, scoary_g
   return 0;
 }
 
-int scoary_gpa_parse(scoary_gpa_t g, const uint8_t* keep) {
+namespace {
+// Rows parsed from one byte range of the body.
+struct Piece {
+  std::vector<uint64_t> bits;
+  std::vector<int32_t> meta_len;
+  std::string meta;
+  int64_t rows = 0;
+  int64_t bad_cells = -1;   // >= 0: the row after `rows` has this many cells (< header cells)
+  size_t stop = 0;          // start of the first record not consumed
+};
+
+// Parses the records that START in [begin, limit).
+void parse_range(const scoary_gpa* g, const std::vector<int32_t>& slot, size_t begin, size_t limit,
+                 Piece* out) {
+  const int64_t ncols = (int64_t)g->header.size(), sc = g->startcol, nstr = ncols - sc;
+  const size_t words = (size_t)g->words;
+  Cursor cur{g->data, g->size, begin, g->delim};
+  std::string scratch;
+  while (cur.pos < limit) {
+    const size_t base = out->bits.size();
+    out->bits.resize(base + words, 0);
+    const size_t meta_base = out->meta_len.size();
+    out->meta_len.resize(meta_base + (size_t)sc, -1);
+    int64_t cells = 0;
+    uint64_t* row = out->bits.data() + base;
+    const bool got = read_record(&cur, scratch, [&](int64_t col, const char* p, size_t n) {
+      ++cells;
+      if (col < sc) {
+        out->meta_len[meta_base + (size_t)col] = (int32_t)n;
+        out->meta.append(p, n);
+      } else if (col - sc < nstr) {
+        const int32_t b = slot[col - sc];
+        if (b >= 0) {
+          const bool absent = n == 0 || (n == 1 && (p[0] == '0' || p[0] == '-'));
+          if (!absent) row[b >> 6] |= (uint64_t)1 << (b & 63);
+        }
+      }
+    });
+    if (!got || cells < ncols) {
+      out->bits.resize(base);
+      out->meta_len.resize(meta_base);
+      if (got) out->bad_cells = cells;   // the reference indexes q[startcol + strain]: IndexError -> exit
+      break;
+    }
+    ++out->rows;
+  }
+  out->stop = cur.pos;
+}
+
+// Record starts for `k` ranges of the body: the guessed cuts are moved to the
+// character after the next line end.  A cut that falls inside a quoted cell is
+// caught later: the range before it then does not stop exactly there.
+std::vector<size_t> guess_cuts(const scoary_gpa* g, size_t body, int64_t k) {
+  std::vector<size_t> cuts{body};
+  const size_t total = g->size - body;
+  for (int64_t i = 1; i < k; ++i) {
+    size_t q = body + (size_t)((double)total * (double)i / (double)k);
+    while (q < g->size && g->data[q] != '\n' && g->data[q] != '\r') ++q;
+    if (q >= g->size) break;
+    q = (g->data[q] == '\r' && q + 1 < g->size && g->data[q + 1] == '\n') ? q + 2 : q + 1;
+    if (q > cuts.back() && q < g->size) cuts.push_back(q);
+  }
+  cuts.push_back(g->size);
+  return cuts;
+}
+}  // namespace
+
+int scoary_gpa_parse_mt(scoary_gpa_t g, const uint8_t* keep, int64_t threads, int64_t min_chunk) {
   if (!g || !g->data) return -1;
   const int64_t ncols = (int64_t)g->header.size();
   const int64_t nstr = ncols - g->startcol;
@@ -198,41 +278,48 @@ int scoary_gpa_parse(scoary_gpa_t g, const uint8_t* keep) {
   g->bits.clear();
   g->meta_len.clear();
   g->meta.clear();
-  std::string scratch;
-  const int64_t sc = g->startcol;
-  for (;;) {
-    const size_t base = g->bits.size();
-    g->bits.resize(base + (size_t)g->words, 0);
-    const size_t meta_base = g->meta_len.size();
-    g->meta_len.resize(meta_base + (size_t)sc, -1);
-    int64_t cells = 0;
-    uint64_t* row = g->bits.data() + base;
-    const bool got = read_record(g, scratch, [&](int64_t col, const char* p, size_t n) {
-      ++cells;
-      if (col < sc) {
-        g->meta_len[meta_base + (size_t)col] = (int32_t)n;
-        g->meta.append(p, n);
-      } else if (col - sc < nstr) {
-        const int32_t b = slot[col - sc];
-        if (b >= 0) {
-          const bool absent = n == 0 || (n == 1 && (p[0] == '0' || p[0] == '-'));
-          if (!absent) row[b >> 6] |= (uint64_t)1 << (b & 63);
-        }
-      }
-    });
-    if (!got) {
-      g->bits.resize(base);
-      g->meta_len.resize(meta_base);
-      break;
-    }
-    if (cells < ncols) {  // the reference indexes q[startcol + strain]: IndexError -> exit
-      g->err = "row " + std::to_string(g->rows + 2) + " has " + std::to_string(cells) +
+  const size_t body = g->pos;
+  if (min_chunk < 1) min_chunk = 1;
+  int64_t k = (int64_t)((g->size - body) / (size_t)min_chunk);
+  if (k > threads) k = threads;
+  if (k < 1) k = 1;
+  std::vector<size_t> cuts = guess_cuts(g, body, k);
+  std::vector<Piece> pieces(cuts.size() - 1);
+#pragma omp parallel for schedule(static, 1) num_threads((int)pieces.size())
+  for (int64_t i = 0; i < (int64_t)pieces.size(); ++i)
+    parse_range(g, slot, cuts[i], cuts[i + 1], &pieces[i]);
+  // a range must stop exactly where the next one started (or at its own bad row);
+  // otherwise a guessed cut was inside a quoted cell: parse in one piece instead
+  bool ok = true;
+  for (size_t i = 0; i + 1 < pieces.size() && ok; ++i) {
+    if (pieces[i].bad_cells >= 0) break;
+    ok = pieces[i].stop == cuts[i + 1];
+  }
+  if (!ok) {
+    pieces.assign(1, Piece());
+    parse_range(g, slot, body, g->size, &pieces[0]);
+  }
+  for (auto& pc : pieces) {
+    g->bits.insert(g->bits.end(), pc.bits.begin(), pc.bits.end());
+    g->meta_len.insert(g->meta_len.end(), pc.meta_len.begin(), pc.meta_len.end());
+    g->meta.append(pc.meta);
+    g->rows += pc.rows;
+    if (pc.bad_cells >= 0) {
+      g->err = "row " + std::to_string(g->rows + 2) + " has " + std::to_string(pc.bad_cells) +
                " cells, header has " + std::to_string(ncols);
       return -5;
     }
-    ++g->rows;
   }
   return 0;
+}
+
+int scoary_gpa_parse(scoary_gpa_t g, const uint8_t* keep) {
+  int64_t threads = 1;
+#ifdef _OPENMP
+  threads = omp_get_max_threads();
+  if (threads > 32) threads = 32;
+#endif
+  return scoary_gpa_parse_mt(g, keep, threads, (int64_t)8 << 20);
 }
 
 void scoary_gpa_close(scoary_gpa_t g) {

@@ -23,6 +23,7 @@ def _load():
         vp, i64 = ctypes.c_void_p, ctypes.c_int64
         L.scoary_gpa_open.argtypes = [ctypes.c_char_p, ctypes.c_char, i64, ctypes.POINTER(vp)]
         L.scoary_gpa_parse.argtypes = [vp, vp]
+        L.scoary_gpa_parse_mt.argtypes = [vp, vp, i64, i64]
         L.scoary_gpa_close.argtypes = [vp]
         L.scoary_gpa_close.restype = None
         L.scoary_gpa_error.argtypes = [vp]
@@ -91,11 +92,13 @@ class GpaError(Exception):
     pass
 
 
-def read_gpa(path, delimiter, startcol, allowed=None):
+def read_gpa(path, delimiter, startcol, allowed=None, threads=None, min_chunk=8 << 20):
     """-> (header, meta_rows, rows64, kept_strains): the file's header cells,
     for every data row the text of columns [0, startcol), the presence bits of
     the kept strain columns as rows64, and the kept strain names.  ``allowed``:
-    None or a container of isolate names (methods.py:416-420, 473-475)."""
+    None or a container of isolate names (methods.py:416-420, 473-475).
+    ``threads`` / ``min_chunk``: parallel body parse (scoary_gpa_parse_mt); the
+    default lets the library use its OpenMP thread count."""
     L = _load()
     h = ctypes.c_void_p()
     rc = L.scoary_gpa_open(os.fsencode(path), delimiter.encode()[0:1], int(startcol),
@@ -112,8 +115,11 @@ def read_gpa(path, delimiter, startcol, allowed=None):
         keep = None
         if allowed is not None:
             keep = np.array([1 if s in allowed else 0 for s in strains], dtype=np.uint8)
-        rc = L.scoary_gpa_parse(h, keep.ctypes.data_as(ctypes.c_void_p) if keep is not None
-                                else None)
+        kp = keep.ctypes.data_as(ctypes.c_void_p) if keep is not None else None
+        if threads is None:
+            rc = L.scoary_gpa_parse(h, kp)
+        else:
+            rc = L.scoary_gpa_parse_mt(h, kp, int(threads), int(min_chunk))
         if rc != 0:
             raise GpaError(L.scoary_gpa_error(h).decode())
         R, W = L.scoary_gpa_rows(h), L.scoary_gpa_words(h)

@@ -339,6 +339,44 @@ def test_native_reader_tokenises_like_python_csv(tmp_path, k):
     assert kept == rows[0][3:]
 
 
+@pytest.mark.parametrize("threads,min_chunk", [(4, 1), (7, 50), (3, 1000), (64, 1)])
+def test_native_reader_parallel_body_parse(tmp_path, threads, min_chunk):
+    """scoary_gpa_parse_mt cuts the body at line ends and parses the ranges in
+    parallel; cuts that land inside quoted multi-line cells are detected and the
+    body is then parsed in one piece.  Same result as one thread, every time."""
+    from conftest import golden_text
+    from scoary_amd import io_native
+    rng = np.random.default_rng(8)
+    texts = [golden_text("synth2/gpa.csv.gz"),
+             golden_text("exampledata/Gene_presence_absence.csv.gz")[:200000].rsplit("\n", 1)[0] + "\n"]
+    # a table whose quoted cells contain line breaks (every few rows), CRLF line ends
+    rows = ['"Gene","b","c",' + ",".join('"s%d"' % i for i in range(9))]
+    for r in range(120):
+        cells = ["x" if rng.random() < 0.5 else "" for _ in range(9)]
+        note = '"multi\nline\r\ncell %d"' % r if r % 3 == 0 else '"plain %d"' % r
+        rows.append('"g%d",%s,"c",%s' % (r, note, ",".join(cells)))
+    texts.append("\r\n".join(rows) + "\r\n")
+    for k, text in enumerate(texts):
+        path = tmp_path / ("t%d.csv" % k)
+        path.write_text(text, newline="")
+        startcol = 3 if k == 2 else 14
+        one = io_native.read_gpa(str(path), ",", startcol, threads=1)
+        many = io_native.read_gpa(str(path), ",", startcol, threads=threads, min_chunk=min_chunk)
+        assert one[0] == many[0] and one[1] == many[1] and one[3] == many[3]
+        assert np.array_equal(one[2], many[2]) and one[2].shape[0] > 100
+    # a short row is reported with the same row number whatever the cut positions
+    short = list(rows)
+    short[78] = '"g77","c"'                                   # record 79 of the file: two cells only
+    path = tmp_path / "bad.csv"
+    path.write_text("\r\n".join(short) + "\r\n", newline="")
+    msgs = []
+    for th in (1, threads):
+        with pytest.raises(io_native.GpaError) as e:
+            io_native.read_gpa(str(path), ",", 3, threads=th, min_chunk=min_chunk)
+        msgs.append(str(e.value))
+    assert msgs[0] == msgs[1] and msgs[0].startswith("row 79 has 2 cells")
+
+
 def test_native_reader_errors_and_restriction(tmp_path):
     from scoary_amd import io_native
     p = tmp_path / "g.csv"
@@ -416,7 +454,7 @@ def test_io_library_exports_every_declared_symbol():
         src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(scoary_(?:gpa|lists|vcf)_[a-z_]+)\s*\(", src)))
     lib = ctypes.CDLL(io_native.LIB_PATH)
-    assert len(names) == 16 and "scoary_vcf_convert" in names and "scoary_lists_build" in names
+    assert len(names) == 17 and "scoary_vcf_convert" in names and "scoary_lists_build" in names
     for n in names:
         assert hasattr(lib, n), n
 
