@@ -149,3 +149,53 @@ def test_gather_to_rank0_gloo():
     want = np.arange(2 * 11 * 9, dtype=np.int32).reshape(2, 11, 9)
     assert all(np.array_equal(o, want) for o in got[0])
     assert got[1] == [None, None] and got[2] == [None, None]
+
+
+def _exchange_worker(rank, world, port, outq):
+    """bench.py's Exchange (async gather, two receive buffers, drained at the
+    barrier) driven for several steps on CPU tensors."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import types
+    import bench
+    from scoary_amd import dist as sd
+    sd.init_from_env()
+    T, G, steps = 2, 5, 5
+    ex = bench.Exchange(torch, types.SimpleNamespace(device="cpu"), world, rank, T, G)
+    for step in range(steps):
+        base = 1000 * step + 100 * rank
+        res = {"counts": torch.full((T, G, 4), base, dtype=torch.int32),
+               "p": torch.full((T, G), float(base), dtype=torch.float64),
+               "odds": torch.full((T, G), float(base) + 0.5, dtype=torch.float64),
+               "r": torch.full((T, G), base + 7, dtype=torch.int32)}
+        ex.submit(res)
+        assert len(ex.pending) <= 1 + (ex.kind == "gather")
+    ex.drain()
+    dist.barrier()
+    out = None
+    if rank == 0:
+        last = ex.recv[(steps - 1) % 2]                        # [world, T, G, words] of the last step
+        d = sd.unpack_records(last.reshape(world * T, G, sd.REC_WORDS))
+        out = (ex.kind, d["counts"].view(world, T, G, 4)[:, 0, 0, 0].tolist(),
+               d["r"].view(world, T, G)[:, 1, 4].tolist(), d["p"].view(world, T, G)[:, 0, 0].tolist())
+    outq.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_bench_exchange_pipeline_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kind, counts, r, pv = got[0]
+    assert kind == "gather"
+    assert counts == [4000, 4100] and r == [4007, 4107] and pv == [4000.0, 4100.0]
+    assert got[1] is None
