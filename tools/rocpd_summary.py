@@ -31,7 +31,7 @@ def main():
                          "from top_kernels").fetchall()
         with open(prefix + "_kernel_stats.txt", "w") as f:
             cmd = "python tools/bench_tree.py" if "tree" in (sys.argv[3] if len(sys.argv) > 3 else "") \
-                else "python bench.py --no-cpu-baseline --steps 10 --warmup 3"
+                else "python bench.py --no-cpu-baseline   (defaults: 5 warm-up + 20 timed steps)"
             f.write("# rocprofv3 --kernel-trace --stats -- %s   (durations in us)\n" % cmd)
             f.write("%-34s %6s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
             for name, calls, tot, avg, pct in rows:
