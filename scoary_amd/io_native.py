@@ -92,13 +92,16 @@ class GpaError(Exception):
     pass
 
 
-def read_gpa(path, delimiter, startcol, allowed=None, threads=None, min_chunk=8 << 20):
+def read_gpa(path, delimiter, startcol, allowed=None, threads=None, min_chunk=8 << 20,
+             need_cols=None):
     """-> (header, meta_rows, rows64, kept_strains): the file's header cells,
     for every data row the text of columns [0, startcol), the presence bits of
     the kept strain columns as rows64, and the kept strain names.  ``allowed``:
     None or a container of isolate names (methods.py:416-420, 473-475).
     ``threads`` / ``min_chunk``: parallel body parse (scoary_gpa_parse_mt); the
-    default lets the library use its OpenMP thread count."""
+    default lets the library use its OpenMP thread count.  ``need_cols``: None
+    (decode every text cell) or a callable header -> columns < startcol whose
+    text is wanted; the other cells of meta_rows are left as ""."""
     L = _load()
     h = ctypes.c_void_p()
     rc = L.scoary_gpa_open(os.fsencode(path), delimiter.encode()[0:1], int(startcol),
@@ -130,8 +133,18 @@ def read_gpa(path, delimiter, startcol, allowed=None, threads=None, min_chunk=8 
         mblob = ctypes.create_string_buffer(max(1, L.scoary_gpa_meta_bytes(h)))
         if R and startcol:
             L.scoary_gpa_meta_copy(h, mlen.ctypes.data_as(ctypes.c_void_p), mblob)
-        flat = _cells(mlen, mblob.raw)
-        meta = [flat[r * startcol:(r + 1) * startcol] for r in range(R)]
+        if need_cols is None or not R or not startcol:
+            flat = _cells(mlen, mblob.raw)
+            meta = [flat[r * startcol:(r + 1) * startcol] for r in range(R)]
+        else:
+            raw = mblob.raw
+            ends = np.cumsum(mlen, dtype=np.int64)
+            begins = ends - mlen
+            meta = [[""] * startcol for _ in range(R)]
+            for c in sorted(set(int(c) for c in need_cols(header) if 0 <= c < startcol)):
+                b, e = begins[c::startcol].tolist(), ends[c::startcol].tolist()
+                for r in range(R):
+                    meta[r][c] = raw[b[r]:e[r]].decode("utf-8", errors="surrogateescape")
         kept = [s for k, s in enumerate(strains) if keep is None or keep[k]]
         return header, meta, bits, kept
     finally:

@@ -242,8 +242,14 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
     rows_iter = None
     if native:
         try:
+            def wanted(hdr):     # identifier, name and annotation columns + the grabbed ones
+                try:
+                    first = [hdr.index(h) for h in ROARY_HEAD] if hdr[0:3] == ROARY_HEAD else [0, 1, 2]
+                except ValueError:
+                    first = [0, 1, 2]
+                return first + list(grabcols)
             header, meta_rows, bits, kept_native = io_native.read_gpa(
-                path, delimiter, startcol, allowed_isolates)
+                path, delimiter, startcol, allowed_isolates, need_cols=wanted)
         except io_native.GpaError as e:
             if "startcol" in str(e):
                 sys.exit("The startcol (-s) you have specified does not seem to correspond to "
