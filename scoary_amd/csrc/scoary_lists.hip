@@ -23,12 +23,12 @@ namespace {
 // permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
 // N <= 5119, 4 (tiles of 128) up to N <= 10239.  A gene takes TW/4 lanes and a
 // wavefront 256/TW genes of similar list length.
-__host__ __device__ constexpr int list_lg(int64_t N) {
+__host__ __device__ constexpr int list_tw(int64_t N) {
   return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : 0));
 }
 // dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
-__host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int LG) {
-  return ((N + 1) * LG + 3) / 4 * 4;
+__host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int TW) {
+  return ((N + 1) * TW + 3) / 4 * 4;
 }
 
 __device__ __forceinline__ uint32_t bit_xor3(uint32_t a, uint32_t b, uint32_t c) {
@@ -76,11 +76,11 @@ __device__ __forceinline__ uint32_t full_add(uint32_t& c, uint32_t x, uint32_t y
   return carry;
 }
 
-// Isolate-major label tiles: tiles[t][tile][row 0..N][LG] dwords, row N all
-// zero; dword j of a row = labels of permutations tile*LG*32 + 32j .. +31.
+// Isolate-major label tiles: tiles[t][tile][row 0..N][TW] dwords, row N all
+// zero; dword j of a row = labels of permutations tile*TW*32 + 32j .. +31.
 // One wavefront generates 64 consecutive permutations (spec S4, same draws as
 // k_perm_generate) and transposes them with ballots.
-template <int LG>
+template <int TW>
 __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __restrict__ masks,
                                                             const int32_t* __restrict__ margins,
                                                             int N, int Wp, int64_t P,
@@ -93,10 +93,10 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
   const int64_t pl = wave * kWave + lane;
   const bool live = pl < P;
   const uint32_t pi = (uint32_t)(perm_base + pl);
-  const int waves_per_tile = LG / 2;
+  const int waves_per_tile = TW / 2;
   const int tile = (int)(wave / waves_per_tile);
   const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
-  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG) + col;
+  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW) + col;
   uint32_t needed = (uint32_t)margins[2 * t], remaining = (uint32_t)margins[2 * t + 1];
   const uint32_t* mrow = masks + (int64_t)t * Wp;
   const int nw = (N + 31) / 32;
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
         if ((iso & 63) == 63 || iso == nw * 32 - 1) {  // 64 isolates collected: one row per lane
           const int row = (iso & ~63) + lane;
           if (row < N) {
-            base[(int64_t)row * LG] = (uint32_t)mine;
-            base[(int64_t)row * LG + 1] = (uint32_t)(mine >> 32);
+            base[(int64_t)row * TW] = (uint32_t)mine;
+            base[(int64_t)row * TW + 1] = (uint32_t)(mine >> 32);
           }
           mine = 0;
         }
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
     }
   }
   if (lane == 0) {  // the all-zero row that list padding points at
-    base[(int64_t)N * LG] = 0u;
-    base[(int64_t)N * LG + 1] = 0u;
+    base[(int64_t)N * TW] = 0u;
+    base[(int64_t)N * TW + 1] = 0u;
   }
 }
 
@@ -183,7 +183,7 @@ __device__ __forceinline__ void select_rows(const uint32_t (&x)[kGenChunk], uint
   }
 }
 
-template <int LG>
+template <int TW>
 __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_tiles_wg(
     const uint32_t* __restrict__ masks, const int32_t* __restrict__ margins, int N, int Wp,
     int64_t P, int64_t perm_base, int trait_base, uint32_t k0, uint32_t k1, int ntiles,
@@ -195,10 +195,10 @@ __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_til
   const int64_t pl = wave * kWave + lane;
   const bool live = pl < P;
   const uint32_t pi = (uint32_t)(perm_base + pl);
-  const int waves_per_tile = LG / 2;
+  const int waves_per_tile = TW / 2;
   const int tile = (int)(wave / waves_per_tile);
   const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
-  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, LG) + col;
+  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW) + col;
   uint32_t needed = (uint32_t)margins[2 * t];
   const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
   // valid isolates left at the start of the chunk this wavefront works on
@@ -245,15 +245,15 @@ __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_til
         select_rows<0, false>(x, mw, livemask, needed, lo, hi);
       const int row = cc * kGenChunk + lane;
       if (row < N) {
-        base[(int64_t)row * LG] = lo;
-        base[(int64_t)row * LG + 1] = hi;
+        base[(int64_t)row * TW] = lo;
+        base[(int64_t)row * TW + 1] = hi;
       }
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {  // the all-zero row that list padding points at
-    base[(int64_t)N * LG] = 0u;
-    base[(int64_t)N * LG + 1] = 0u;
+    base[(int64_t)N * TW] = 0u;
+    base[(int64_t)N * TW + 1] = 0u;
   }
 }
 
@@ -476,17 +476,17 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
 extern "C" {
 
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
-  const int LG = list_lg(N);
-  if (!LG) return 0;
-  const int64_t tile_perms = LG * 32;
+  const int TW = list_tw(N);
+  if (!TW) return 0;
+  const int64_t tile_perms = TW * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  return T * ntiles * list_tile_dwords(N, LG);
+  return T * ntiles * list_tile_dwords(N, TW);
 }
-int64_t scoary_list_tile_words(int64_t N) { return list_lg(N) ? list_tile_dwords(N, list_lg(N)) : 0; }
+int64_t scoary_list_tile_words(int64_t N) { return list_tw(N) ? list_tile_dwords(N, list_tw(N)) : 0; }
 int64_t scoary_list_max_isolates(void) { return 10239; }
 int scoary_list_params(int64_t N, int64_t* out5) {
   if (!out5) return SCOARY_ERR_ARG;
-  const int TW = list_lg(N);
+  const int TW = list_tw(N);
   out5[0] = TW;                     /* tile row width in dwords (0: N too large for LDS tiles) */
   out5[1] = TW * 4;                 /* LDS / tile row stride in bytes */
   out5[2] = TW ? 4 * kWave / TW : 0;   /* genes per wavefront: lists padded to equal length */
@@ -504,28 +504,28 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
     return fail(h, SCOARY_ERR_ARG, "scoary_perm_generate_tiles: bad argument");
   if (T > 65535 || perm_base + P > 0xffffffffLL)
     return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: T > 65535 or permutation index >= 2^32");
-  const int LG = list_lg(N);
-  if (!LG) return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: N too large for LDS tiles");
+  const int TW = list_tw(N);
+  if (!TW) return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: N too large for LDS tiles");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int64_t tile_perms = LG * 32;
+  const int64_t tile_perms = TW * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
   const dim3 grid((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T);
   KernelTimer kt(h, s, "k_perm_generate_tiles");
   // one wavefront per 64 permutations when there are enough of them to fill the
   // chip; otherwise a workgroup each, with the Philox draws spread over more lanes
   const bool wg = (int64_t)grid.x * grid.y < (int64_t)h->num_cu * 4 * kGenSplitBelow;
-#define GEN_TILES(LGV)                                                                            \
+#define GEN_TILES(TWV)                                                                            \
   if (wg)                                                                                         \
-    hipLaunchKernelGGL((k_perm_generate_tiles_wg<LGV>), grid, dim3(kWave * (1 + kGenProducers)),  \
+    hipLaunchKernelGGL((k_perm_generate_tiles_wg<TWV>), grid, dim3(kWave * (1 + kGenProducers)),  \
                        0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P, perm_base,  \
                        (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles,      \
                        d_tiles);                                                                  \
   else                                                                                            \
-    hipLaunchKernelGGL((k_perm_generate_tiles<LGV>), grid, dim3(kWave), 0, s, d_masks, d_margins, \
+    hipLaunchKernelGGL((k_perm_generate_tiles<TWV>), grid, dim3(kWave), 0, s, d_masks, d_margins, \
                        (int)N, (int)scoary_row_words(N), P, perm_base, (int)trait_base,           \
                        (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
-  if (LG == 16) { GEN_TILES(16); } else if (LG == 8) { GEN_TILES(8); } else { GEN_TILES(4); }
+  if (TW == 16) { GEN_TILES(16); } else if (TW == 8) { GEN_TILES(8); } else { GEN_TILES(4); }
 #undef GEN_TILES
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
@@ -586,7 +586,7 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   if (!d_tiles || !d_lidx || !d_lstart || !d_lngroups || !d_lorder || !d_lflipped || !d_crit ||
       !d_margins || !d_lcrit || !d_r || G < 1 || T < 1 || N < 1 || P < 1)
     return fail(h, SCOARY_ERR_ARG, "scoary_permute_lists: bad argument");
-  const int TW = list_lg(N);
+  const int TW = list_tw(N);
   if (!TW)
     return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: label tile does not fit in LDS for this N");
   if (T > 65535) return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: T > 65535");
