@@ -67,7 +67,8 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
  * the wavefront's index loads are contiguous; start[] is then the group base
  * for every slot of the group and the last group is stored in full (missing
  * genes all padding).  piece = 0: every list contiguous, back to back.
- * row_stride / genes_per_wave / classes / piece come from scoary_list_params(N).
+ * row_stride / genes_per_wave / classes / piece come from scoary_list_params(N);
+ * classes must be a power of two (1..64), piece must divide 32.
  *   first call  : scoary_lists_count -> total number of entries
  *   second call : scoary_lists_build fills
  *       idx     uint32 [total]   entry = position * row_stride (the LDS byte offset of
