@@ -31,14 +31,31 @@ __host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int TW) {
   return ((N + 1) * TW + 3) / 4 * 4;
 }
 
+// VGPR banks.  A VOP3 instruction whose src0 and src1 live in the same VGPR bank
+// (register index mod 4) issues in ~4.5 cycles instead of ~2.65 on gfx950
+// (tools/valu_banks.hip); src2 is free.  xor3 and majority are symmetric in their
+// operands, so the ASSEMBLER picks an operand order with src0 and src1 in
+// different banks: the register names are only known after allocation, and
+// `scoary_bank_vN` (defined once per kernel by SCOARY_BANK_DEFS) maps a name to
+// its bank inside an .if.  39 % of the full-adder ops had the conflict before.
+__device__ __forceinline__ void scoary_bank_defs() {
+  asm volatile(".ifndef scoary_bank_defs\n"
+               ".set scoary_bank_defs, 1\n"
+#include "scoary_vgpr_banks.inc"
+               ".endif");
+}
+#define SCOARY_SYM3(LUT)                                                        \
+  ".if scoary_bank_%1 != scoary_bank_%2\n v_bitop3_b32 %0, %1, %2, %3 bitop3:" LUT \
+  "\n.elseif scoary_bank_%1 != scoary_bank_%3\n v_bitop3_b32 %0, %1, %3, %2 bitop3:" LUT \
+  "\n.else\n v_bitop3_b32 %0, %2, %3, %1 bitop3:" LUT "\n.endif"
 __device__ __forceinline__ uint32_t bit_xor3(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t d;
-  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  asm(SCOARY_SYM3("0x96") : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
 __device__ __forceinline__ uint32_t bit_maj(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t d;
-  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe8" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  asm(SCOARY_SYM3("0xe8") : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
 // majority(~a, b, c): the borrow of a - b - c
@@ -69,10 +86,38 @@ __device__ __forceinline__ uint32_t region_lt(const uint32_t (&c)[16], uint32_t 
   }
   return lt;
 }
+// Counter plane K of permutation word W, pinned to one physical VGPR
+// (scoary_ctr_regs.inc) whose bank is never the bank of a row word W: the full
+// adders that consume LDS rows (half of all) then never have src0 and src1 in
+// one bank, and for the adders on carries the assembler still picks the order.
+template <int W, int K>
+struct Ctr;
+#define SCOARY_SYM3_INPLACE(LUT)                                                      \
+  ".if scoary_bank_%0 != scoary_bank_%1\n v_bitop3_b32 %0, %0, %1, %2 bitop3:" LUT    \
+  "\n.elseif scoary_bank_%0 != scoary_bank_%2\n v_bitop3_b32 %0, %0, %2, %1 bitop3:" LUT \
+  "\n.else\n v_bitop3_b32 %0, %1, %2, %0 bitop3:" LUT "\n.endif"
+#define SCOARY_CTR(W, K, R)                                                            \
+  template <>                                                                          \
+  struct Ctr<W, K> {                                                                   \
+    static __device__ __forceinline__ uint32_t maj(uint32_t c, uint32_t x, uint32_t y) { \
+      uint32_t d;                                                                      \
+      asm(SCOARY_SYM3("0xe8") : "=v"(d) : "{" R "}"(c), "v"(x), "v"(y));               \
+      return d;                                                                        \
+    }                                                                                  \
+    static __device__ __forceinline__ void xor3(uint32_t& c, uint32_t x, uint32_t y) { \
+      asm(SCOARY_SYM3_INPLACE("0x96") : "+{" R "}"(c) : "v"(x), "v"(y));               \
+    }                                                                                  \
+    static __device__ __forceinline__ void xor2(uint32_t& c, uint32_t x) {             \
+      asm("v_xor_b32 %0, %1, %0" : "+{" R "}"(c) : "v"(x));                            \
+    }                                                                                  \
+  };
+#include "scoary_ctr_regs.inc"
+#undef SCOARY_CTR
 // c += x + y at bit-plane weight 1: returns the carry (weight 2)
+template <int W, int K>
 __device__ __forceinline__ uint32_t full_add(uint32_t& c, uint32_t x, uint32_t y) {
-  const uint32_t carry = bit_maj(c, x, y);
-  c = bit_xor3(c, x, y);
+  const uint32_t carry = Ctr<W, K>::maj(c, x, y);
+  Ctr<W, K>::xor3(c, x, y);
   return carry;
 }
 
@@ -292,6 +337,11 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
 __device__ __forceinline__ uint4 lds128_at(const uint32_t* lds, uint32_t byte_off) {
   return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds) + byte_off);
 }
+#ifdef SCOARY_EXP_NOLDS   /* experiment: no LDS traffic, rows are a function of the address */
+#define SCOARY_EXP_READ(v, lds, a) const uint4 v = {a, a * 3u, a ^ 0x55u, a + 7u};
+#else
+#define SCOARY_EXP_READ(v, lds, a) const uint4 v = lds128_at(lds, a);
+#endif
 struct Rows4 { uint32_t w0[4], w1[4], w2[4], w3[4]; };   // 4 tile rows x 4 permutation words
 // The 4 entries held by lane H of every LPG-lane gene group -> 4 ds_read_b128.
 template <int LPG, int H>
@@ -306,7 +356,7 @@ __device__ __forceinline__ void read4x4(Rows4& x, const uint32_t* __restrict__ l
       a = e[J];                                                                                    \
     else                                                                                           \
       a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e[J], kCtrl, 0xf, 0xf, false) + colb;      \
-    const uint4 v = lds128_at(lds, a);                                                             \
+    SCOARY_EXP_READ(v, lds, a)                                                                     \
     x.w0[J] = v.x;                                                                                 \
     x.w1[J] = v.y;                                                                                 \
     x.w2[J] = v.z;                                                                                 \
@@ -315,11 +365,12 @@ __device__ __forceinline__ void read4x4(Rows4& x, const uint32_t* __restrict__ l
   RD(0) RD(1) RD(2) RD(3)
 #undef RD
 }
-// 4 row words -> counter planes 0..1, returns the carry of weight 4
+// 4 row words -> counter planes 0..1 of word W, returns the carry of weight 4
+template <int W>
 __device__ __forceinline__ uint32_t sum4(uint32_t (&c)[16], const uint32_t (&x)[4]) {
-  const uint32_t a1 = full_add(c[0], x[0], x[1]);
-  const uint32_t a2 = full_add(c[0], x[2], x[3]);
-  return full_add(c[1], a1, a2);
+  const uint32_t a1 = full_add<W, 0>(c[0], x[0], x[1]);
+  const uint32_t a2 = full_add<W, 0>(c[0], x[2], x[3]);
+  return full_add<W, 1>(c[1], a1, a2);
 }
 struct Carry4 { uint32_t w[4]; };
 
@@ -337,6 +388,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
                                                         int groups_per_block,
                                                         uint32_t* __restrict__ r) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
+  scoary_bank_defs();                // assembler symbols for the operand-ordering .if blocks
   constexpr int TW = 4 * LPG;        // tile row, dwords
   constexpr int GPW = kWave / LPG;   // genes per wavefront
   const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
@@ -368,8 +420,9 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     // interleaved lists (piece = TW entries): the wavefront's 64 lanes read 64
     // consecutive 16-byte index vectors per piece
     struct alignas(16) Ent { uint32_t e[4]; };
-    const Ent* lp = reinterpret_cast<const Ent*>(lidx) +
-                    (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 8 + lane;
+    // wave-uniform base of the group's lists; lane l reads vector piece*64 + l
+    const Ent* gbase = reinterpret_cast<const Ent*>(lidx) +
+                       (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 8;
     const uint32_t colb = (uint32_t)col * 16u;
 
     uint32_t c0[16], c1[16], c2[16], c3[16];
@@ -378,77 +431,91 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     Rows4 xa, xb;
     auto s4 = [&](const Rows4& x) -> Carry4 {
       Carry4 b;
-      b.w[0] = sum4(c0, x.w0);
-      b.w[1] = sum4(c1, x.w1);
-      b.w[2] = sum4(c2, x.w2);
-      b.w[3] = sum4(c3, x.w3);
+      b.w[0] = sum4<0>(c0, x.w0);
+      b.w[1] = sum4<1>(c1, x.w1);
+      b.w[2] = sum4<2>(c2, x.w2);
+      b.w[3] = sum4<3>(c3, x.w3);
       return b;
     };
-    auto fa = [&](int plane, const Carry4& a, const Carry4& b) -> Carry4 {
-      Carry4 o;
-      o.w[0] = full_add(c0[plane], a.w[0], b.w[0]);
-      o.w[1] = full_add(c1[plane], a.w[1], b.w[1]);
-      o.w[2] = full_add(c2[plane], a.w[2], b.w[2]);
-      o.w[3] = full_add(c3[plane], a.w[3], b.w[3]);
-      return o;
-    };
-    // pieces of 4*LPG entries; the index loads run three pieces ahead.  Reads past
-    // the end of the list re-read its last piece (valid rows, never summed).
-    const int last = max(nsuper * (8 / LPG) - 1, 0);
-    int piece = 0;
-    Ent cur = lp[0], nxt = lp[(int64_t)min(1, last) * kWave], nn = lp[(int64_t)min(2, last) * kWave];
-    read4x4<LPG, 0>(xa, tile_lds, cur.e, colb);
-    // sub-step S of a step: issue the reads of sub-step S+1 into `other`, sum `mine`
-#define SUBSTEP(S, MINE, OTHER)                                        \
-  [&]() -> Carry4 {                                                    \
-    constexpr int Hn = ((S) + 1) % LPG;                                \
-    if constexpr (Hn == 0) {                                           \
-      cur = nxt;                                                       \
-      nxt = nn;                                                        \
-      ++piece;                                                         \
-      nn = lp[(int64_t)min(piece + 2, last) * kWave];                  \
+#define FA4(PLANE, A, B)                                               \
+  Carry4 {                                                             \
+    {                                                                  \
+      full_add<0, PLANE>(c0[PLANE], (A).w[0], (B).w[0]),               \
+          full_add<1, PLANE>(c1[PLANE], (A).w[1], (B).w[1]),           \
+          full_add<2, PLANE>(c2[PLANE], (A).w[2], (B).w[2]),           \
+          full_add<3, PLANE>(c3[PLANE], (A).w[3], (B).w[3])            \
     }                                                                  \
-    read4x4<LPG, Hn>(OTHER, tile_lds, cur.e, colb);                    \
-    return s4(MINE);                                                   \
+  }
+    // pieces of 4*LPG entries; the index loads run three pieces ahead in a ring of
+    // four vectors (a region of four steps is a multiple of four pieces, so the ring
+    // slot of every piece is a compile-time constant).  Reads past the end of the
+    // list re-read its last piece (valid rows, never summed).
+    const int last = max(nsuper * (8 / LPG) - 1, 0);
+    int piece = 0;                                   // piece whose vector is ring[piece % 4]
+    const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(Ent);   // scalar base + 32-bit lane offset
+    auto load_piece = [&](int p) -> Ent {
+      return *reinterpret_cast<const Ent*>(
+          reinterpret_cast<const char*>(gbase + (int64_t)min(p, last) * kWave) + lane_off);
+    };
+    Ent ring[4] = {load_piece(0), load_piece(1), load_piece(2), load_piece(3)};
+    read4x4<LPG, 0>(xa, tile_lds, ring[0].e, colb);
+    // sub-step S of step K (both literals): issue the reads of the next sub-step into
+    // `other`, sum `mine`
+#define SUBSTEP(K, S, MINE, OTHER)                                          \
+  [&]() -> Carry4 {                                                         \
+    constexpr int kSub = (K) * 8 + (S);          /* sub-step within the region */ \
+    constexpr int kCur = (kSub / LPG) % 4;       /* ring slot in use */           \
+    constexpr int Hn = (kSub + 1) % LPG;                                     \
+    if constexpr (Hn == 0) {                     /* piece finished: refill its slot */ \
+      ring[kCur] = load_piece(piece + 4);                                    \
+      ++piece;                                                               \
+      read4x4<LPG, 0>(OTHER, tile_lds, ring[(kCur + 1) % 4].e, colb);         \
+    } else {                                                                 \
+      read4x4<LPG, Hn>(OTHER, tile_lds, ring[kCur].e, colb);                  \
+    }                                                                        \
+    return s4(MINE);                                                         \
   }()
     for (int sg = 0; sg < nsuper; sg += 4) {
       const Carry4 zero = {{0u, 0u, 0u, 0u}};
-      auto step = [&](int k) -> Carry4 {                    // 32 listed isolates
-        if (sg + k >= nsuper) return zero;
-        const Carry4 b0 = SUBSTEP(0, xa, xb);
-        const Carry4 b1 = SUBSTEP(1, xb, xa);
-        const Carry4 d0 = fa(2, b0, b1);
-        const Carry4 b2 = SUBSTEP(2, xa, xb);
-        const Carry4 b3 = SUBSTEP(3, xb, xa);
-        const Carry4 d1 = fa(2, b2, b3);
-        const Carry4 e0 = fa(3, d0, d1);
-        const Carry4 b4 = SUBSTEP(4, xa, xb);
-        const Carry4 b5 = SUBSTEP(5, xb, xa);
-        const Carry4 d2 = fa(2, b4, b5);
-        const Carry4 b6 = SUBSTEP(6, xa, xb);
-        const Carry4 b7 = SUBSTEP(7, xb, xa);
-        const Carry4 d3 = fa(2, b6, b7);
-        const Carry4 e1 = fa(3, d2, d3);
-        return fa(4, e0, e1);                               // weight 32
-      };
-      const Carry4 f0 = step(0), f1 = step(1);
-      const Carry4 g0 = fa(5, f0, f1);
-      const Carry4 f2 = step(2), f3 = step(3);
-      const Carry4 g1 = fa(5, f2, f3);
-      Carry4 carry = fa(6, g0, g1);
-#pragma unroll
-      for (int k = 7; k < KC; ++k) {
-#define RIPPLE(C, W)                         \
-  {                                          \
-    const uint32_t nc = C[k] & carry.w[W];   \
-    C[k] ^= carry.w[W];                      \
-    carry.w[W] = nc;                         \
+#define STEP(K)                                   /* 32 listed isolates */ \
+  [&]() -> Carry4 {                                                         \
+    if (sg + (K) >= nsuper) return zero;                                    \
+    const Carry4 b0 = SUBSTEP(K, 0, xa, xb);                                \
+    const Carry4 b1 = SUBSTEP(K, 1, xb, xa);                                \
+    const Carry4 d0 = FA4(2, b0, b1);                                       \
+    const Carry4 b2 = SUBSTEP(K, 2, xa, xb);                                \
+    const Carry4 b3 = SUBSTEP(K, 3, xb, xa);                                \
+    const Carry4 d1 = FA4(2, b2, b3);                                       \
+    const Carry4 e0 = FA4(3, d0, d1);                                       \
+    const Carry4 b4 = SUBSTEP(K, 4, xa, xb);                                \
+    const Carry4 b5 = SUBSTEP(K, 5, xb, xa);                                \
+    const Carry4 d2 = FA4(2, b4, b5);                                       \
+    const Carry4 b6 = SUBSTEP(K, 6, xa, xb);                                \
+    const Carry4 b7 = SUBSTEP(K, 7, xb, xa);                                \
+    const Carry4 d3 = FA4(2, b6, b7);                                       \
+    const Carry4 e1 = FA4(3, d2, d3);                                       \
+    return FA4(4, e0, e1);                       /* weight 32 */            \
+  }()
+      const Carry4 f0 = STEP(0), f1 = STEP(1);
+      const Carry4 g0 = FA4(5, f0, f1);
+      const Carry4 f2 = STEP(2), f3 = STEP(3);
+      const Carry4 g1 = FA4(5, f2, f3);
+      Carry4 carry = FA4(6, g0, g1);
+#define RIPPLE(K)                                                       \
+  if constexpr (K < KC) {                                               \
+    Carry4 nc = {{c0[K] & carry.w[0], c1[K] & carry.w[1], c2[K] & carry.w[2], c3[K] & carry.w[3]}}; \
+    Ctr<0, K>::xor2(c0[K], carry.w[0]);                                 \
+    Ctr<1, K>::xor2(c1[K], carry.w[1]);                                 \
+    Ctr<2, K>::xor2(c2[K], carry.w[2]);                                 \
+    Ctr<3, K>::xor2(c3[K], carry.w[3]);                                 \
+    carry = nc;                                                         \
   }
-        RIPPLE(c0, 0) RIPPLE(c1, 1) RIPPLE(c2, 2) RIPPLE(c3, 3)
+      RIPPLE(7) RIPPLE(8) RIPPLE(9) RIPPLE(10) RIPPLE(11) RIPPLE(12)
 #undef RIPPLE
-      }
     }
+#undef STEP
 #undef SUBSTEP
+#undef FA4
     const uint2 cr = lcrit[(int64_t)t * G + slot];
     const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
     const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;

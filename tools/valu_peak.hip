@@ -55,6 +55,59 @@ __global__ __launch_bounds__(64) void k_fma(float* out, int iters, float a) {
   out[blockIdx.x * 64 + threadIdx.x] = s;
 }
 
+// 16 independent chains of one instruction, all-VGPR operands: the issue rate of
+// the op itself.  KIND 0: v_bitop3_b32 (xor3), 1: v_xor_b32, 2: v_add_u32,
+// 3: v_add_u32_dpp quad_perm, 4: v_bitop3 full adder pair (sum + carry of the same inputs)
+template <int KIND>
+__global__ __launch_bounds__(64) void k_op(uint32_t* out, int iters, uint32_t seed) {
+  uint32_t x[16], y = threadIdx.x * 2654435761u ^ seed, z = threadIdx.x * 40503u + seed;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = (threadIdx.x + i) * 2246822519u ^ seed;
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (KIND == 0)
+        asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x[i]) : "v"(y), "v"(z));
+      else if (KIND == 1)
+        asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[i]) : "v"(y));
+      else if (KIND == 2)
+        asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[i]) : "v"(y));
+      else if (KIND == 3)
+        asm volatile("v_add_u32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf"
+                     : "+v"(x[i]) : "v"(y));
+      else {
+        uint32_t c;
+        asm volatile("v_bitop3_b32 %1, %0, %2, %3 bitop3:0xe8\n\tv_bitop3_b32 %0, %0, %2, %3 bitop3:0x96"
+                     : "+v"(x[i]), "=&v"(c) : "v"(y), "v"(z));
+        y ^= c & 1u ? 0u : 0u;   // keep c alive without extra VALU work being measured
+      }
+    }
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s ^= x[i];
+  out[blockIdx.x * 64 + threadIdx.x] = s ^ y;
+}
+
+template <int KIND>
+static void run_op(const char* name, uint32_t* d, int blocks, int iters, int ops_per_slot) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k_op<KIND>), dim3(blocks), dim3(64), 0, 0, d, iters, 777u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double ops = (double)blocks * 64 * iters * 16 * ops_per_slot;
+    printf("%s: %.3f ms  %.3e lane-ops/s = %.1f%% of 256CU*4*16*2.4GHz\n", name, ms, ops / (ms * 1e-3),
+           100.0 * ops / (ms * 1e-3) / (256.0 * 4 * 16 * 2.4e9));
+  }
+}
+
 int main() {
   const int blocks = 256 * 4 * 8;  // 8 waves per SIMD
   uint32_t* d;
@@ -88,5 +141,10 @@ int main() {
     printf("v_fma_f32: %.3f ms  %.3e lane-ops/s = %.1f%%  (%.1f TFLOP/s)\n", ms, ops / (ms * 1e-3),
            100.0 * ops / (ms * 1e-3) / (256.0 * 4 * 32 * 2.4e9), 2 * ops / (ms * 1e-3) / 1e12);
   }
+  run_op<0>("v_bitop3_b32 (xor3)", d, blocks, iters * 4, 1);
+  run_op<4>("v_bitop3_b32 pair (carry + sum)", d, blocks, iters * 2, 2);
+  run_op<1>("v_xor_b32", d, blocks, iters * 4, 1);
+  run_op<2>("v_add_u32", d, blocks, iters * 4, 1);
+  run_op<3>("v_add_u32_dpp quad_perm", d, blocks, iters * 4, 1);
   return 0;
 }
