@@ -33,8 +33,12 @@ if ROOT not in sys.path:
 LISTS_DEFAULT = True         # list-driven kernel: 4.9 ms vs 16.1 ms (dense) on the headline config
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (upper bound)
-INT_VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9   # integer/logic ops: 16 lanes/clk/SIMD at the nominal
-                                                 # 2.4 GHz (profiles/r01_valu_peak.txt measures 3.8-4.1e13)
+# measured issue rates (lane-ops/s, whole chip): the dense kernel's op pair (v_and_b32 with an SGPR
+# operand + v_bcnt_u32_b32 accumulate, tools/valu_peak.hip) and the list kernel's v_bitop3_b32 with
+# VGPR operands in distinct banks (tools/valu_banks.hip: 2.5 cycles per wave-instruction at 8 waves
+# per SIMD, 2.8 at the 4 the list kernel runs with)
+VALU_PEAK_AND_BCNT = 4.1e13
+VALU_PEAK_BITOP3 = 6.2e13
 
 
 def parse():
@@ -182,16 +186,18 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
         "tests_per_s_kernel": tests_per_launch / (k3_ms * 1e-3),
         "dense_model_valu_frac_of_2.4GHz_simd32_peak":
             None if use_lists else valu_ops / (k3_ms * 1e-3) / VALU_LANE_OPS_PER_S,
-        # what actually binds: integer-VALU issue (figure iii).  Instruction
-        # count from the committed SQ_INSTS_VALU pass, duration measured live; the
-        # ceiling is 256 CU x 4 SIMD x 16 lanes/clk x the nominal 2.4 GHz for
-        # v_and / v_bcnt / v_bitop3 (tools/valu_peak.hip measures 3.8-4.1e13).
+        # what actually binds: VALU instruction issue (figure iii).  Instruction
+        # count from the committed SQ_INSTS_VALU pass, duration measured live; the ceiling
+        # is the measured chip-wide issue rate of the kernel's own op (see the constants).
         "valu": None if not valu_insts else {
             "wave_insts_per_launch": valu_insts,
             "ops_per_test": valu_insts * 64.0 / tests_per_launch,
             "lane_ops_per_s": valu_insts * 64.0 / (k3_ms * 1e-3),
-            "peak_lane_ops_per_s": INT_VALU_LANE_OPS_PER_S,
-            "frac": valu_insts * 64.0 / (k3_ms * 1e-3) / INT_VALU_LANE_OPS_PER_S,
+            "peak_lane_ops_per_s": VALU_PEAK_BITOP3 if use_lists else VALU_PEAK_AND_BCNT,
+            "peak_source": "tools/valu_banks.hip (v_bitop3_b32, 8 waves/SIMD)" if use_lists
+                           else "tools/valu_peak.hip (v_and_b32 + v_bcnt_u32_b32)",
+            "frac": valu_insts * 64.0 / (k3_ms * 1e-3)
+                    / (VALU_PEAK_BITOP3 if use_lists else VALU_PEAK_AND_BCNT),
             "source": traffic_src},
     }
 
