@@ -191,7 +191,8 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
 // (lane = permutation in every wavefront) and ONE selection wavefront walks the
 // chunk; its compare mask over the 64 lanes IS the tile row of that isolate.
 constexpr int kGenProducers = 7;
-constexpr int kGenSplitBelow = 1;  // workgroup variant below this many wavefronts per SIMD
+constexpr int kGenSplitBelow = 1;  // workgroup-of-8 variant below this many wavefronts per SIMD
+constexpr int kGenWg4Below = 8;    // workgroup-of-4 variant below this many
 constexpr int kGenChunk = 64;      // isolates per LDS buffer = 16 Philox counters
 // Philox counters (of the 16 per chunk) each producer wavefront computes.  A
 // workgroup's wavefronts go to the SIMDs cyclically, so wavefront 4 shares the
@@ -289,6 +290,74 @@ __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_til
       else
         select_rows<0, false>(x, mw, livemask, needed, lo, hi);
       const int row = cc * kGenChunk + lane;
+      if (row < N) {
+        base[(int64_t)row * TW] = lo;
+        base[(int64_t)row * TW + 1] = hi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {  // the all-zero row that list padding points at
+    base[(int64_t)N * TW] = 0u;
+    base[(int64_t)N * TW + 1] = 0u;
+  }
+}
+
+// The middle regime (one to eight wavefronts per SIMD): four wavefronts per 64
+// permutations, single LDS buffer (16 KB, eight workgroups per CU).  All four compute
+// the chunk's Philox draws, then wavefront 0 selects; the other workgroups of the CU
+// fill the gaps.  Spreads the quarter-rate Philox multiplies evenly over the SIMDs,
+// which one wavefront per 64 permutations cannot do with 1-2 wavefronts per SIMD.
+template <int TW>
+__global__ __launch_bounds__(kWave * 4) void k_perm_generate_tiles_wg4(
+    const uint32_t* __restrict__ masks, const int32_t* __restrict__ margins, int N, int Wp,
+    int64_t P, int64_t perm_base, int trait_base, uint32_t k0, uint32_t k1, int ntiles,
+    uint32_t* __restrict__ tiles) {
+  __shared__ uint32_t draws[kGenChunk][kWave];
+  const int t = blockIdx.y;
+  const int lane = threadIdx.x & (kWave - 1), role = threadIdx.x / kWave;
+  const int64_t wave = blockIdx.x;                    // 64 permutations each
+  const int64_t pl = wave * kWave + lane;
+  const bool live = pl < P;
+  const uint32_t pi = (uint32_t)(perm_base + pl);
+  const int waves_per_tile = TW / 2;
+  const int tile = (int)(wave / waves_per_tile);
+  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
+  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW) + col;
+  uint32_t needed = (uint32_t)margins[2 * t];
+  const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
+  uint32_t remaining = (uint32_t)__builtin_amdgcn_readfirstlane(margins[2 * t + 1]);
+  const uint32_t* mrow = masks + (int64_t)t * Wp;     // Wp >= 2*nchunks words, zero padded
+  const int nchunks = (N + kGenChunk - 1) / kGenChunk;
+  for (int c = 0; c < nchunks; ++c) {
+    const uint64_t mw = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * c]) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * c + 1]) << 32;
+    const uint32_t rem0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)remaining);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                      // 16 Philox counters per chunk, 4 per wavefront
+      const int jj = role + 4 * k;
+      uint32_t r[4];
+      philox4x32_10((uint32_t)(c * (kGenChunk / 4) + jj), pi, (uint32_t)(trait_base + t),
+                    kPermDomain, k0, k1, r);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ii = 4 * jj + q;
+        const uint32_t rem = rem0 - (uint32_t)__popcll(mw & (((uint64_t)1 << ii) - 1));
+        draws[ii][lane] = __umulhi(r[q], rem);
+      }
+    }
+    remaining -= (uint32_t)__popcll(mw);
+    __syncthreads();
+    if (role == 0) {
+      uint32_t x[kGenChunk];
+#pragma unroll
+      for (int ii = 0; ii < kGenChunk; ++ii) x[ii] = draws[ii][lane];
+      uint32_t lo = 0u, hi = 0u;
+      if (mw == ~(uint64_t)0)
+        select_rows<0, true>(x, mw, livemask, needed, lo, hi);
+      else
+        select_rows<0, false>(x, mw, livemask, needed, lo, hi);
+      const int row = c * kGenChunk + lane;
       if (row < N) {
         base[(int64_t)row * TW] = lo;
         base[(int64_t)row * TW + 1] = hi;
@@ -579,13 +648,21 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
   const dim3 grid((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T);
   KernelTimer kt(h, s, "k_perm_generate_tiles");
-  // one wavefront per 64 permutations when there are enough of them to fill the
-  // chip; otherwise a workgroup each, with the Philox draws spread over more lanes
-  const bool wg = (int64_t)grid.x * grid.y < (int64_t)h->num_cu * 4 * kGenSplitBelow;
+  // three kernels for the same tiles, by how many 64-permutation wavefronts there are per
+  // SIMD: < 1: a workgroup of 8 (Philox producers + one selection wavefront, latency
+  // regime); 1..kGenWg4Below: a workgroup of 4 (balances the Philox work over the SIMDs);
+  // more: one wavefront each
+  const int64_t gen_waves = (int64_t)grid.x * grid.y, simds = (int64_t)h->num_cu * 4;
+  const int variant = gen_waves < simds * kGenSplitBelow ? 0 : (gen_waves < simds * kGenWg4Below ? 1 : 2);
 #define GEN_TILES(TWV)                                                                            \
-  if (wg)                                                                                         \
+  if (variant == 0)                                                                               \
     hipLaunchKernelGGL((k_perm_generate_tiles_wg<TWV>), grid, dim3(kWave * (1 + kGenProducers)),  \
                        0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P, perm_base,  \
+                       (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles,      \
+                       d_tiles);                                                                  \
+  else if (variant == 1)                                                                          \
+    hipLaunchKernelGGL((k_perm_generate_tiles_wg4<TWV>), grid, dim3(kWave * 4), 0, s, d_masks,    \
+                       d_margins, (int)N, (int)scoary_row_words(N), P, perm_base,                 \
                        (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles,      \
                        d_tiles);                                                                  \
   else                                                                                            \

@@ -350,12 +350,13 @@ def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
 
 
 @pytest.mark.parametrize("N,T,P", [(333, 2, 700), (2700, 2, 700), (6000, 2, 700), (64, 1, 64),
-                                   (333, 4, 17000)])
+                                   (333, 4, 17000), (100, 3, 180000)])
 def test_perm_tiles_are_the_transposed_row_labels(eng, N, T, P):
     """k_perm_generate_tiles writes the same spec-S4 labels as k_perm_generate,
     isolate-major in tiles of 512 / 256 / 128 permutations, zero row + zero ragged
     tail.  Few (trait, 64-permutation) wavefronts -> the workgroup variant with
-    Philox producer wavefronts; >= 1024 of them (last case) -> one wavefront each."""
+    Philox producer wavefronts; 1024..8191 of them (last-but-one case) -> the
+    four-wavefront workgroup; more (last case) -> one wavefront each."""
     rng = np.random.default_rng(2)
     base = 40
     traits = (rng.random((T, N)) < 0.4).astype(np.uint8)
