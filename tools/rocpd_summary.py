@@ -47,7 +47,7 @@ def main():
         c.close()
     pmc = {}
     for sub, db in (("pmc_fetch", "fetch_results.db"), ("pmc_write", "write_results.db"),
-                    ("pmc_sq", "sq_results.db")):
+                    ("pmc_sq", "sq_results.db"), ("pmc_lds", "lds_results.db")):
         path = os.path.join(src, sub, db)
         if not os.path.exists(path):
             continue

@@ -23,6 +23,25 @@ __global__ __launch_bounds__(64) void k(uint32_t* out, int iters) {
     if (KIND == 3) asm volatile(Q1 "s_waitcnt lgkmcnt(0)\n" Q2 "s_waitcnt lgkmcnt(0)\n" Q3 "s_waitcnt lgkmcnt(0)\n" Q4 "s_waitcnt lgkmcnt(0)\n" ::: CLOB);
     if (KIND == 4) asm volatile(Q1 "ds_read_b128 v[40:43], v44\n" Q2 "ds_read_b128 v[40:43], v44\n" Q3 "ds_read_b128 v[40:43], v44\n" Q4 "ds_read_b128 v[40:43], v44\ns_waitcnt lgkmcnt(0)\n" ::: CLOB, "v44");
     if (KIND == 5) asm volatile(Q1 "v_add_u32_dpp v40, v2, v3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n" Q2 "v_add_u32_dpp v41, v2, v3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n" Q3 "v_add_u32_dpp v42, v2, v3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n" Q4 "v_add_u32_dpp v43, v2, v3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n" ::: CLOB);
+#define MIX4(I) Q1 I(40) Q2 I(41) Q3 I(42) Q4 I(43)
+#define I_MAD16(D) "v_mad_u32_u16 v" #D ", v2, 64, v3 op_sel:[1,0,0,0]\n"
+#define I_MAD24(D) "v_mad_u32_u24 v" #D ", v2, 64, v3\n"
+#define I_LSHLADD(D) "v_lshl_add_u32 v" #D ", v2, 6, v3\n"
+#define I_BFE(D) "v_bfe_u32 v" #D ", v2, 0, 16\n"
+#define I_ANDLIT(D) "v_and_b32 v" #D ", 0xffff, v2\n"
+#define I_LSHR(D) "v_lshrrev_b32 v" #D ", 16, v2\n"
+#define I_SDWA(D) "v_add_u32_sdwa v" #D ", v3, v2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define I_MOVDPP(D) "v_mov_b32_dpp v" #D ", v2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n"
+#define I_PERM(D) "v_perm_b32 v" #D ", v2, v3, v2\n"
+    if (KIND == 7) asm volatile(MIX4(I_MAD16) ::: CLOB);
+    if (KIND == 8) asm volatile(MIX4(I_MAD24) ::: CLOB);
+    if (KIND == 9) asm volatile(MIX4(I_LSHLADD) ::: CLOB);
+    if (KIND == 10) asm volatile(MIX4(I_BFE) ::: CLOB);
+    if (KIND == 11) asm volatile(MIX4(I_ANDLIT) ::: CLOB);
+    if (KIND == 12) asm volatile(MIX4(I_LSHR) ::: CLOB);
+    if (KIND == 13) asm volatile(MIX4(I_SDWA) ::: CLOB);
+    if (KIND == 14) asm volatile(MIX4(I_MOVDPP) ::: CLOB);
+    if (KIND == 15) asm volatile(MIX4(I_PERM) ::: CLOB);
     if (KIND == 6) asm volatile(Q1 "v_add_u32 v40, v2, v3\n" Q2 "v_add_u32 v41, v2, v3\n" Q3 "v_add_u32 v42, v2, v3\n" Q4 "v_add_u32 v43, v2, v3\n" ::: CLOB);
   }
   uint32_t s;
@@ -61,6 +80,15 @@ int main() {
     run<4>("16 bitop3 + 4 ds_read_b128", d, w);
     run<5>("16 bitop3 + 4 v_add_u32_dpp", d, w);
     run<6>("16 bitop3 + 4 v_add_u32", d, w);
+    run<7>("16 bitop3 + 4 v_mad_u32_u16", d, w);
+    run<8>("16 bitop3 + 4 v_mad_u32_u24", d, w);
+    run<9>("16 bitop3 + 4 v_lshl_add_u32", d, w);
+    run<10>("16 bitop3 + 4 v_bfe_u32", d, w);
+    run<11>("16 bitop3 + 4 v_and_b32 literal", d, w);
+    run<12>("16 bitop3 + 4 v_lshrrev_b32", d, w);
+    run<13>("16 bitop3 + 4 v_add_u32_sdwa", d, w);
+    run<14>("16 bitop3 + 4 v_mov_b32_dpp", d, w);
+    run<15>("16 bitop3 + 4 v_perm_b32", d, w);
   }
   return 0;
 }
