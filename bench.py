@@ -198,7 +198,9 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
                            else "tools/valu_peak.hip (v_and_b32 + v_bcnt_u32_b32)",
             "frac": valu_insts * 64.0 / (k3_ms * 1e-3)
                     / (VALU_PEAK_BITOP3 if use_lists else VALU_PEAK_AND_BCNT),
-            "source": traffic_src},
+            "source": traffic_src,
+            "clock_note": "the list kernel runs at the socket power cap: 1.37 kW, shader clock "
+                          "2.15 of 2.4 GHz (profiles/r01_clock_power.txt)" if use_lists else None},
     }
 
 
