@@ -406,34 +406,45 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
 __device__ __forceinline__ uint4 lds128_at(const uint32_t* lds, uint32_t byte_off) {
   return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds) + byte_off);
 }
-#ifdef SCOARY_EXP_NOLDS   /* experiment: no LDS traffic, rows are a function of the address */
-#define SCOARY_EXP_READ(v, lds, a) const uint4 v = {a, a * 3u, a ^ 0x55u, a + 7u};
-#else
-#define SCOARY_EXP_READ(v, lds, a) const uint4 v = lds128_at(lds, a);
-#endif
 struct Rows4 { uint32_t w0[4], w1[4], w2[4], w3[4]; };   // 4 tile rows x 4 permutation words
 // The 4 entries held by lane H of every LPG-lane gene group -> 4 ds_read_b128.
+// The four address adds (entry of lane H, DPP quad_perm broadcast, + column) are issued
+// back to back from one asm block: a DPP add between v_bitop3 ops costs ~10 cycles, four in
+// a row ~10 together (tools/valu_mix.hip -- the price is the switch, not the op).
+#define SCOARY_DPP4(QP)                                                                  \
+  asm("v_add_u32_dpp %0, %4, %8 " QP " row_mask:0xf bank_mask:0xf\n"                    \
+      "v_add_u32_dpp %1, %5, %8 " QP " row_mask:0xf bank_mask:0xf\n"                    \
+      "v_add_u32_dpp %2, %6, %8 " QP " row_mask:0xf bank_mask:0xf\n"                    \
+      "v_add_u32_dpp %3, %7, %8 " QP " row_mask:0xf bank_mask:0xf"                       \
+      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])                               \
+      : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(colb))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int LPG, int H>
 __device__ __forceinline__ void read4x4(Rows4& x, const uint32_t* __restrict__ lds,
                                         const uint32_t (&e)[4], uint32_t colb) {
-  // quad_perm broadcast of lane H of the group: [H,H,H,H] or [H,H,2+H,2+H]
-  constexpr int kCtrl = LPG == 4 ? H * 0x55 : 0xA0 + H * 0x55;
-#define RD(J)                                                                                      \
-  {                                                                                                \
-    uint32_t a;                                                                                    \
-    if constexpr (LPG == 1)                                                                        \
-      a = e[J];                                                                                    \
-    else                                                                                           \
-      a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e[J], kCtrl, 0xf, 0xf, false) + colb;      \
-    SCOARY_EXP_READ(v, lds, a)                                                                     \
-    x.w0[J] = v.x;                                                                                 \
-    x.w1[J] = v.y;                                                                                 \
-    x.w2[J] = v.z;                                                                                 \
-    x.w3[J] = v.w;                                                                                 \
+  uint32_t a[4];
+  if constexpr (LPG == 1) {
+    a[0] = e[0], a[1] = e[1], a[2] = e[2], a[3] = e[3];
+  } else if constexpr (LPG == 4) {             // lane H of the quad
+    if constexpr (H == 0) SCOARY_DPP4("quad_perm:[0,0,0,0]");
+    if constexpr (H == 1) SCOARY_DPP4("quad_perm:[1,1,1,1]");
+    if constexpr (H == 2) SCOARY_DPP4("quad_perm:[2,2,2,2]");
+    if constexpr (H == 3) SCOARY_DPP4("quad_perm:[3,3,3,3]");
+  } else {                                     // lane H of each pair
+    if constexpr (H == 0) SCOARY_DPP4("quad_perm:[0,0,2,2]");
+    if constexpr (H == 1) SCOARY_DPP4("quad_perm:[1,1,3,3]");
   }
-  RD(0) RD(1) RD(2) RD(3)
-#undef RD
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // colb carries the tile's LDS address: a[j] is the absolute LDS address of the row piece
+    const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)a[j];
+    x.w0[j] = v.x;
+    x.w1[j] = v.y;
+    x.w2[j] = v.z;
+    x.w3[j] = v.w;
+  }
 }
+#undef SCOARY_DPP4
 // 4 row words -> counter planes 0..1 of word W, returns the carry of weight 4
 template <int W>
 __device__ __forceinline__ uint32_t sum4(uint32_t (&c)[16], const uint32_t (&x)[4]) {
@@ -479,6 +490,11 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   }
   __syncthreads();
 
+  // LPG == 1: an entry is used as the LDS address as it is -- the tile is the kernel's only LDS
+  // object and sits at LDS address 0
+  if constexpr (LPG == 1)
+    if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds != 0u)
+      __builtin_trap();
   const int ngroups = (G + GPW - 1) / GPW;         // wave groups of GPW genes
   const int q_lo = blockIdx.y * groups_per_block;
   const int q_hi = min(ngroups, q_lo + groups_per_block);
@@ -492,7 +508,9 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     // wave-uniform base of the group's lists; lane l reads vector piece*64 + l
     const Ent* gbase = reinterpret_cast<const Ent*>(lidx) +
                        (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 8;
-    const uint32_t colb = (uint32_t)col * 16u;
+    // this lane's column of a tile row, as an absolute LDS address (entries are row byte offsets)
+    const uint32_t colb = (uint32_t)col * 16u +
+                          (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds;
 
     uint32_t c0[16], c1[16], c2[16], c3[16];
 #pragma unroll

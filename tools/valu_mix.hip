@@ -42,6 +42,11 @@ __global__ __launch_bounds__(64) void k(uint32_t* out, int iters) {
     if (KIND == 13) asm volatile(MIX4(I_SDWA) ::: CLOB);
     if (KIND == 14) asm volatile(MIX4(I_MOVDPP) ::: CLOB);
     if (KIND == 15) asm volatile(MIX4(I_PERM) ::: CLOB);
+#define TAIL4(I) Q1 Q2 Q3 Q4 I(40) I(41) I(42) I(43)
+#define I_ADDDPP(D) "v_add_u32_dpp v" #D ", v2, v3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n"
+    if (KIND == 16) asm volatile(TAIL4(I_ADDDPP) ::: CLOB);        // the 4 odd ops back to back
+    if (KIND == 17) asm volatile(TAIL4(I_LSHLADD) ::: CLOB);
+    if (KIND == 18) asm volatile(Q1 Q2 I_ADDDPP(40) I_ADDDPP(41) Q3 Q4 I_ADDDPP(42) I_ADDDPP(43) ::: CLOB);
     if (KIND == 6) asm volatile(Q1 "v_add_u32 v40, v2, v3\n" Q2 "v_add_u32 v41, v2, v3\n" Q3 "v_add_u32 v42, v2, v3\n" Q4 "v_add_u32 v43, v2, v3\n" ::: CLOB);
   }
   uint32_t s;
@@ -89,6 +94,9 @@ int main() {
     run<13>("16 bitop3 + 4 v_add_u32_sdwa", d, w);
     run<14>("16 bitop3 + 4 v_mov_b32_dpp", d, w);
     run<15>("16 bitop3 + 4 v_perm_b32", d, w);
+    run<16>("16 bitop3, 4 v_add_u32_dpp in a row", d, w);
+    run<17>("16 bitop3, 4 v_lshl_add in a row", d, w);
+    run<18>("8 bitop3, 2 dpp, 8 bitop3, 2 dpp", d, w);
   }
   return 0;
 }
