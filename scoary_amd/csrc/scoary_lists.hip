@@ -21,11 +21,14 @@ namespace {
 //
 // TW = tile row width in dwords (32 permutations each): 16 while a tile of 512
 // permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
-// N <= 5119, 4 (tiles of 128) up to N <= 10239.  A gene takes TW/4 lanes and a
-// wavefront 256/TW genes of similar list length.
+// N <= 5119, 4 (tiles of 128) up to N <= 10239, 2 (tiles of 64, two words per lane)
+// up to N <= 20479.  A gene takes max(TW/4, 1) lanes and a wavefront 64 / that many
+// genes of similar list length.
 __host__ __device__ constexpr int list_tw(int64_t N) {
-  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : 0));
+  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : (N <= 20479 ? 2 : 0)));
 }
+__host__ __device__ constexpr int list_lpg(int TW) { return TW >= 4 ? TW / 4 : 1; }   // lanes per gene
+__host__ __device__ constexpr int list_nw(int TW) { return TW >= 4 ? 4 : TW; }        // words per lane
 // dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
 __host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int TW) {
   return ((N + 1) * TW + 3) / 4 * 4;
@@ -90,12 +93,23 @@ __device__ __forceinline__ uint32_t region_lt(const uint32_t (&c)[16], uint32_t 
 // (scoary_ctr_regs.inc) whose bank is never the bank of a row word W: the full
 // adders that consume LDS rows (half of all) then never have src0 and src1 in
 // one bank, and for the adders on carries the assembler still picks the order.
-template <int W, int K>
-struct Ctr;
 #define SCOARY_SYM3_INPLACE(LUT)                                                      \
   ".if scoary_bank_%0 != scoary_bank_%1\n v_bitop3_b32 %0, %0, %1, %2 bitop3:" LUT    \
   "\n.elseif scoary_bank_%0 != scoary_bank_%2\n v_bitop3_b32 %0, %0, %2, %1 bitop3:" LUT \
   "\n.else\n v_bitop3_b32 %0, %1, %2, %0 bitop3:" LUT "\n.endif"
+// planes without a pinned register (plane 13 of the two-word kernel): allocator's choice
+template <int W, int K>
+struct Ctr {
+  static __device__ __forceinline__ uint32_t maj(uint32_t c, uint32_t x, uint32_t y) {
+    uint32_t d;
+    asm(SCOARY_SYM3("0xe8") : "=v"(d) : "v"(c), "v"(x), "v"(y));
+    return d;
+  }
+  static __device__ __forceinline__ void xor3(uint32_t& c, uint32_t x, uint32_t y) {
+    asm(SCOARY_SYM3_INPLACE("0x96") : "+v"(c) : "v"(x), "v"(y));
+  }
+  static __device__ __forceinline__ void xor2(uint32_t& c, uint32_t x) { c ^= x; }
+};
 #define SCOARY_CTR(W, K, R)                                                            \
   template <>                                                                          \
   struct Ctr<W, K> {                                                                   \
@@ -403,9 +417,6 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
 // ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, ... over the full
 // 256-byte bank row: with slot k starting at residue class k mod (64/TW)
 // (scoary_lists_build) the genes of a group sit on distinct 4*TW-byte slots.
-__device__ __forceinline__ uint4 lds128_at(const uint32_t* lds, uint32_t byte_off) {
-  return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(lds) + byte_off);
-}
 struct Rows4 { uint32_t w0[4], w1[4], w2[4], w3[4]; };   // 4 tile rows x 4 permutation words
 // The 4 entries held by lane H of every LPG-lane gene group -> 4 ds_read_b128.
 // The four address adds (entry of lane H, DPP quad_perm broadcast, + column) are issued
@@ -419,9 +430,9 @@ struct Rows4 { uint32_t w0[4], w1[4], w2[4], w3[4]; };   // 4 tile rows x 4 perm
       : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])                               \
       : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(colb))
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <int LPG, int H>
-__device__ __forceinline__ void read4x4(Rows4& x, const uint32_t* __restrict__ lds,
-                                        const uint32_t (&e)[4], uint32_t colb) {
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int LPG, int H, int NW>
+__device__ __forceinline__ void read4x4(Rows4& x, const uint32_t (&e)[4], uint32_t colb) {
   uint32_t a[4];
   if constexpr (LPG == 1) {
     a[0] = e[0], a[1] = e[1], a[2] = e[2], a[3] = e[3];
@@ -437,11 +448,17 @@ __device__ __forceinline__ void read4x4(Rows4& x, const uint32_t* __restrict__ l
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     // colb carries the tile's LDS address: a[j] is the absolute LDS address of the row piece
-    const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)a[j];
-    x.w0[j] = v.x;
-    x.w1[j] = v.y;
-    x.w2[j] = v.z;
-    x.w3[j] = v.w;
+    if constexpr (NW == 4) {
+      const u32x4 v = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)a[j];
+      x.w0[j] = v.x;
+      x.w1[j] = v.y;
+      x.w2[j] = v.z;
+      x.w3[j] = v.w;
+    } else {                                   // two words per lane: ds_read_b64
+      const u32x2 v = *(const __attribute__((address_space(3))) u32x2*)(uintptr_t)a[j];
+      x.w0[j] = v.x;
+      x.w1[j] = v.y;
+    }
   }
 }
 #undef SCOARY_DPP4
@@ -455,9 +472,10 @@ __device__ __forceinline__ uint32_t sum4(uint32_t (&c)[16], const uint32_t (&x)[
 struct Carry4 { uint32_t w[4]; };
 
 // LPG lanes per gene (4, 2, 1 for 16-, 8-, 4-dword tile rows), 64/LPG genes per
-// wavefront.  Lists are walked in sub-steps of 4 entries: lane j of a gene group
-// holds entries 4j..4j+3 of each 4*LPG-entry piece.
-template <int LPG, int KC, int KD>
+// wavefront, NW permutation words per lane (4; 2 for the 2-dword rows of N > 10239,
+// one lane per gene).  Lists are walked in sub-steps of 4 entries: lane j of a gene
+// group holds entries 4j..4j+3 of each 4*LPG-entry piece.
+template <int LPG, int NW, int KC, int KD>
 __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
                                                         const uint32_t* __restrict__ lidx,
                                                         const int32_t* __restrict__ lstart,
@@ -469,7 +487,8 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
                                                         uint32_t* __restrict__ r) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
   scoary_bank_defs();                // assembler symbols for the operand-ordering .if blocks
-  constexpr int TW = 4 * LPG;        // tile row, dwords
+  constexpr int TW = NW * LPG;       // tile row, dwords
+  static_assert(NW == 4 || (NW == 2 && LPG == 1), "2 words per lane only with one lane per gene");
   constexpr int GPW = kWave / LPG;   // genes per wavefront
   const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -482,7 +501,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     // per instruction straight into LDS (destination = wave-uniform base + 16*lane),
     // no VGPR round trip and no ds_write pass
     const uint4* src4 = reinterpret_cast<const uint4*>(src);
-    const int n4 = tile_dwords / 4;
+    const int n4 = (int)(list_tile_dwords(N, TW) / 4);   // HBM tiles are padded to 16 bytes
     for (int i = wave * kWave; i < n4; i += nwaves * kWave)
       if (i + lane < n4)
         __builtin_amdgcn_global_load_lds(src4 + i + lane, tile_lds + (size_t)i * 4, 16, 0, 0);
@@ -509,7 +528,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const Ent* gbase = reinterpret_cast<const Ent*>(lidx) +
                        (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 8;
     // this lane's column of a tile row, as an absolute LDS address (entries are row byte offsets)
-    const uint32_t colb = (uint32_t)col * 16u +
+    const uint32_t colb = (uint32_t)col * (NW * 4u) +
                           (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds;
 
     uint32_t c0[16], c1[16], c2[16], c3[16];
@@ -520,8 +539,12 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
       Carry4 b;
       b.w[0] = sum4<0>(c0, x.w0);
       b.w[1] = sum4<1>(c1, x.w1);
-      b.w[2] = sum4<2>(c2, x.w2);
-      b.w[3] = sum4<3>(c3, x.w3);
+      if constexpr (NW > 2) {
+        b.w[2] = sum4<2>(c2, x.w2);
+        b.w[3] = sum4<3>(c3, x.w3);
+      } else {
+        b.w[2] = b.w[3] = 0u;
+      }
       return b;
     };
 #define FA4(PLANE, A, B)                                               \
@@ -529,8 +552,8 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     {                                                                  \
       full_add<0, PLANE>(c0[PLANE], (A).w[0], (B).w[0]),               \
           full_add<1, PLANE>(c1[PLANE], (A).w[1], (B).w[1]),           \
-          full_add<2, PLANE>(c2[PLANE], (A).w[2], (B).w[2]),           \
-          full_add<3, PLANE>(c3[PLANE], (A).w[3], (B).w[3])            \
+          NW > 2 ? full_add<2, PLANE>(c2[PLANE], (A).w[2], (B).w[2]) : 0u, \
+          NW > 2 ? full_add<3, PLANE>(c3[PLANE], (A).w[3], (B).w[3]) : 0u  \
     }                                                                  \
   }
     // pieces of 4*LPG entries; the index loads run three pieces ahead in a ring of
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
       return Ent{{v.x, v.y, v.z, v.w}};
     };
     Ent ring[4] = {load_piece(0), load_piece(1), load_piece(2), load_piece(3)};
-    read4x4<LPG, 0>(xa, tile_lds, ring[0].e, colb);
+    read4x4<LPG, 0, NW>(xa, ring[0].e, colb);
     // sub-step S of step K (both literals): issue the reads of the next sub-step into
     // `other`, sum `mine`
 #define SUBSTEP(K, S, MINE, OTHER)                                          \
@@ -562,9 +585,9 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     if constexpr (Hn == 0) {                     /* piece finished: refill its slot */ \
       ring[kCur] = load_piece(piece + 4);                                    \
       ++piece;                                                               \
-      read4x4<LPG, 0>(OTHER, tile_lds, ring[(kCur + 1) % 4].e, colb);         \
+      read4x4<LPG, 0, NW>(OTHER, ring[(kCur + 1) % 4].e, colb);               \
     } else {                                                                 \
-      read4x4<LPG, Hn>(OTHER, tile_lds, ring[kCur].e, colb);                  \
+      read4x4<LPG, Hn, NW>(OTHER, ring[kCur].e, colb);                        \
     }                                                                        \
     return s4(MINE);                                                         \
   }()
@@ -599,11 +622,13 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     Carry4 nc = {{c0[K] & carry.w[0], c1[K] & carry.w[1], c2[K] & carry.w[2], c3[K] & carry.w[3]}}; \
     Ctr<0, K>::xor2(c0[K], carry.w[0]);                                 \
     Ctr<1, K>::xor2(c1[K], carry.w[1]);                                 \
-    Ctr<2, K>::xor2(c2[K], carry.w[2]);                                 \
-    Ctr<3, K>::xor2(c3[K], carry.w[3]);                                 \
+    if constexpr (NW > 2) {                                             \
+      Ctr<2, K>::xor2(c2[K], carry.w[2]);                               \
+      Ctr<3, K>::xor2(c3[K], carry.w[3]);                               \
+    }                                                                   \
     carry = nc;                                                         \
   }
-      RIPPLE(7) RIPPLE(8) RIPPLE(9) RIPPLE(10) RIPPLE(11) RIPPLE(12)
+      RIPPLE(7) RIPPLE(8) RIPPLE(9) RIPPLE(10) RIPPLE(11) RIPPLE(12) RIPPLE(13)
 #undef RIPPLE
     }
 #undef STEP
@@ -616,14 +641,16 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     uint32_t valid[4];                                // permutations of this tile that exist
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const int64_t p_first = ((int64_t)tile * TW + 4 * col + w) * 32;
+      const int64_t p_first = ((int64_t)tile * TW + NW * col + w) * 32;
       valid[w] = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
     }
     int cnt = 0;
     cnt += __popc((((~region_lt<KC, KD>(c0, base, span)) ^ inv) | always) & valid[0]);
     cnt += __popc((((~region_lt<KC, KD>(c1, base, span)) ^ inv) | always) & valid[1]);
-    cnt += __popc((((~region_lt<KC, KD>(c2, base, span)) ^ inv) | always) & valid[2]);
-    cnt += __popc((((~region_lt<KC, KD>(c3, base, span)) ^ inv) | always) & valid[3]);
+    if constexpr (NW > 2) {
+      cnt += __popc((((~region_lt<KC, KD>(c2, base, span)) ^ inv) | always) & valid[2]);
+      cnt += __popc((((~region_lt<KC, KD>(c3, base, span)) ^ inv) | always) & valid[3]);
+    }
     if (!have) cnt = 0;
 #pragma unroll
     for (int off = LPG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
@@ -643,15 +670,15 @@ int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
   return T * ntiles * list_tile_dwords(N, TW);
 }
 int64_t scoary_list_tile_words(int64_t N) { return list_tw(N) ? list_tile_dwords(N, list_tw(N)) : 0; }
-int64_t scoary_list_max_isolates(void) { return 10239; }
+int64_t scoary_list_max_isolates(void) { return 20479; }
 int scoary_list_params(int64_t N, int64_t* out5) {
   if (!out5) return SCOARY_ERR_ARG;
   const int TW = list_tw(N);
   out5[0] = TW;                     /* tile row width in dwords (0: N too large for LDS tiles) */
   out5[1] = TW * 4;                 /* LDS / tile row stride in bytes */
-  out5[2] = TW ? 4 * kWave / TW : 0;   /* genes per wavefront: lists padded to equal length */
+  out5[2] = TW ? kWave / list_lpg(TW) : 0;   /* genes per wavefront: lists padded to equal length */
   out5[3] = TW ? 64 / TW : 0;       /* residue classes of the isolate index (256-byte bank row) */
-  out5[4] = TW;                     /* interleave piece, entries */
+  out5[4] = TW ? 4 * list_lpg(TW) : 0;   /* interleave piece, entries */
   return TW ? SCOARY_OK : SCOARY_ERR_SIZE;
 }
 
@@ -693,7 +720,7 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
     hipLaunchKernelGGL((k_perm_generate_tiles<TWV>), grid, dim3(kWave), 0, s, d_masks, d_margins, \
                        (int)N, (int)scoary_row_words(N), P, perm_base, (int)trait_base,           \
                        (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
-  if (TW == 16) { GEN_TILES(16); } else if (TW == 8) { GEN_TILES(8); } else { GEN_TILES(4); }
+  if (TW == 16) { GEN_TILES(16); } else if (TW == 8) { GEN_TILES(8); } else if (TW == 4) { GEN_TILES(4); } else { GEN_TILES(2); }
 #undef GEN_TILES
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
@@ -715,7 +742,7 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   }
   const int64_t tile_perms = TW * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  constexpr int GPW = 4 * kWave / TW;           // genes per wavefront
+  constexpr int GPW = kWave / list_lpg(TW);     // genes per wavefront
   const int64_t ngroups = (G + GPW - 1) / GPW;
   // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index
   // lists (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the
@@ -728,14 +755,14 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   int64_t gpb = (ngroups + chunks - 1) / chunks;
   gpb = (gpb + 15) / 16 * 16;
   chunks = (ngroups + gpb - 1) / gpb;
-  const size_t lds = (size_t)(N + 1) * TW * sizeof(uint32_t);
+  const size_t lds = (size_t)list_tile_dwords(N, TW) * sizeof(uint32_t);
   if (!(h->lists_lds_optin & TW)) {   // once per handle (= per device) and tile width
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_permute_lists<TW / 4, KC, KD>),
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     h->lists_lds_optin |= TW;
   }
   KernelTimer kt(h, s, "k_permute_lists");
-  hipLaunchKernelGGL((k_permute_lists<TW / 4, KC, KD>), dim3((unsigned)(ntiles * T), (unsigned)chunks),
+  hipLaunchKernelGGL((k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>), dim3((unsigned)(ntiles * T), (unsigned)chunks),
                      dim3(1024), lds, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                      reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P, (int)ntiles,
                      (int)gpb, d_r);
@@ -767,7 +794,10 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   if (TW == 8)
     return launch_permute_lists<8, 12, 14>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                            d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  return launch_permute_lists<4, 13, 15>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+  if (TW == 4)
+    return launch_permute_lists<4, 13, 15>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                           d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  return launch_permute_lists<2, 14, 16>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                          d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
 }
 
