@@ -155,6 +155,26 @@ class Exchange:
         self.step_no += 1
 
 
+def measured_copy_peak(device):
+    """Device-to-device copy rate (read + write bytes per second) of a 1 GiB buffer: the
+    measured HBM figure SURVEY 8d asks for next to the 8 TB/s datasheet peak."""
+    import torch
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    src.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        dst.copy_(src)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
     """The `roofline` object: operand-bandwidth model, measured HBM
     traffic and VALU instruction count from the committed PMC passes."""
@@ -168,6 +188,7 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
     traffic, traffic_src, valu_insts = load_traffic(args.config, default_sizes, k3_name)
     w32 = -(-N // 32)
     valu_ops = tests_per_launch * (2.0 * w32 + 6)     # dense-kernel op model (reference point)
+    copy_gbs = measured_copy_peak(eng.device)
     return {
         "bound": "hbm",
         "kernel": k3_name,
@@ -178,6 +199,9 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
         "traffic": traffic,
         "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024",
         "traffic_source": traffic_src,
+        "traffic_gbs": None if not traffic else traffic / (k3_ms * 1e-3) / 1e9,
+        "measured_copy_peak_gbs": copy_gbs,            # torch D2D copy of 1 GiB, read + write
+        "frac_of_measured_copy": achieved / copy_gbs,
         "algorithmic_bytes_per_launch": alg_bytes,
         "model": "operand bytes 16*ceil(N/64) B per test (SURVEY 8d); frac > 1 means the "
                  "kernel left the HBM-bound regime (operands reused from VGPR/SGPR)",
