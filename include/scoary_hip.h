@@ -134,8 +134,9 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
  * different data flow: genes as lists of the isolates that carry their
  * minority value (built once per dataset by scoary_lists_build,
  * include/scoary_io.h), permuted labels as isolate-major tiles of 512 / 256 /
- * 128 / 64 permutations (N <= 2559 / 5119 / 10239 / 20479) that live in LDS,
- * overlap counts as bit-sliced counters, 128 (64 for the last) permutations per lane.  Cost
+ * 128 / 64 / 32 permutations (N <= 2559 / 5119 / 10239 / 20479 / 40959) that live
+ * in LDS, overlap counts as bit-sliced counters, 128 (64, 32 for the last two)
+ * permutations per lane.  Cost
  * is proportional to the list length, so sparse (or near-core) genes are
  * cheap.  Available while a tile fits in LDS: N <= scoary_list_max_isolates().
  *   d_tiles : uint32 [scoary_list_tiles_words(N, P, T)]
@@ -146,7 +147,7 @@ int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T);
 int64_t scoary_list_tile_words(int64_t N);   /* dwords per (trait, tile) */
 int64_t scoary_list_max_isolates(void);
 /* out5 = { tile row width in dwords of 32 permutations (16 for N <= 2559, 8 for N <= 5119,
- * 4 for N <= 10239, 2 for N <= 20479), row stride in bytes, genes per wavefront, residue classes,
+ * 4 for N <= 10239, 2 for N <= 20479, 1 for N <= 40959), row stride in bytes, genes per wavefront, residue classes,
  * interleave piece } -- the last four are the arguments scoary_lists_build
  * wants.  Error if N is too large. */
 int scoary_list_params(int64_t N, int64_t *out5);

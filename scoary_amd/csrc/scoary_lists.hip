@@ -22,10 +22,10 @@ namespace {
 // TW = tile row width in dwords (32 permutations each): 16 while a tile of 512
 // permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
 // N <= 5119, 4 (tiles of 128) up to N <= 10239, 2 (tiles of 64, two words per lane)
-// up to N <= 20479.  A gene takes max(TW/4, 1) lanes and a wavefront 64 / that many
-// genes of similar list length.
+// up to N <= 20479, 1 (tiles of 32, one word per lane) up to N <= 40959.  A gene takes
+// max(TW/4, 1) lanes and a wavefront 64 / that many genes of similar list length.
 __host__ __device__ constexpr int list_tw(int64_t N) {
-  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : (N <= 20479 ? 2 : 0)));
+  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : (N <= 20479 ? 2 : (N <= 40959 ? 1 : 0))));
 }
 __host__ __device__ constexpr int list_lpg(int TW) { return TW >= 4 ? TW / 4 : 1; }   // lanes per gene
 __host__ __device__ constexpr int list_nw(int TW) { return TW >= 4 ? 4 : TW; }        // words per lane
@@ -139,6 +139,28 @@ __device__ __forceinline__ uint32_t full_add(uint32_t& c, uint32_t x, uint32_t y
 // zero; dword j of a row = labels of permutations tile*TW*32 + 32j .. +31.
 // One wavefront generates 64 consecutive permutations (spec S4, same draws as
 // k_perm_generate) and transposes them with ballots.
+// Where the 64 permutations of generator wavefront `wave` go: dwords lo / hi of tile rows
+// `stride` dwords apart.  TW >= 2: two adjacent dwords of one tile; TW == 1: the rows of two
+// consecutive 32-permutation tiles (hi == nullptr when the second tile does not exist).
+struct TileOut {
+  uint32_t* lo;
+  uint32_t* hi;
+  int stride;
+};
+template <int TW>
+__device__ __forceinline__ TileOut tile_out(uint32_t* tiles, int t, int ntiles, int64_t wave, int N) {
+  const int64_t tile_dw = list_tile_dwords(N, TW);
+  if constexpr (TW >= 2) {
+    const int waves_per_tile = TW / 2;
+    const int tile = (int)(wave / waves_per_tile);
+    const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
+    uint32_t* base = tiles + ((int64_t)t * ntiles + tile) * tile_dw + col;
+    return {base, base + 1, TW};
+  } else {
+    uint32_t* base = tiles + ((int64_t)t * ntiles + 2 * wave) * tile_dw;
+    return {base, 2 * wave + 1 < ntiles ? base + tile_dw : nullptr, 1};
+  }
+}
 template <int TW>
 __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __restrict__ masks,
                                                             const int32_t* __restrict__ margins,
@@ -152,10 +174,7 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
   const int64_t pl = wave * kWave + lane;
   const bool live = pl < P;
   const uint32_t pi = (uint32_t)(perm_base + pl);
-  const int waves_per_tile = TW / 2;
-  const int tile = (int)(wave / waves_per_tile);
-  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
-  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW) + col;
+  const TileOut out = tile_out<TW>(tiles, t, ntiles, wave, N);
   uint32_t needed = (uint32_t)margins[2 * t], remaining = (uint32_t)margins[2 * t + 1];
   const uint32_t* mrow = masks + (int64_t)t * Wp;
   const int nw = (N + 31) / 32;
@@ -183,8 +202,8 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
         if ((iso & 63) == 63 || iso == nw * 32 - 1) {  // 64 isolates collected: one row per lane
           const int row = (iso & ~63) + lane;
           if (row < N) {
-            base[(int64_t)row * TW] = (uint32_t)mine;
-            base[(int64_t)row * TW + 1] = (uint32_t)(mine >> 32);
+            out.lo[(int64_t)row * out.stride] = (uint32_t)mine;
+            if (out.hi) out.hi[(int64_t)row * out.stride] = (uint32_t)(mine >> 32);
           }
           mine = 0;
         }
@@ -192,8 +211,8 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
     }
   }
   if (lane == 0) {  // the all-zero row that list padding points at
-    base[(int64_t)N * TW] = 0u;
-    base[(int64_t)N * TW + 1] = 0u;
+    out.lo[(int64_t)N * out.stride] = 0u;
+    if (out.hi) out.hi[(int64_t)N * out.stride] = 0u;
   }
 }
 
@@ -255,10 +274,7 @@ __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_til
   const int64_t pl = wave * kWave + lane;
   const bool live = pl < P;
   const uint32_t pi = (uint32_t)(perm_base + pl);
-  const int waves_per_tile = TW / 2;
-  const int tile = (int)(wave / waves_per_tile);
-  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
-  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW) + col;
+  const TileOut out = tile_out<TW>(tiles, t, ntiles, wave, N);
   uint32_t needed = (uint32_t)margins[2 * t];
   const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
   // valid isolates left at the start of the chunk this wavefront works on
@@ -305,15 +321,15 @@ __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_til
         select_rows<0, false>(x, mw, livemask, needed, lo, hi);
       const int row = cc * kGenChunk + lane;
       if (row < N) {
-        base[(int64_t)row * TW] = lo;
-        base[(int64_t)row * TW + 1] = hi;
+        out.lo[(int64_t)row * out.stride] = lo;
+        if (out.hi) out.hi[(int64_t)row * out.stride] = hi;
       }
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {  // the all-zero row that list padding points at
-    base[(int64_t)N * TW] = 0u;
-    base[(int64_t)N * TW + 1] = 0u;
+    out.lo[(int64_t)N * out.stride] = 0u;
+    if (out.hi) out.hi[(int64_t)N * out.stride] = 0u;
   }
 }
 
@@ -334,10 +350,7 @@ __global__ __launch_bounds__(kWave * 4) void k_perm_generate_tiles_wg4(
   const int64_t pl = wave * kWave + lane;
   const bool live = pl < P;
   const uint32_t pi = (uint32_t)(perm_base + pl);
-  const int waves_per_tile = TW / 2;
-  const int tile = (int)(wave / waves_per_tile);
-  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
-  uint32_t* base = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW) + col;
+  const TileOut out = tile_out<TW>(tiles, t, ntiles, wave, N);
   uint32_t needed = (uint32_t)margins[2 * t];
   const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
   uint32_t remaining = (uint32_t)__builtin_amdgcn_readfirstlane(margins[2 * t + 1]);
@@ -373,15 +386,15 @@ __global__ __launch_bounds__(kWave * 4) void k_perm_generate_tiles_wg4(
         select_rows<0, false>(x, mw, livemask, needed, lo, hi);
       const int row = c * kGenChunk + lane;
       if (row < N) {
-        base[(int64_t)row * TW] = lo;
-        base[(int64_t)row * TW + 1] = hi;
+        out.lo[(int64_t)row * out.stride] = lo;
+        if (out.hi) out.hi[(int64_t)row * out.stride] = hi;
       }
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) {  // the all-zero row that list padding points at
-    base[(int64_t)N * TW] = 0u;
-    base[(int64_t)N * TW + 1] = 0u;
+    out.lo[(int64_t)N * out.stride] = 0u;
+    if (out.hi) out.hi[(int64_t)N * out.stride] = 0u;
   }
 }
 
@@ -454,10 +467,12 @@ __device__ __forceinline__ void read4x4(Rows4& x, const uint32_t (&e)[4], uint32
       x.w1[j] = v.y;
       x.w2[j] = v.z;
       x.w3[j] = v.w;
-    } else {                                   // two words per lane: ds_read_b64
+    } else if constexpr (NW == 2) {            // two words per lane: ds_read_b64
       const u32x2 v = *(const __attribute__((address_space(3))) u32x2*)(uintptr_t)a[j];
       x.w0[j] = v.x;
       x.w1[j] = v.y;
+    } else {                                   // one word per lane: ds_read_b32
+      x.w0[j] = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)a[j];
     }
   }
 }
@@ -472,8 +487,8 @@ __device__ __forceinline__ uint32_t sum4(uint32_t (&c)[16], const uint32_t (&x)[
 struct Carry4 { uint32_t w[4]; };
 
 // LPG lanes per gene (4, 2, 1 for 16-, 8-, 4-dword tile rows), 64/LPG genes per
-// wavefront, NW permutation words per lane (4; 2 for the 2-dword rows of N > 10239,
-// one lane per gene).  Lists are walked in sub-steps of 4 entries: lane j of a gene
+// wavefront, NW permutation words per lane (4; 2 / 1 for the 2- / 1-dword rows of
+// N > 10239 / 20479, one lane per gene).  Lists are walked in sub-steps of 4 entries: lane j of a gene
 // group holds entries 4j..4j+3 of each 4*LPG-entry piece.
 template <int LPG, int NW, int KC, int KD>
 __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
   scoary_bank_defs();                // assembler symbols for the operand-ordering .if blocks
   constexpr int TW = NW * LPG;       // tile row, dwords
-  static_assert(NW == 4 || (NW == 2 && LPG == 1), "2 words per lane only with one lane per gene");
+  static_assert(NW == 4 || ((NW == 2 || NW == 1) && LPG == 1), "narrow rows: one lane per gene");
   constexpr int GPW = kWave / LPG;   // genes per wavefront
   const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     auto s4 = [&](const Rows4& x) -> Carry4 {
       Carry4 b;
       b.w[0] = sum4<0>(c0, x.w0);
-      b.w[1] = sum4<1>(c1, x.w1);
+      b.w[1] = NW > 1 ? sum4<1>(c1, x.w1) : 0u;
       if constexpr (NW > 2) {
         b.w[2] = sum4<2>(c2, x.w2);
         b.w[3] = sum4<3>(c3, x.w3);
@@ -551,7 +566,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   Carry4 {                                                             \
     {                                                                  \
       full_add<0, PLANE>(c0[PLANE], (A).w[0], (B).w[0]),               \
-          full_add<1, PLANE>(c1[PLANE], (A).w[1], (B).w[1]),           \
+          NW > 1 ? full_add<1, PLANE>(c1[PLANE], (A).w[1], (B).w[1]) : 0u, \
           NW > 2 ? full_add<2, PLANE>(c2[PLANE], (A).w[2], (B).w[2]) : 0u, \
           NW > 2 ? full_add<3, PLANE>(c3[PLANE], (A).w[3], (B).w[3]) : 0u  \
     }                                                                  \
@@ -621,14 +636,14 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   if constexpr (K < KC) {                                               \
     Carry4 nc = {{c0[K] & carry.w[0], c1[K] & carry.w[1], c2[K] & carry.w[2], c3[K] & carry.w[3]}}; \
     Ctr<0, K>::xor2(c0[K], carry.w[0]);                                 \
-    Ctr<1, K>::xor2(c1[K], carry.w[1]);                                 \
+    if constexpr (NW > 1) Ctr<1, K>::xor2(c1[K], carry.w[1]);           \
     if constexpr (NW > 2) {                                             \
       Ctr<2, K>::xor2(c2[K], carry.w[2]);                               \
       Ctr<3, K>::xor2(c3[K], carry.w[3]);                               \
     }                                                                   \
     carry = nc;                                                         \
   }
-      RIPPLE(7) RIPPLE(8) RIPPLE(9) RIPPLE(10) RIPPLE(11) RIPPLE(12) RIPPLE(13)
+      RIPPLE(7) RIPPLE(8) RIPPLE(9) RIPPLE(10) RIPPLE(11) RIPPLE(12) RIPPLE(13) RIPPLE(14)
 #undef RIPPLE
     }
 #undef STEP
@@ -646,7 +661,8 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     }
     int cnt = 0;
     cnt += __popc((((~region_lt<KC, KD>(c0, base, span)) ^ inv) | always) & valid[0]);
-    cnt += __popc((((~region_lt<KC, KD>(c1, base, span)) ^ inv) | always) & valid[1]);
+    if constexpr (NW > 1)
+      cnt += __popc((((~region_lt<KC, KD>(c1, base, span)) ^ inv) | always) & valid[1]);
     if constexpr (NW > 2) {
       cnt += __popc((((~region_lt<KC, KD>(c2, base, span)) ^ inv) | always) & valid[2]);
       cnt += __popc((((~region_lt<KC, KD>(c3, base, span)) ^ inv) | always) & valid[3]);
@@ -670,7 +686,7 @@ int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
   return T * ntiles * list_tile_dwords(N, TW);
 }
 int64_t scoary_list_tile_words(int64_t N) { return list_tw(N) ? list_tile_dwords(N, list_tw(N)) : 0; }
-int64_t scoary_list_max_isolates(void) { return 20479; }
+int64_t scoary_list_max_isolates(void) { return 40959; }
 int scoary_list_params(int64_t N, int64_t* out5) {
   if (!out5) return SCOARY_ERR_ARG;
   const int TW = list_tw(N);
@@ -697,7 +713,8 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t tile_perms = TW * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  const dim3 grid((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T);
+  // one generator wavefront per 64 permutations of a tile row (TW = 1: per two 32-permutation tiles)
+  const dim3 grid((unsigned)(TW >= 2 ? ntiles * (tile_perms / kWave) : (ntiles + 1) / 2), (unsigned)T);
   KernelTimer kt(h, s, "k_perm_generate_tiles");
   // three kernels for the same tiles, by how many 64-permutation wavefronts there are per
   // SIMD: < 1: a workgroup of 8 (Philox producers + one selection wavefront, latency
@@ -720,7 +737,7 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
     hipLaunchKernelGGL((k_perm_generate_tiles<TWV>), grid, dim3(kWave), 0, s, d_masks, d_margins, \
                        (int)N, (int)scoary_row_words(N), P, perm_base, (int)trait_base,           \
                        (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
-  if (TW == 16) { GEN_TILES(16); } else if (TW == 8) { GEN_TILES(8); } else if (TW == 4) { GEN_TILES(4); } else { GEN_TILES(2); }
+  if (TW == 16) { GEN_TILES(16); } else if (TW == 8) { GEN_TILES(8); } else if (TW == 4) { GEN_TILES(4); } else if (TW == 2) { GEN_TILES(2); } else { GEN_TILES(1); }
 #undef GEN_TILES
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
@@ -797,7 +814,10 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   if (TW == 4)
     return launch_permute_lists<4, 13, 15>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                            d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  return launch_permute_lists<2, 14, 16>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+  if (TW == 2)
+    return launch_permute_lists<2, 14, 16>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
+                                           d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+  return launch_permute_lists<1, 15, 17>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
                                          d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
 }
 

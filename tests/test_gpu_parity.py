@@ -324,6 +324,7 @@ def test_headline_config_properties(eng, orc):
     (90, 5000, 2, 257), (40, 5119, 1, 100),          # 8-dword tile rows, tiles of 256
     (50, 5120, 1, 129), (120, 7000, 2, 200), (70, 10000, 1, 130), (33, 10239, 1, 64),   # 4-dword
     (40, 10240, 1, 65), (130, 12001, 2, 130), (70, 16000, 1, 200), (65, 20479, 1, 64),   # 2-dword, two words per lane
+    (40, 20480, 1, 33), (100, 30001, 2, 70), (65, 40959, 1, 32),                         # 1-dword, one word per lane
 ])
 def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     """The list-driven kernel (minority lists + bit-sliced counters) gives
@@ -352,10 +353,10 @@ def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
 
 @pytest.mark.parametrize("N,T,P", [(333, 2, 700), (2700, 2, 700), (6000, 2, 700), (64, 1, 64),
                                    (333, 4, 17000), (100, 3, 180000), (12001, 2, 130),
-                                   (20479, 1, 70)])
+                                   (20479, 1, 70), (30001, 2, 100), (40959, 1, 33)])
 def test_perm_tiles_are_the_transposed_row_labels(eng, N, T, P):
     """k_perm_generate_tiles writes the same spec-S4 labels as k_perm_generate,
-    isolate-major in tiles of 512 / 256 / 128 permutations, zero row + zero ragged
+    isolate-major in tiles of 512 / 256 / 128 / 64 / 32 permutations, zero row + zero ragged
     tail.  Few (trait, 64-permutation) wavefronts -> the workgroup variant with
     Philox producer wavefronts; 1024..8191 of them (last-but-one case) -> the
     four-wavefront workgroup; more (last case) -> one wavefront each."""
@@ -433,7 +434,7 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_fisher(h, p, 0, p, p, null, null) == -1
     assert lib.scoary_permute(h, p, p, p, 1, 70000, 10, 10, p, null) == -3          # T > 65535
     assert lib.scoary_perm_generate(h, p, p, 1, 10, 2**33, 0, 0, 1, p, null) == -3   # index >= 2^32
-    assert lib.scoary_permute_lists(h, p, p, p, p, p, p, p, p, p, 4, 1, 20480, 10, p, null) == -3
+    assert lib.scoary_permute_lists(h, p, p, p, p, p, p, p, p, p, 4, 1, 40960, 10, p, null) == -3
     assert b"LDS" in lib.scoary_last_error(h)
     assert lib.scoary_tree_pairs(h, p, 3, 40, p, p, 1, 1, 2, p, null) == -3          # stack_depth > 32
     assert lib.scoary_counts(null, p, p, p, 1, 1, 1, p, p, null) == -1
@@ -444,5 +445,6 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_list_params(5000, params) == 0 and list(params) == [8, 32, 32, 8, 8]
     assert lib.scoary_list_params(5120, params) == 0 and list(params) == [4, 16, 64, 16, 4]
     assert lib.scoary_list_params(10240, params) == 0 and list(params) == [2, 8, 64, 32, 4]
-    assert lib.scoary_list_params(20480, params) == -3 and params[0] == 0
-    assert lib.scoary_list_max_isolates() == 20479
+    assert lib.scoary_list_params(20480, params) == 0 and list(params) == [1, 4, 64, 64, 4]
+    assert lib.scoary_list_params(40960, params) == -3 and params[0] == 0
+    assert lib.scoary_list_max_isolates() == 40959

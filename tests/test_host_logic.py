@@ -462,7 +462,7 @@ def test_io_library_exports_every_declared_symbol():
 # ------------------------------------------------- minority index lists ------
 @pytest.mark.parametrize("gpw,classes,stride,piece", [(4, 2, 64, 0), (8, 4, 32, 0), (16, 8, 16, 0),
                                                        (16, 4, 64, 16), (32, 8, 32, 8),
-                                                       (64, 16, 16, 4), (64, 32, 8, 4)])
+                                                       (64, 16, 16, 4), (64, 32, 8, 4), (64, 64, 4, 4)])
 def test_minority_lists_builder(gpw, classes, stride, piece):
     """scoary_lists_build (host native): per gene the positions of its minority
     value, padded with N to a multiple of 32 and to the wave group's longest list,

@@ -18,7 +18,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0
 for case in range(cases):
     N = int(rng.choice([1, 2, 31, 32, 33, 64, 100, 511, 1000, 2047, 2048, 2559, 2560, 3333, 5119, 5120,
-                        7777, 10239, 10240, 13001, 20479]))
+                        7777, 10239, 10240, 13001, 20479, 20480, 33333, 40959]))
     G = int(rng.choice([1, 3, 15, 16, 17, 63, 64, 65, 300, 1000, 4097]))
     T = int(rng.integers(1, 4))
     P = int(rng.choice([1, 100, 128, 129, 512, 513, 700]))
