@@ -15,7 +15,7 @@ rng = np.random.default_rng(11)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0
 for case in range(cases):
-    N = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 500, 1000, 2559, 2560, 4000, 5120, 9000]))
+    N = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 500, 1000, 2559, 2560, 4000, 5120, 9000, 10240, 15000, 20480, 31000, 40959]))
     T = int(rng.integers(1, 5))
     P = int(rng.choice([1, 31, 64, 65, 500, 513, 1200]))
     if case % 10 == 9:
