@@ -99,6 +99,14 @@ void scoary_lists_build(const uint64_t *rows64, int64_t G, int64_t N, int64_t ro
 int64_t scoary_vcf_convert(const char *vcf_path, int64_t offset, const char *out_path,
                            const char *types);
 
+/* ---- UPGMA merge order (scoary/methods.py:640-707, scoary/classes.py:68-196) ------
+ * D: n x n float64 distances, row-major, diagonal already forced to 1
+ * (methods.py:636-638).  Runs the reference's merge loop -- quad tree of 2x2
+ * block minima, smallest (value, i, j) per block, size-weighted averaging -- and
+ * writes the n-1 merged index pairs (i keeps the new cluster, j dies) to
+ * merges[2*(n-1)].  Returns 0; -1 bad argument; -2 internal inconsistency. */
+int scoary_upgma_merges(const double *D, int64_t n, int32_t *merges);
+
 #ifdef __cplusplus
 }
 #endif

@@ -659,3 +659,126 @@ int64_t scoary_vcf_convert(const char* vcf_path, int64_t offset, const char* out
 }
 
 }  // extern "C"
+
+// ---- UPGMA merge order (scoary/methods.py:640-707, scoary/classes.py:68-196) ---------
+// The reference keeps the distance matrix in a quad tree of 2x2 block minima and takes,
+// descending from the top, the smallest (value, i, j) of each block -- that order decides
+// ties, so the levels are kept exactly as the reference has them (matrix padded to even
+// size with BIG at every level, both triangles stored).
+namespace {
+struct MinQuadTree {
+  static constexpr double BIG = 9223372036854775807.0;     // float(sys.maxsize)
+  std::vector<std::vector<double>> lv;
+  std::vector<int64_t> dim;
+  std::vector<double> v, pair;
+  MinQuadTree(const double* D, int64_t n) {
+    int64_t m = n + n % 2;
+    lv.emplace_back((size_t)(m * m), BIG);
+    dim.push_back(m);
+    for (int64_t r = 0; r < n; ++r) std::memcpy(&lv[0][(size_t)(r * m)], D + r * n, (size_t)n * sizeof(double));
+    while (m > 2) {
+      const int64_t h = m / 2, mm = h + h % 2;
+      std::vector<double> nxt((size_t)(mm * mm), BIG);
+      const std::vector<double>& cur = lv.back();
+      for (int64_t r = 0; r < h; ++r)
+        for (int64_t c = 0; c < h; ++c) {
+          const double a = cur[(size_t)(2 * r * m + 2 * c)], b = cur[(size_t)(2 * r * m + 2 * c + 1)];
+          const double e = cur[(size_t)((2 * r + 1) * m + 2 * c)], f = cur[(size_t)((2 * r + 1) * m + 2 * c + 1)];
+          const double x = a < b ? a : b, y = e < f ? e : f;
+          nxt[(size_t)(r * mm + c)] = x < y ? x : y;
+        }
+      lv.push_back(std::move(nxt));
+      dim.push_back(mm);
+      m = mm;
+    }
+    v.resize((size_t)dim[0]);
+    pair.resize((size_t)dim[0]);
+  }
+  // row (or column) idx of level 0 := vec[0..n), then the block minima above it
+  void set(int64_t idx, const double* vec, int64_t n, bool row) {
+    int64_t len = n;
+    std::memcpy(v.data(), vec, (size_t)n * sizeof(double));
+    for (size_t l = 0; l < lv.size(); ++l) {
+      const int64_t m = dim[l];
+      std::vector<double>& cur = lv[l];
+      for (int64_t k = len; k < m; ++k) v[(size_t)k] = BIG;
+      const int64_t lo = idx & ~(int64_t)1, hi = idx | 1;
+      if (row) {
+        std::memcpy(&cur[(size_t)(idx * m)], v.data(), (size_t)m * sizeof(double));
+        const double *a = &cur[(size_t)(lo * m)], *b = &cur[(size_t)(hi * m)];
+        for (int64_t k = 0; k < m; ++k) pair[(size_t)k] = a[k] < b[k] ? a[k] : b[k];
+      } else {
+        // column lo/hi share a cache line per row; one strided pass, prefetched (the matrix is
+        // far larger than the caches and this pass is the whole cost of a merge)
+        for (int64_t k = 0; k < m; ++k) {
+          if (k + 24 < m) __builtin_prefetch(&cur[(size_t)((k + 24) * m + lo)], 1);
+          cur[(size_t)(k * m + idx)] = v[(size_t)k];
+          const double a = cur[(size_t)(k * m + lo)], b = cur[(size_t)(k * m + hi)];
+          pair[(size_t)k] = a < b ? a : b;
+        }
+      }
+      len = m / 2;
+      for (int64_t k = 0; k < len; ++k)
+        v[(size_t)k] = pair[(size_t)(2 * k)] < pair[(size_t)(2 * k + 1)] ? pair[(size_t)(2 * k)] : pair[(size_t)(2 * k + 1)];
+      idx /= 2;
+    }
+  }
+  void argmin(int64_t& oi, int64_t& oj) const {
+    int64_t i = 0, j = 0;
+    for (size_t l = lv.size(); l-- > 0;) {
+      const int64_t m = dim[l];
+      const std::vector<double>& cur = lv[l];
+      i *= 2;
+      j *= 2;
+      int64_t bi = i, bj = j;
+      double bv = cur[(size_t)(i * m + j)];
+      for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj) {
+          if (!di && !dj) continue;
+          const double x = cur[(size_t)((i + di) * m + j + dj)];
+          if (x < bv) {                       // (value, i, j): candidates come in increasing (i, j)
+            bv = x;
+            bi = i + di;
+            bj = j + dj;
+          }
+        }
+      i = bi;
+      j = bj;
+    }
+    oi = i;
+    oj = j;
+  }
+};
+}  // namespace
+
+extern "C" int scoary_upgma_merges(const double* D, int64_t n, int32_t* merges) {
+  if (!D || !merges || n < 1) return -1;
+  if (n == 1) return 0;
+  MinQuadTree qt(D, n);
+  std::vector<double> size((size_t)n, 1.0), nd((size_t)n), dead((size_t)n, MinQuadTree::BIG);
+  std::vector<char> alive((size_t)n, 1);
+  const int64_t m0 = qt.dim[0];
+  for (int64_t step = 0; step < n - 1; ++step) {
+    int64_t i, j;
+    qt.argmin(i, j);
+    if (i >= n || j >= n || i == j || !alive[(size_t)i] || !alive[(size_t)j]) return -2;
+    merges[2 * step] = (int32_t)i;
+    merges[2 * step + 1] = (int32_t)j;
+    const double si = size[(size_t)i], sj = size[(size_t)j], ns = si + sj;
+    const double *ri = &qt.lv[0][(size_t)(i * m0)], *rj = &qt.lv[0][(size_t)(j * m0)];
+    for (int64_t k = 0; k < n; ++k) {
+      const double a = ri[k] * si, b = rj[k] * sj;      // no contraction: as numpy evaluates it
+      const double sum = a + b;
+      nd[(size_t)k] = alive[(size_t)k] ? sum / ns : 1.0;
+    }
+    nd[(size_t)i] = MinQuadTree::BIG;
+    qt.set(i, nd.data(), n, true);
+    qt.set(i, nd.data(), n, false);
+    qt.set(j, dead.data(), n, true);
+    qt.set(j, dead.data(), n, false);
+    alive[(size_t)j] = 0;
+    size[(size_t)i] = ns;
+    size[(size_t)j] = 0.0;
+  }
+  return 0;
+}

@@ -53,6 +53,22 @@ def vcf_convert(vcf_path, offset, out_path, types=None):
     return int(L.scoary_vcf_convert(os.fsencode(vcf_path), int(offset), os.fsencode(out_path), t))
 
 
+def upgma_merges(D):
+    """The reference's UPGMA merge loop on an (n, n) float64 distance matrix whose
+    diagonal is already 1 (scoary_upgma_merges): (n-1, 2) int32 merged index pairs."""
+    L = _load()
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    n = D.shape[0]
+    merges = np.zeros((max(n - 1, 0), 2), dtype=np.int32)
+    L.scoary_upgma_merges.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    L.scoary_upgma_merges.restype = ctypes.c_int
+    rc = L.scoary_upgma_merges(D.ctypes.data_as(ctypes.c_void_p), n,
+                               merges.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise RuntimeError("scoary_upgma_merges failed: %d" % rc)
+    return merges
+
+
 def build_lists(rows64, N, row_stride, genes_per_wave, classes, piece=0):
     """Minority index lists of every gene row (include/scoary_io.h,
     scoary_lists_build): dict of numpy arrays idx (uint32), start, ngroups,

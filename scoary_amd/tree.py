@@ -15,7 +15,6 @@ traversals are iterative: UPGMA trees can be caterpillars thousands deep.
 """
 import sys
 from fractions import Fraction
-from math import comb
 
 import numpy as np
 
@@ -83,11 +82,28 @@ class _MinQuadTree:
         return i, j
 
 
-def upgma_from_counts(counts, ncols, names):
-    """counts: (n, n) integer Hamming counts over ``ncols`` variable genes."""
+def upgma_from_counts(counts, ncols, names, native=None):
+    """counts: (n, n) integer Hamming counts over ``ncols`` variable genes.
+    The merge loop runs in the host library (scoary_upgma_merges, ~100x the numpy
+    loop below) when it is built; ``native=False`` forces the numpy loop, which the
+    tests keep as the cross-check."""
     n = len(names)
     D = counts.astype(np.float64) / float(ncols)      # pdist 'hamming' fractions
     np.fill_diagonal(D, 1.0)                          # methods.py:636-638
+    if native is None:
+        from . import io_native
+        native = io_native.available()
+    if native and n > 1:
+        from . import io_native
+        try:
+            merges = io_native.upgma_merges(D).tolist()
+        except RuntimeError:                          # degenerate input (a diagonal entry is the
+            merges = None                             # minimum): the numpy loop mirrors the reference
+        if merges is not None:
+            cluster = list(names)
+            for i, j in merges:
+                cluster[i], cluster[j] = [cluster[i], cluster[j]], None
+            return cluster[i]
     qt = _MinQuadTree(D)
     d0 = qt.levels[0]
     cluster = list(names)
@@ -329,8 +345,22 @@ def binom_two_sided(x, n):
     if 2 * x == n:
         return 1.0
     k = min(x, n - x)
-    tail = sum(comb(n, j) for j in range(k + 1))
-    return float(min(Fraction(1), Fraction(2 * tail, 2 ** n)))
+    # prefix sums of C(n, 0..k), by the recurrence C(n, j+1) = C(n, j) (n-j) / (j+1), kept per n
+    # (thousands of genes share a few hundred values of n)
+    pre = _BINOM_PREFIX.get(n)
+    if pre is None:
+        if len(_BINOM_PREFIX) > 4096:
+            _BINOM_PREFIX.clear()
+        pre = _BINOM_PREFIX[n] = ([1], [1])             # C(n, j), sum_{i<=j} C(n, i)
+    cs, sums = pre
+    while len(cs) <= k:
+        j = len(cs) - 1
+        cs.append(cs[j] * (n - j) // (j + 1))
+        sums.append(sums[j] + cs[j + 1])
+    return float(min(Fraction(1), Fraction(2 * sums[k], 2 ** n)))
+
+
+_BINOM_PREFIX = {}
 
 
 _ABORT_CACHE = {}

@@ -452,9 +452,9 @@ def test_io_library_exports_every_declared_symbol():
     from scoary_amd import io_native
     with open(os.path.join(ROOT, "include", "scoary_io.h")) as f:
         src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(scoary_(?:gpa|lists|vcf)_[a-z_]+)\s*\(", src)))
+    names = sorted(set(re.findall(r"\b(scoary_(?:gpa|lists|vcf|upgma)_[a-z_]+)\s*\(", src)))
     lib = ctypes.CDLL(io_native.LIB_PATH)
-    assert len(names) == 17 and "scoary_vcf_convert" in names and "scoary_lists_build" in names
+    assert len(names) == 18 and "scoary_vcf_convert" in names and "scoary_upgma_merges" in names
     for n in names:
         assert hasattr(lib, n), n
 
@@ -520,3 +520,35 @@ def test_minority_lists_builder(gpw, classes, stride, piece):
             ent = L["idx"][start[k0] * 32 + ((e // piece) * gpw + j) * piece + e % piece]
             assert np.all(ent == N * stride)
     assert L["entries"] == total and len(L["idx"]) >= total + 32
+
+
+# ------------------------------------------------------------ UPGMA, host ----
+def test_native_upgma_equals_numpy_loop_and_reference_goldens():
+    """scoary_upgma_merges (host library) == the numpy quad-tree loop == the trees the
+    reference built (tests/golden/upgma_cases.json, random matrices with many exact ties),
+    plus tie-heavy larger cases (duplicated strains) native vs numpy."""
+    from scoary_amd import io_native, tree as T
+    assert io_native.available()
+    with open(os.path.join(GOLDEN, "upgma_cases.json")) as f:
+        cases = json.load(f)["cases"]
+
+    def counts_of(X):                                   # strains x variable genes, 0/1
+        Xi = X.astype(np.int64)
+        return Xi @ (1 - Xi).T + (1 - Xi) @ Xi.T
+
+    for c in cases:
+        X = np.array(c["matrix"], dtype=np.uint8)
+        tot = X.sum(axis=0)
+        var = X[:, (tot > 0) & (tot < X.shape[0])]
+        cnt = counts_of(var)
+        for native in (True, False):
+            assert str(T.upgma_from_counts(cnt, var.shape[1], c["names"], native=native)) == c["newick"]
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        n = int(rng.choice([2, 3, 5, 8, 9, 17, 33, 64, 65, 130]))
+        X = (rng.random((n, int(rng.choice([3, 8, 40])))) < 0.3).astype(np.uint8)
+        if seed % 2:
+            X[n // 2:] = X[:n - n // 2]                 # duplicated strains: distance-0 and other ties
+        cnt, names = counts_of(X), ["s%d" % i for i in range(n)]
+        assert T.upgma_from_counts(cnt, X.shape[1], names, native=True) == \
+            T.upgma_from_counts(cnt, X.shape[1], names, native=False)
