@@ -177,6 +177,21 @@ int scoary_permute_lists(scoary_handle h, const uint32_t *d_tiles, const uint32_
 int scoary_hamming(scoary_handle h, const uint32_t *d_tiled, const uint32_t *d_vecrows,
                    int64_t R, int64_t N, int32_t *d_out, scoary_stream_t stream);
 
+/* ---- UPGMA merge loop (scoary/methods.py:640-707, scoary/classes.py:68-196) ----
+ * From the n x n Hamming counts (scoary_hamming) over ncols variable genes: the
+ * reference's merge order -- distances count / ncols with the diagonal forced to
+ * 1, repeatedly the cell with the smallest (value, position in the reference's
+ * quad tree of 2x2 block minima), size-weighted averaging in the same fp64
+ * operations.  Writes the n-1 merged index pairs (i keeps the new cluster, j is
+ * retired) to d_merges[2*(n-1)] and 0 to d_status[0]; a non-zero status means
+ * the degenerate case (a minimum >= 1 or on the diagonal, in which the
+ * reference merges retired clusters): the caller then runs the host loop
+ * (scoary_upgma_merges, include/scoary_io.h), which mirrors that.
+ *   d_scratch : scoary_upgma_scratch_bytes(n) bytes */
+int64_t scoary_upgma_scratch_bytes(int64_t n);
+int scoary_upgma(scoary_handle h, const int32_t *d_counts, int64_t n, int64_t ncols, void *d_scratch,
+                 int32_t *d_merges, int32_t *d_status, scoary_stream_t stream);
+
 /* ---- bit gather: reorder the columns of bit rows --------------------------
  * d_out[r] bit k = d_rows[r] bit d_index[k]   (k < K; output rows are
  * uint32 [R][Wout], Wout = (K+31)/32, pad bits zero).  Used to bring gene rows

@@ -39,6 +39,8 @@ SIGNATURES = {
                                           _vp]),
     "scoary_permute_lists": (_i32, [_vp] * 10 + [_i64, _i64, _i64, _i64, _vp, _vp]),
     "scoary_hamming": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "scoary_upgma_scratch_bytes": (_i64, [_i64]),
+    "scoary_upgma": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "scoary_gather_bits": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "scoary_tree_pairs": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "scoary_tree_permute": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,

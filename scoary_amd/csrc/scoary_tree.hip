@@ -282,6 +282,163 @@ __global__ __launch_bounds__(64) void k_tree_dp(const int32_t* __restrict__ ops,
   }
 }
 
+// ---------------------------------------------------------------------------
+// UPGMA merge loop on the device (scoary/methods.py:640-707, scoary/classes.py:68-196).
+// The reference keeps the distances in a quad tree of 2x2 block minima and descends by the
+// smallest (value, i, j) of each block; over the whole matrix that is the cell with the
+// smallest (value, i-major Morton index of (i, j)).  Two launches per merge:
+//   k_upgma_rowmin : one block per live row -> (min value, smallest column attaining it); a row is
+//                    rescanned only if the previous merge touched its minimum (else one compare)
+//   k_upgma_merge  : one block: pick the row whose (value, Morton(i, j)) is smallest, form
+//                    the size-weighted average row with the reference's fp64 operations,
+//                    write row/column i, retire row/column j, record (i, j)
+// Entries at retired columns are 1.0 in row/column i, as in the reference; a minimum >= 1.0
+// (or on the diagonal) is the degenerate case in which the reference merges retired
+// clusters -- status is set and the host loop, which mirrors that, takes over.
+// ---------------------------------------------------------------------------
+constexpr double kUpgmaBig = 9223372036854775807.0;    // float(sys.maxsize), the reference's "infinity"
+struct UpgmaState {       // device scratch header
+  int32_t status;         // 0, or 1 + step at which the degenerate case showed up
+  int32_t prev_i, prev_j; // the previous merge (-1 before the first): which row minima are stale
+  int32_t pad;
+};
+struct UpgmaMin {
+  double v;
+  int32_t i, j;
+};
+// a < b in the (value, i-major Morton(i, j)) order
+__device__ __forceinline__ bool upgma_less(const UpgmaMin& a, const UpgmaMin& b) {
+  if (a.v != b.v) return a.v < b.v;
+  const uint32_t x = (uint32_t)(a.i ^ b.i), y = (uint32_t)(a.j ^ b.j);
+  const bool j_level_higher = x < y && x < (x ^ y);     // msb(x) < msb(y)
+  return j_level_higher ? a.j < b.j : a.i < b.i;
+}
+__global__ __launch_bounds__(256) void k_upgma_init(const int32_t* __restrict__ counts, int n,
+                                                    double ncols, double* __restrict__ D,
+                                                    int32_t* __restrict__ alive_list,
+                                                    int32_t* __restrict__ pos,
+                                                    double* __restrict__ size,
+                                                    UpgmaState* __restrict__ st) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x; f < total; f += (int64_t)gridDim.x * 256) {
+    const int i = (int)(f / n), j = (int)(f % n);
+    D[f] = i == j ? 1.0 : (double)counts[f] / ncols;     // pdist 'hamming', diagonal forced to 1
+  }
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+    alive_list[k] = k;
+    pos[k] = k;
+    size[k] = 1.0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->status = 0;
+    st->prev_i = st->prev_j = -1;
+  }
+}
+__global__ __launch_bounds__(256) void k_upgma_rowmin(const double* __restrict__ D, int n,
+                                                      const int32_t* __restrict__ alive_list,
+                                                      const UpgmaState* __restrict__ st,
+                                                      UpgmaMin* __restrict__ rowmin) {
+  if (st->status) return;
+  const int row = alive_list[blockIdx.x];
+  const double* r = D + (int64_t)row * n;
+  const int pi = st->prev_i, pj = st->prev_j;
+  if (pi >= 0 && row != pi) {                 // cached minimum still valid unless it sat at i or j
+    const UpgmaMin c = rowmin[row];
+    if (c.j != pi && c.j != pj) {
+      if (threadIdx.x == 0) {
+        const double v = r[pi];               // the one entry of this row the merge rewrote
+        if (v < c.v || (v == c.v && pi < c.j)) rowmin[row] = UpgmaMin{v, row, pi};
+      }
+      return;
+    }
+  }
+  UpgmaMin best = {kUpgmaBig * 2.0, row, n};
+  for (int x = threadIdx.x; x < n; x += 256) {
+    const double v = r[x];
+    if (v < best.v) {                                    // ascending x per thread: first minimum kept
+      best.v = v;
+      best.j = x;
+    }
+  }
+  // same row: the order is (value, column)
+  __shared__ UpgmaMin sh[256];
+  sh[threadIdx.x] = best;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const UpgmaMin o = sh[threadIdx.x + off];
+      UpgmaMin& m = sh[threadIdx.x];
+      if (o.v < m.v || (o.v == m.v && o.j < m.j)) m = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowmin[row] = sh[0];
+}
+__global__ __launch_bounds__(1024) void k_upgma_merge(double* __restrict__ D, int n, int nalive,
+                                                      int step, int32_t* __restrict__ alive_list,
+                                                      int32_t* __restrict__ pos,
+                                                      double* __restrict__ size,
+                                                      double* __restrict__ nd,
+                                                      const UpgmaMin* __restrict__ rowmin,
+                                                      UpgmaState* __restrict__ st,
+                                                      int32_t* __restrict__ merges) {
+  if (st->status) return;
+  __shared__ UpgmaMin sh[1024];
+  UpgmaMin best = {kUpgmaBig * 2.0, 0x7fffffff, 0x7fffffff};
+  for (int p = threadIdx.x; p < nalive; p += 1024) {
+    const UpgmaMin o = rowmin[alive_list[p]];
+    if (upgma_less(o, best)) best = o;
+  }
+  sh[threadIdx.x] = best;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const UpgmaMin o = sh[threadIdx.x + off];
+      if (upgma_less(o, sh[threadIdx.x])) sh[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  const int i = sh[0].i, j = sh[0].j;
+  const double vmin = sh[0].v;
+  if (!(vmin < 1.0) || i == j || j >= n) {               // degenerate: hand over to the host loop
+    if (threadIdx.x == 0) st->status = step + 1;
+    return;
+  }
+  const double si = size[i], sj = size[j], ns = si + sj;
+  double* ri = D + (int64_t)i * n;
+  double* rj = D + (int64_t)j * n;
+  // (d_ik size_i + d_jk size_j) / new_size, each operation rounded as numpy rounds it
+  // (the library is built with -ffp-contract=off); 1.0 at retired clusters
+  for (int x = threadIdx.x; x < n; x += 1024) {
+    const double a = ri[x] * si, b = rj[x] * sj;
+    const double sum = a + b;
+    const bool live = size[x] != 0.0;
+    nd[x] = x == i ? kUpgmaBig : (live ? sum / ns : 1.0);
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < n; x += 1024) {
+    const double v = nd[x];
+    ri[x] = v;
+    D[(int64_t)x * n + i] = v;
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < n; x += 1024) {
+    rj[x] = kUpgmaBig;
+    D[(int64_t)x * n + j] = kUpgmaBig;
+  }
+  if (threadIdx.x == 0) {
+    merges[2 * step] = i;
+    merges[2 * step + 1] = j;
+    size[i] = ns;
+    size[j] = 0.0;
+    const int pj = pos[j], last = alive_list[nalive - 1];   // drop j from the list of live rows
+    alive_list[pj] = last;
+    pos[last] = pj;
+    st->prev_i = i;
+    st->prev_j = j;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -300,6 +457,46 @@ int scoary_hamming(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_v
   hipLaunchKernelGGL((k_hamming<TB>), dim3((unsigned)(Rp / 256), (unsigned)((R + TB - 1) / TB)),
                      dim3(256), 0, s, reinterpret_cast<const uint4*>(d_tiled), d_vecrows, (int)R,
                      (int)Rp, (int)Qp, d_out);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+
+int64_t scoary_upgma_scratch_bytes(int64_t n) {
+  if (n < 1) return 0;
+  // D, nd, size (fp64) | partial minima | live-row list, positions | state
+  return (n * n + 2 * n) * (int64_t)sizeof(double) + n * (int64_t)sizeof(UpgmaMin) +
+         2 * n * (int64_t)sizeof(int32_t) + (int64_t)sizeof(UpgmaState) + 64;
+}
+
+int scoary_upgma(scoary_handle h, const int32_t* d_counts, int64_t n, int64_t ncols, void* d_scratch,
+                 int32_t* d_merges, int32_t* d_status, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_counts || !d_scratch || !d_merges || !d_status || n < 1 || ncols < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_upgma: bad argument");
+  if (n > 46340) return fail(h, SCOARY_ERR_SIZE, "scoary_upgma: more than 46340 isolates");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* base = static_cast<char*>(d_scratch);
+  double* D = reinterpret_cast<double*>(base);
+  double* nd = D + n * n;
+  double* size = nd + n;
+  UpgmaMin* partial = reinterpret_cast<UpgmaMin*>(size + n);
+  int32_t* alive_list = reinterpret_cast<int32_t*>(partial + n);
+  int32_t* pos = alive_list + n;
+  UpgmaState* st = reinterpret_cast<UpgmaState*>(pos + n + (n & 1));
+  KernelTimer kt(h, s, "k_upgma");
+  const int64_t init_blocks = (n * n + 255) / 256;
+  hipLaunchKernelGGL(k_upgma_init, dim3((unsigned)(init_blocks < 65535 ? init_blocks : 65535)), dim3(256),
+                     0, s, d_counts, (int)n, (double)ncols, D, alive_list, pos, size, st);
+  for (int64_t step = 0; step + 1 < n; ++step) {
+    const int nalive = (int)(n - step);
+    hipLaunchKernelGGL(k_upgma_rowmin, dim3((unsigned)nalive), dim3(256), 0, s, D, (int)n, alive_list,
+                       st, partial);
+    hipLaunchKernelGGL(k_upgma_merge, dim3(1), dim3(1024), 0, s, D, (int)n, nalive, (int)step,
+                       alive_list, pos, size, nd, partial, st, d_merges);
+  }
+  HIP_TRY(h, hipMemcpyAsync(d_status, &st->status, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }

@@ -315,9 +315,27 @@ class AssociationEngine:
         return out.cpu().numpy().view(np.uint64)
 
     # -- population-structure stage ----------------------------------
-    def hamming(self, rows01):
+    def upgma_merges(self, rows01):
+        """rows01: (R, N) 0/1 numpy (rows = isolates, columns = variable genes) -> the
+        reference's UPGMA merge order as an (R-1, 2) int32 numpy array, or None when the
+        device loop met the degenerate case it hands back (scoary_upgma).  Hamming counts,
+        distances and the merge loop stay on the device; only the merge list comes back."""
+        torch = _torch()
+        R, N = rows01.shape
+        counts = self.hamming(rows01, device=True)
+        scratch = self._empty(((int(self.lib.scoary_upgma_scratch_bytes(R)) + 7) // 8,), torch.int64)
+        merges = self._empty((max(R - 1, 1), 2), torch.int32)
+        status = self._empty((1,), torch.int32)
+        self._check(self.lib.scoary_upgma(self.h, self._ptr(counts), R, N, self._ptr(scratch),
+                                          self._ptr(merges), self._ptr(status), self._stream()),
+                    "scoary_upgma")
+        if int(status.cpu()[0]) != 0:
+            return None
+        return merges.cpu().numpy()[:R - 1]
+
+    def hamming(self, rows01, device=False):
         """rows01: (R, N) 0/1 numpy (rows = isolates, columns = variable genes)
-        -> (R, R) int32 numpy of pairwise Hamming counts."""
+        -> (R, R) int32 pairwise Hamming counts (numpy, or the device tensor)."""
         torch = _torch()
         rows01 = np.ascontiguousarray(rows01, dtype=np.uint8)
         R, N = rows01.shape
@@ -327,7 +345,7 @@ class AssociationEngine:
         out = self._empty((R, R), torch.int32)
         self._check(self.lib.scoary_hamming(self.h, self._ptr(gm.tiled), self._ptr(vec), R, N,
                                             self._ptr(out), self._stream()), "scoary_hamming")
-        return out.cpu().numpy()
+        return out if device else out.cpu().numpy()
 
     def gather_bits(self, rows, index):
         """rows: int32 device tensor [R, Wsrc] of bit rows; index: int32 device

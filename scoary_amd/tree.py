@@ -131,14 +131,23 @@ def upgma_from_counts(counts, ncols, names, native=None):
 def upgma(engine, dense_genes_by_strain, names):
     """dense (G, N) 0/1 presence matrix -> UPGMA tree over the N strains, from
     Hamming distances over the variable genes (methods.py:496-502, 619-707).
-    The N x N Hamming counts are computed on the GPU (scoary_hamming)."""
+    Hamming counts and the merge loop run on the GPU (scoary_hamming,
+    scoary_upgma); the host loop takes over in the degenerate case the device
+    loop hands back."""
     dense = np.asarray(dense_genes_by_strain, dtype=np.uint8)
     tot = dense.sum(axis=1)
     var = dense[(tot > 0) & (tot < dense.shape[1])]
     if var.shape[0] == 0:
         raise ValueError("no variable genes: cannot build a tree")
-    counts = engine.hamming(np.ascontiguousarray(var.T))
-    return upgma_from_counts(counts, var.shape[0], names)
+    rows = np.ascontiguousarray(var.T)
+    if len(names) > 1:
+        merges = engine.upgma_merges(rows)            # device loop (scoary_upgma)
+        if merges is not None:
+            cluster = list(names)
+            for i, j in merges.tolist():
+                cluster[i], cluster[j] = [cluster[i], cluster[j]], None
+            return cluster[i]
+    return upgma_from_counts(engine.hamming(rows), var.shape[0], names)
 
 
 # ---------------------------------------------------------------------------

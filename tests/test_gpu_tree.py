@@ -61,6 +61,38 @@ def test_upgma_random_cases_and_exampledata(eng):
     assert T.newick_text(t) == golden_text("exampledata/ExampleTree.nwk.gz").strip()
 
 
+def test_device_upgma_equals_host_loop_with_ties(eng):
+    """scoary_upgma (device merge loop) == the numpy quad-tree loop on tie-heavy inputs
+    (duplicated strains: many distance-0 and equal-distance cells), sizes around the
+    2x2-block boundaries; the degenerate all-distances-1 case is handed back to the host."""
+    from scoary_amd import tree as T
+    for seed in range(30):
+        rng = np.random.default_rng(100 + seed)
+        n = int(rng.choice([2, 3, 4, 5, 8, 9, 16, 17, 33, 64, 65, 130, 257]))
+        X = (rng.random((n, int(rng.choice([3, 8, 40, 300])))) < 0.3).astype(np.uint8)
+        if seed % 2:
+            X[n // 2:] = X[:n - n // 2]
+        tot = X.sum(axis=0)
+        var = X[:, (tot > 0) & (tot < n)]
+        if var.shape[1] == 0:
+            continue
+        names = ["s%d" % i for i in range(n)]
+        Xi = var.astype(np.int64)
+        cnt = Xi @ (1 - Xi).T + (1 - Xi) @ Xi.T
+        want = T.upgma_from_counts(cnt, var.shape[1], names, native=False)
+        assert T.upgma(eng, var.T, names) == want
+        m = eng.upgma_merges(var)
+        if m is not None:                                 # the device loop itself, not the fallback
+            cluster = list(names)
+            for i, j in m.tolist():
+                cluster[i], cluster[j] = [cluster[i], cluster[j]], None
+            assert cluster[i] == want
+    comp = np.array([[1, 0, 1, 0], [0, 1, 0, 1]], dtype=np.uint8)       # distance exactly 1
+    assert eng.upgma_merges(comp) is None
+    assert T.upgma(eng, comp.T, ["a", "b"]) == T.upgma_from_counts(
+        np.array([[0, 4], [4, 0]]), 4, ["a", "b"], native=False)
+
+
 @pytest.mark.parametrize("R,N,K", [(1, 1, 1), (5, 40, 40), (70, 100, 97), (300, 2000, 1980), (3, 5000, 4999)])
 def test_gather_bits_bit_exact(eng, R, N, K):
     import torch
