@@ -48,7 +48,13 @@ def main():
     out["k_hamming_pair_words_per_s"] = N * N * (args.all_genes / 32.0) / (out["k_hamming_ms"] * 1e-3)
     t0 = time.perf_counter()
     tree = T.upgma_from_counts(counts, args.all_genes, strains)
-    out["upgma_host_s"] = time.perf_counter() - t0
+    out["upgma_host_library_s"] = time.perf_counter() - t0
+    rows01 = np.ascontiguousarray(dense.T)
+    eng.upgma_merges(rows01[:64])                       # warm-up
+    t0 = time.perf_counter()
+    tree_dev = T.upgma(eng, dense, strains)             # Hamming + merge loop on the device
+    out["upgma_device_s_incl_hamming_and_transfer"] = time.perf_counter() - t0
+    out["upgma_device_equals_host"] = tree_dev == tree
 
     trait = (rng.random(N) < 0.4).astype(np.uint8)
     stage = m._TreeStage(eng, tree, strains, trait, 0, 5)
