@@ -269,7 +269,7 @@ def main():
     use_lists = args.kernel == "lists" or (args.kernel == "auto" and LISTS_DEFAULT
                                            and eng.lists_supported(N))
     if use_lists:
-        eng.build_lists(gm, pack_bits_rows(genes))    # once per dataset, like the packing
+        eng.build_lists(gm)    # once per dataset, like the packing
     pbatch = eng.perm_batch(T, N, P)
     perm_buf = torch.empty((T, pbatch, eng.row_words(N)), dtype=torch.int32, device=eng.device)
     exchange = Exchange(torch, eng, world, rank, T, G) if sharded else None

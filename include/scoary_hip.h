@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SCOARY_ABI_VERSION 3
+#define SCOARY_ABI_VERSION 4
 
 /* error codes */
 #define SCOARY_OK 0
@@ -132,17 +132,22 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
 /* ---- a7/a8, list-driven variant -------------------------------------------
  * Same result as scoary_perm_generate + scoary_permute (d_r is bit-identical),
  * different data flow: genes as lists of the isolates that carry their
- * minority value (built once per dataset by scoary_lists_build,
- * include/scoary_io.h), permuted labels as isolate-major tiles of 512 / 256 /
+ * minority value (built once per dataset, on the device: scoary_lists_plan /
+ * scoary_lists_fill below), permuted labels as isolate-major tiles of 512 / 256 /
  * 128 / 64 / 32 permutations (N <= 2559 / 5119 / 10239 / 20479 / 40959) that live
  * in LDS, overlap counts as bit-sliced counters, 128 (64, 32 for the last two)
  * permutations per lane.  Cost
  * is proportional to the list length, so sparse (or near-core) genes are
  * cheap.  Available while a tile fits in LDS: N <= scoary_list_max_isolates().
  *   d_tiles : uint32 [scoary_list_tiles_words(N, P, T)]
- *   d_lidx / d_lstart / d_lngroups / d_lorder / d_lflipped : scoary_lists_build
- *             output (arguments from scoary_list_params), copied to the GPU
- *   d_lcrit : scratch, uint32 [T][G][2] */
+ *   d_lidx / d_lstart / d_lngroups / d_lorder / d_lflipped : the index lists of the
+ *             gene matrix, built on the device by scoary_lists_plan + scoary_lists_fill
+ *             (below); `entries` = the entry count scoary_lists_plan returned
+ *   d_scratch : scoary_permute_lists_scratch_bytes(G, T, N, P) bytes (list-order
+ *             rejection regions + per-part exceedance counts; one block owns a
+ *             (trait, part of the tiles, gene chunk) and writes its counts once, a
+ *             small second kernel adds the <= 3 parts into d_r -- no atomics)
+ *   d_r     : uint32 [T][G], += like scoary_permute */
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T);
 int64_t scoary_list_tile_words(int64_t N);   /* dwords per (trait, tile) */
 int64_t scoary_list_max_isolates(void);
@@ -155,12 +160,40 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t *d_masks,
                                const int32_t *d_margins, int64_t T, int64_t N, int64_t P,
                                int64_t perm_base, int64_t trait_base, uint64_t seed,
                                uint32_t *d_tiles, scoary_stream_t stream);
+int64_t scoary_permute_lists_scratch_bytes(int64_t G, int64_t T, int64_t N, int64_t P);
 int scoary_permute_lists(scoary_handle h, const uint32_t *d_tiles, const uint32_t *d_lidx,
-                         const int32_t *d_lstart, const int32_t *d_lngroups,
+                         int64_t entries, const int32_t *d_lstart, const int32_t *d_lngroups,
                          const int32_t *d_lorder, const uint8_t *d_lflipped,
-                         const uint32_t *d_crit, const int32_t *d_margins, uint32_t *d_lcrit,
+                         const uint32_t *d_crit, const int32_t *d_margins, void *d_scratch,
                          int64_t G, int64_t T, int64_t N, int64_t P, uint32_t *d_r,
                          scoary_stream_t stream);
+
+/* ---- index lists of the list-driven kernel, built on the device -----------------
+ * From the tiled gene matrix already in HBM (no host pass, no PCIe copy of the
+ * lists): for every gene the positions of its MINORITY value (ones if popcount <=
+ * N/2, else zeros: d_flipped[g] = 1), genes ordered by descending list length
+ * (stable), lists padded to 32 entries and to the longest list of their wavefront
+ * group, the lists of a group interleaved in pieces of `piece` entries, entries in
+ * the bank-rotation order of spec S6 (the same layout
+ * scoary_lists_build of include/scoary_io.h -- the checker -- produces on the host).
+ *   scoary_lists_plan : popcount -> flip -> radix sort by length -> padded lengths
+ *       and group bases (prefix sum).  Writes d_start / d_ngroups / d_order (int32
+ *       [G], per list slot) and d_flipped (uint8 [G], per gene); *entries_out (HOST)
+ *       = total number of entries.  Synchronises `stream` (the caller needs the
+ *       count to allocate d_idx).
+ *   scoary_lists_fill : d_idx = uint32 [entries + scoary_lists_slack_entries()],
+ *       entry = position * row stride (the LDS byte offset of that isolate's label
+ *       row), padding = N * row stride (the all-zero row).
+ *   d_scratch : scoary_lists_scratch_bytes(G, N) bytes, the SAME buffer in both calls
+ *       (plan leaves the lengths and group bases in it). */
+int64_t scoary_lists_scratch_bytes(int64_t G, int64_t N);
+int64_t scoary_lists_slack_entries(void);
+int scoary_lists_plan(scoary_handle h, const uint32_t *d_tiled, int64_t G, int64_t N,
+                      void *d_scratch, int32_t *d_start, int32_t *d_ngroups, int32_t *d_order,
+                      uint8_t *d_flipped, int64_t *entries_out, scoary_stream_t stream);
+int scoary_lists_fill(scoary_handle h, const uint32_t *d_tiled, int64_t G, int64_t N,
+                      const void *d_scratch, const int32_t *d_order, const uint8_t *d_flipped,
+                      int64_t entries, uint32_t *d_idx, scoary_stream_t stream);
 
 /* ======================================================================
  * Population-structure stage
@@ -235,6 +268,20 @@ int scoary_tree_permute(scoary_handle h, const int32_t *d_ops, int64_t nops,
  * so a collision can cost time but never correctness. */
 int scoary_row_hash(scoary_handle h, const uint32_t *d_tiled, const uint32_t *d_masks,
                     int64_t G, int64_t T, int64_t N, uint64_t *d_out, scoary_stream_t stream);
+
+/* ---- hipGraph capture ----------------------------------------------------------
+ * Small workloads are launch-bound (BASELINE configs[1]: six kernels, 0.14 ms).
+ * scoary_graph_begin puts `stream` into capture mode; every scoary_* call made on
+ * that stream (and on streams forked from it by event waits) until
+ * scoary_graph_end is recorded instead of executed.  The captured sequence must not
+ * allocate, synchronise or read results back: use caller-owned buffers that stay
+ * alive for as long as the graph is replayed.  scoary_graph_launch replays it.
+ * Not available while per-kernel timing (scoary_set_timing) is on. */
+typedef struct scoary_graph *scoary_graph_t;
+int scoary_graph_begin(scoary_handle h, scoary_stream_t stream);
+int scoary_graph_end(scoary_handle h, scoary_stream_t stream, scoary_graph_t *out);
+int scoary_graph_launch(scoary_handle h, scoary_graph_t g, scoary_stream_t stream);
+void scoary_graph_destroy(scoary_graph_t g);
 
 /* Name + average device time (ms, hipEvent on `stream`) of the kernels the
  * last scoary_permute call launched; for bench.py's roofline line.  Costs a

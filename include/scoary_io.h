@@ -58,9 +58,13 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
  * back to back in `order`: genes sorted by descending list length, so that the
  * `genes_per_wave` genes a wavefront processes together (slots w*gpw ..) have
  * similar lengths and, after padding, the same number of 32-entry groups.
- * Within a list, entry e of slot k is taken from residue class (k + e) mod
- * classes of the positions, ascending within a class; when a class runs dry the
- * next non-empty class of the rotation stands in (LDS bank trick, see the kernel).
+ * Within a list (spec S6) the positions are ordered by
+ * rank-within-class * classes + ((class - k) mod classes), class = position mod
+ * classes, ascending position within a class, written without gaps: while every
+ * class still has positions, entry e of slot k comes from residue class (k + e)
+ * mod classes (LDS bank trick, see the kernel).  This host builder is the CHECKER
+ * of the device builder (scoary_lists_plan / scoary_lists_fill, scoary_hip.h), which
+ * the product path uses; both implement the spec independently.
  * With piece > 0 the lists of one wavefront group are interleaved in pieces of
  * `piece` entries -- entry e of the group's j-th gene sits at
  * group_base + ((e / piece) * genes_per_wave + j) * piece + e % piece -- so that

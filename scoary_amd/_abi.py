@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libscoary_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "scoary_hip.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _i64, _u64, _i32, _vp, _cp = (ctypes.c_int64, ctypes.c_uint64, ctypes.c_int,
                               ctypes.c_void_p, ctypes.c_char_p)
@@ -37,7 +37,14 @@ SIGNATURES = {
     "scoary_list_max_isolates": (_i64, []),
     "scoary_perm_generate_tiles": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp,
                                           _vp]),
-    "scoary_permute_lists": (_i32, [_vp] * 10 + [_i64, _i64, _i64, _i64, _vp, _vp]),
+    "scoary_permute_lists_scratch_bytes": (_i64, [_i64, _i64, _i64, _i64]),
+    "scoary_permute_lists": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 7 + [_i64, _i64, _i64, _i64, _vp,
+                                                                       _vp]),
+    "scoary_lists_scratch_bytes": (_i64, [_i64, _i64]),
+    "scoary_lists_slack_entries": (_i64, []),
+    "scoary_lists_plan": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
+                                 ctypes.POINTER(_i64), _vp]),
+    "scoary_lists_fill": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
     "scoary_hamming": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "scoary_upgma_scratch_bytes": (_i64, [_i64]),
     "scoary_upgma": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
@@ -46,6 +53,10 @@ SIGNATURES = {
     "scoary_tree_permute": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
                                    _vp]),
     "scoary_row_hash": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "scoary_graph_begin": (_i32, [_vp, _vp]),
+    "scoary_graph_end": (_i32, [_vp, _vp, ctypes.POINTER(_vp)]),
+    "scoary_graph_launch": (_i32, [_vp, _vp, _vp]),
+    "scoary_graph_destroy": (None, [_vp]),
     "scoary_set_timing": (_i32, [_vp, _i32]),
     "scoary_last_kernel_ms": (_i32, [_vp, _cp, ctypes.POINTER(ctypes.c_double)]),
 }

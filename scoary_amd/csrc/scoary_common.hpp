@@ -52,6 +52,26 @@ inline int64_t tiled_quads(int64_t N) {
   return round_up(q, kChunkQuads);
 }
 
+// ---- list-driven permutation path: layout constants shared by scoary_lists.hip
+// (kernels) and scoary_listbuild.hip (device-side list builder) ----
+// TW = tile row width in dwords (32 permutations each): 16 while a tile of 512
+// permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
+// N <= 5119, 4 (tiles of 128) up to N <= 10239, 2 (tiles of 64, two words per lane)
+// up to N <= 20479, 1 (tiles of 32, one word per lane) up to N <= 40959.  A gene takes
+// max(TW/4, 1) lanes and a wavefront 64 / that many genes of similar list length.
+__host__ __device__ constexpr int list_tw(int64_t N) {
+  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : (N <= 20479 ? 2 : (N <= 40959 ? 1 : 0))));
+}
+__host__ __device__ constexpr int list_lpg(int TW) { return TW >= 4 ? TW / 4 : 1; }   // lanes per gene
+__host__ __device__ constexpr int list_nw(int TW) { return TW >= 4 ? 4 : TW; }        // words per lane
+// dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
+__host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int TW) {
+  return ((N + 1) * TW + 3) / 4 * 4;
+}
+
+constexpr int kListPad = 32;        // list lengths are padded to a multiple of this many entries
+constexpr int kListSlack = 256;     // zero entries after the last list (one wavefront index load)
+
 int fail(scoary_handle h, int code, const std::string& msg) {
   if (h) h->err = msg;
   return code;

@@ -71,4 +71,48 @@ int scoary_last_kernel_ms(scoary_handle h, const char* kernel, double* ms_out) {
   return SCOARY_OK;
 }
 
+// ---- hipGraph capture of a launch sequence (small, launch-bound workloads) ----
+struct scoary_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+int scoary_graph_begin(scoary_handle h, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (h->timing) return fail(h, SCOARY_ERR_ARG, "scoary_graph_begin: per-kernel timing is on (events cannot be read back from a replayed graph)");
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeRelaxed));
+  return SCOARY_OK;
+}
+
+int scoary_graph_end(scoary_handle h, scoary_stream_t stream, scoary_graph_t* out) {
+  if (!h || !out) return SCOARY_ERR_ARG;
+  DeviceGuard guard(h->device);
+  scoary_graph* g = new scoary_graph();
+  hipError_t e = hipStreamEndCapture(static_cast<hipStream_t>(stream), &g->graph);
+  if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    *out = nullptr;
+    return fail(h, SCOARY_ERR_HIP, std::string("scoary_graph_end: ") + hipGetErrorString(e));
+  }
+  *out = g;
+  return SCOARY_OK;
+}
+
+int scoary_graph_launch(scoary_handle h, scoary_graph_t g, scoary_stream_t stream) {
+  if (!h || !g || !g->exec) return SCOARY_ERR_ARG;
+  DeviceGuard guard(h->device);
+  HIP_TRY(h, hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+  return SCOARY_OK;
+}
+
+void scoary_graph_destroy(scoary_graph_t g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+}
+
 }  // extern "C"

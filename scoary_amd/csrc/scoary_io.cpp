@@ -13,6 +13,7 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -441,11 +442,15 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
         start[k] = (int32_t)((piece > 0 ? base[q] : base[k]) / kListPad);
         const uint64_t* r = rows64 + g * W;
         const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
-        // The genes of one LDS lane group read the label tile in lockstep, and a
-        // row's bank range is fixed by (isolate index mod classes).  Entry e of
-        // slot k is taken from residue class (k + e) mod classes -- ascending
-        // within a class -- so at every step the genes of a group sit on distinct
-        // bank slots; when a class runs dry the next non-empty one stands in.
+        // Spec S6: the genes of one LDS lane group read the label tile in
+        // lockstep, and a row's bank range is fixed by (isolate index mod classes).  The
+        // listed positions are ordered by rank-within-class * classes + ((class - k) mod
+        // classes), ascending position within a class, and written without gaps: while
+        // every class still has positions, entry e of slot k comes from class (k + e) mod
+        // classes, so the genes of a group sit on distinct bank slots; the tails of the
+        // longer classes keep the rotation order.  Closed form (what the device builder
+        // k_lists_fill evaluates per position):
+        //   entry(c, rho) = sum over c' of min(cnt[c'], rho + [(c'-k) mod C < (c-k) mod C]).
         std::fill(first.begin(), first.end(), 0);     // counting sort by class
         int64_t nt = 0;
         for (int64_t w = 0; w < W; ++w) {
@@ -463,15 +468,18 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
         std::copy(first.begin(), first.begin() + classes, taken.begin());
         for (int64_t i = 0; i < nt; ++i)
           sorted[taken[tmp[i] & cmask]++] = (uint32_t)(tmp[i] * row_stride);
-        const int64_t total_n = len[g], L = padded[k];
+        const int64_t L = padded[k];
         one.assign(L, zero_row);                      // padding -> the zero row
-        std::copy(first.begin(), first.begin() + classes, taken.begin());
-        int64_t c = k & cmask;
-        for (int64_t n = 0; n < total_n; ++n) {
-          int64_t cc = c;
-          while (taken[cc] >= first[cc + 1]) cc = (cc + 1) & cmask;
-          one[n] = sorted[taken[cc]++];
-          c = (c + 1) & cmask;
+        for (int64_t c = 0; c < classes; ++c) {
+          const int64_t dc = (c - k) & cmask;
+          for (int64_t rho = 0; rho < first[c + 1] - first[c]; ++rho) {
+            int64_t e = 0;
+            for (int64_t x = 0; x < classes; ++x) {
+              const int64_t dx = (x - k) & cmask;
+              e += std::min<int64_t>(first[x + 1] - first[x], rho + (dx < dc ? 1 : 0));
+            }
+            one[e] = sorted[first[c] + rho];
+          }
         }
         if (piece <= 0) {                             // gene-contiguous
           std::memcpy(idx + base[k], one.data(), (size_t)L * sizeof(uint32_t));

@@ -1,0 +1,374 @@
+// scoary_listbuild.hip -- the minority index lists of the list-driven permutation
+// kernel (scoary_lists.hip), built on the device from the tiled gene matrix that is
+// already in HBM: per-gene popcount -> flip decision -> stable length sort (LSD radix,
+// 8-bit digits) -> padded lengths and group bases (prefix sum) -> scatter of the listed
+// positions in the bank-rotation order.  The layout is spec S6;
+// the host builder scoary_lists_build (scoary_io.cpp) implements the same spec
+// independently and is the checker in the tests.
+#include "scoary_common.hpp"
+
+namespace {
+
+constexpr int kSortItems = 2048;   // items per sort block (one wavefront)
+
+__host__ __device__ inline int64_t lb_align8(int64_t x) { return (x + 7) / 8 * 8; }
+
+// Scratch layout (bytes), shared by scoary_lists_plan and scoary_lists_fill.
+struct ListScratch {
+  int64_t len, ord_a, ord_b, hist, base, padded, total;
+  int64_t nblk, nwg;
+};
+inline ListScratch list_scratch(int64_t G, int64_t N) {
+  ListScratch s{};
+  const int TW = list_tw(N);
+  const int64_t gpw = TW ? kWave / list_lpg(TW) : 64;
+  s.nblk = (G + kSortItems - 1) / kSortItems;
+  s.nwg = (G + gpw - 1) / gpw;
+  int64_t off = 0;
+  s.len = off;    off += lb_align8(4 * G);
+  s.ord_a = off;  off += lb_align8(4 * G);
+  s.ord_b = off;  off += lb_align8(4 * G);
+  s.hist = off;   off += lb_align8(4 * 256 * s.nblk);
+  s.base = off;   off += 8 * (s.nwg + 1);
+  s.padded = off; off += lb_align8(4 * s.nwg);
+  s.total = off;
+  return s;
+}
+
+// lane = gene: minority length and flip flag from the tiled rows (pad bits are zero)
+__global__ __launch_bounds__(256) void k_lists_len(const uint4* __restrict__ tiled, int64_t Gp,
+                                                   int G, int N, int Qn, int32_t* __restrict__ len,
+                                                   uint8_t* __restrict__ flipped) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= G) return;
+  int n1 = 0;
+  for (int q = 0; q < Qn; ++q) {
+    const uint4 v = tiled[(int64_t)q * Gp + g];
+    n1 += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+  const bool fl = 2 * n1 > N;
+  len[g] = fl ? N - n1 : n1;
+  flipped[g] = fl ? 1 : 0;
+}
+
+// ---- stable LSD radix sort of the genes by DESCENDING list length ----------------
+// key = kmax - len (ascending key = descending length), 8-bit digits; one wavefront
+// per block of kSortItems consecutive items keeps the in-block order without any
+// cross-wavefront hand-over.
+__device__ __forceinline__ int sort_digit(const int32_t* in_order, const int32_t* len, int i,
+                                          int kmax, int shift, int& g) {
+  g = in_order ? in_order[i] : i;
+  return ((kmax - len[g]) >> shift) & 255;
+}
+__global__ __launch_bounds__(64) void k_sort_hist(const int32_t* __restrict__ in_order,
+                                                  const int32_t* __restrict__ len, int G, int kmax,
+                                                  int shift, int nblk, int32_t* __restrict__ hist) {
+  __shared__ int32_t h[256];
+  const int lane = threadIdx.x, b = blockIdx.x;
+  for (int d = lane; d < 256; d += 64) h[d] = 0;
+  __syncthreads();
+  const int lo = b * kSortItems, hi = min(G, lo + kSortItems);
+  for (int i = lo + lane; i < hi; i += 64) {
+    int g;
+    atomicAdd(&h[sort_digit(in_order, len, i, kmax, shift, g)], 1);
+  }
+  __syncthreads();
+  for (int d = lane; d < 256; d += 64) hist[(int64_t)d * nblk + b] = h[d];
+}
+// exclusive prefix sum of n int32 values in place, one block
+__global__ __launch_bounds__(1024) void k_scan_excl(int32_t* __restrict__ v, int64_t n) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + tid;
+    const int32_t x = i < n ? v[i] : 0;
+    int32_t s = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t y = __shfl_up(s, off);
+      if (lane >= off) s += y;
+    }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    int32_t wo = 0;
+    for (int w = 0; w < wave; ++w) wo += wsum[w];
+    const int32_t carry = carry_s;
+    if (i < n) v[i] = carry + wo + s - x;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wo + s;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(64) void k_sort_scatter(const int32_t* __restrict__ in_order,
+                                                     const int32_t* __restrict__ len, int G,
+                                                     int kmax, int shift, int nblk,
+                                                     const int32_t* __restrict__ hist,
+                                                     int32_t* __restrict__ out_order) {
+  __shared__ int32_t cnt[256];
+  const int lane = threadIdx.x, b = blockIdx.x;
+  for (int d = lane; d < 256; d += 64) cnt[d] = hist[(int64_t)d * nblk + b];
+  __syncthreads();
+  const int lo = b * kSortItems, hi = min(G, lo + kSortItems);
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const bool valid = i < hi;
+    int g = 0;
+    const int d = valid ? sort_digit(in_order, len, i, kmax, shift, g) : 0;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool set = (d >> bit) & 1;
+      const uint64_t bb = __ballot(valid && set);
+      peers &= set ? bb : ~bb;
+    }
+    const int rank = __popcll(peers & (((uint64_t)1 << lane) - 1));
+    if (valid) out_order[cnt[d] + rank] = g;
+    __syncthreads();
+    if (valid && rank == 0) cnt[d] += __popcll(peers);
+    __syncthreads();
+  }
+}
+
+// Padded list length of every wavefront group (the longest list of the group, rounded
+// up to kListPad) and the first entry of the group: exclusive prefix sum, one block.
+__global__ __launch_bounds__(1024) void k_lists_plan(const int32_t* __restrict__ len,
+                                                     const int32_t* __restrict__ order, int G,
+                                                     int gpw, int64_t nwg,
+                                                     int32_t* __restrict__ padded,
+                                                     int64_t* __restrict__ base) {
+  __shared__ int64_t wsum[16];
+  __shared__ int64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t q0 = 0; q0 < nwg; q0 += 1024) {
+    const int64_t q = q0 + tid;
+    int32_t L = 0;
+    if (q < nwg) {
+      L = (len[order[q * gpw]] + kListPad - 1) / kListPad * kListPad;
+      padded[q] = L;
+    }
+    const int64_t x = (int64_t)L * gpw;
+    int64_t s = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int64_t y = __shfl_up(s, off);
+      if (lane >= off) s += y;
+    }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    int64_t wo = 0;
+    for (int w = 0; w < wave; ++w) wo += wsum[w];
+    const int64_t carry = carry_s;
+    if (q < nwg) base[q] = carry + wo + s - x;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wo + s;
+    __syncthreads();
+  }
+  if (tid == 0) base[nwg] = carry_s;
+}
+__global__ __launch_bounds__(256) void k_lists_slots(const int32_t* __restrict__ padded,
+                                                     const int64_t* __restrict__ base, int G,
+                                                     int gpw, int32_t* __restrict__ start,
+                                                     int32_t* __restrict__ ngroups) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= G) return;
+  const int q = k / gpw;
+  start[k] = (int32_t)(base[q] / kListPad);
+  ngroups[k] = padded[q] / kListPad;
+}
+
+// Spec S6, entry order: the listed positions of slot k are ordered by
+//   rank-within-class * C + ((class - k) mod C),     class = position mod C
+// (ascending position within a class) and written without gaps: while every class still
+// has positions, entry e comes from class (k + e) mod C -- the genes of an LDS lane group
+// sit on distinct bank slots -- and the tail of the longer classes keeps the rotation
+// order.  Closed form, so every position finds its entry independently:
+//   entry(class c, rank p) = sum over c' of min(cnt[c'], p + [(c'-k) mod C < (c-k) mod C]).
+// C lanes per slot (lane = class), 64 / C slots per wavefront.
+template <int C>
+__global__ __launch_bounds__(256) void k_lists_fill(const uint4* __restrict__ tiled, int64_t Gp,
+                                                    int G, int N, int Qn,
+                                                    const int32_t* __restrict__ len,
+                                                    const int32_t* __restrict__ order,
+                                                    const uint8_t* __restrict__ flipped,
+                                                    const int64_t* __restrict__ base,
+                                                    const int32_t* __restrict__ padded, int gpw,
+                                                    int piece, uint32_t row_stride, int64_t nslots,
+                                                    uint32_t* __restrict__ idx) {
+  __shared__ int32_t s_cnt[256];
+  constexpr int SPW = 64 / C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane % C;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * SPW + lane / C;
+  const bool exists = k < nslots, live = k < G;
+  const int64_t q = exists ? k / gpw : 0;
+  const int j = (int)(k - q * gpw);
+  const int L = exists ? padded[q] : 0;
+  const int64_t b0 = exists ? base[q] : 0;
+  const int g = live ? order[k] : 0;
+  const int total = live ? len[g] : 0;
+  const uint32_t inv = (live && flipped[g]) ? 0xffffffffu : 0u;
+  uint32_t cmask = 0u;                       // bits of a 32-bit word that belong to class c
+  if constexpr (C <= 32) {
+    for (int b = c; b < 32; b += C) cmask |= 1u << b;
+  } else {
+    cmask = 1u << (c & 31);                  // C == 64: words of parity c >> 5 only
+  }
+  auto class_bits = [&](uint32_t word, int w) -> uint32_t {
+    const int first = 32 * w;
+    uint32_t bits = word ^ inv;
+    if (first + 32 > N) bits &= first < N ? ((1u << (N - first)) - 1u) : 0u;
+    if constexpr (C == 64)
+      if ((w & 1) != (c >> 5)) return 0u;
+    return bits & cmask;
+  };
+  auto at = [&](int n) -> int64_t {          // interleaved position of entry n of this slot
+    return b0 + ((int64_t)(n / piece) * gpw + j) * piece + n % piece;
+  };
+  int my_cnt = 0;
+  if (live)
+    for (int qd = 0; qd < Qn; ++qd) {
+      const uint4 v = tiled[(int64_t)qd * Gp + g];
+      my_cnt += __popc(class_bits(v.x, 4 * qd)) + __popc(class_bits(v.y, 4 * qd + 1)) +
+                __popc(class_bits(v.z, 4 * qd + 2)) + __popc(class_bits(v.w, 4 * qd + 3));
+    }
+  s_cnt[tid] = my_cnt;
+  __syncthreads();
+  const int32_t* cnt = s_cnt + (tid - c);    // the C class counts of this slot
+  int m = cnt[0];
+  for (int x = 1; x < C; ++x) m = min(m, cnt[x]);
+  const int dk = (int)((c - k) & (C - 1));
+  if (live) {
+    int rho = 0;
+    for (int qd = 0; qd < Qn; ++qd) {
+      const uint4 v = tiled[(int64_t)qd * Gp + g];
+      const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        uint32_t bits = class_bits(words[w4], 4 * qd + w4);
+        while (bits) {
+          const int b = __builtin_ctz(bits);
+          bits &= bits - 1;
+          int pos;
+          if (rho < m) {
+            pos = rho * C + dk;
+          } else {
+            pos = 0;
+            for (int x = 0; x < C; ++x) {
+              const int dx = (int)((x - k) & (C - 1));
+              pos += min(cnt[x], rho + (dx < dk ? 1 : 0));
+            }
+          }
+          idx[at(pos)] = (uint32_t)(32 * (4 * qd + w4) + b) * row_stride;
+          ++rho;
+        }
+      }
+    }
+  }
+  const uint32_t zero_row = (uint32_t)N * row_stride;
+  for (int n = total + c; n < L; n += C) idx[at(n)] = zero_row;
+}
+
+__global__ __launch_bounds__(256) void k_lists_slack(uint32_t* __restrict__ idx, int64_t entries) {
+  if (threadIdx.x < kListSlack) idx[entries + threadIdx.x] = 0u;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t scoary_lists_scratch_bytes(int64_t G, int64_t N) {
+  if (G < 1 || N < 1 || !list_tw(N)) return 0;
+  return list_scratch(G, N).total;
+}
+int64_t scoary_lists_slack_entries(void) { return kListSlack; }
+
+int scoary_lists_plan(scoary_handle h, const uint32_t* d_tiled, int64_t G, int64_t N,
+                      void* d_scratch, int32_t* d_start, int32_t* d_ngroups, int32_t* d_order,
+                      uint8_t* d_flipped, int64_t* entries_out, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_scratch || !d_start || !d_ngroups || !d_order || !d_flipped || !entries_out ||
+      G < 1 || N < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_lists_plan: bad argument");
+  const int TW = list_tw(N);
+  if (!TW) return fail(h, SCOARY_ERR_SIZE, "scoary_lists_plan: N too large for LDS label tiles");
+  if (G > 0x7fffffffLL - kSortItems)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_lists_plan: G >= 2^31");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const ListScratch L = list_scratch(G, N);
+  char* sc = static_cast<char*>(d_scratch);
+  int32_t* len = reinterpret_cast<int32_t*>(sc + L.len);
+  int32_t* ord[2] = {reinterpret_cast<int32_t*>(sc + L.ord_a), reinterpret_cast<int32_t*>(sc + L.ord_b)};
+  int32_t* hist = reinterpret_cast<int32_t*>(sc + L.hist);
+  int64_t* base = reinterpret_cast<int64_t*>(sc + L.base);
+  int32_t* padded = reinterpret_cast<int32_t*>(sc + L.padded);
+  const int64_t Gp = scoary_tiled_genes(G);
+  const int Qn = (int)((N + 127) / 128);
+  const int gpw = kWave / list_lpg(TW);
+  KernelTimer kt(h, s, "k_lists_plan");
+  hipLaunchKernelGGL(k_lists_len, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const uint4*>(d_tiled), Gp, (int)G, (int)N, Qn, len, d_flipped);
+  const int kmax = (int)(N / 2);               // minority lists hold <= N/2 entries
+  int bits = 0;
+  while ((kmax >> bits) != 0) ++bits;
+  const int passes = bits <= 8 ? 1 : (bits <= 16 ? 2 : 3);
+  for (int p = 0; p < passes; ++p) {
+    const int32_t* in = p == 0 ? nullptr : ord[(p - 1) & 1];
+    int32_t* out = p == passes - 1 ? d_order : ord[p & 1];
+    hipLaunchKernelGGL(k_sort_hist, dim3((unsigned)L.nblk), dim3(64), 0, s, in, len, (int)G, kmax,
+                       8 * p, (int)L.nblk, hist);
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, hist, (int64_t)256 * L.nblk);
+    hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)L.nblk), dim3(64), 0, s, in, len, (int)G,
+                       kmax, 8 * p, (int)L.nblk, hist, out);
+  }
+  hipLaunchKernelGGL(k_lists_plan, dim3(1), dim3(1024), 0, s, len, d_order, (int)G, gpw, L.nwg,
+                     padded, base);
+  hipLaunchKernelGGL(k_lists_slots, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, padded, base,
+                     (int)G, gpw, d_start, d_ngroups);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(entries_out, base + L.nwg, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipStreamSynchronize(s));
+  return SCOARY_OK;
+}
+
+int scoary_lists_fill(scoary_handle h, const uint32_t* d_tiled, int64_t G, int64_t N,
+                      const void* d_scratch, const int32_t* d_order, const uint8_t* d_flipped,
+                      int64_t entries, uint32_t* d_idx, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_scratch || !d_order || !d_flipped || !d_idx || G < 1 || N < 1 || entries < 0)
+    return fail(h, SCOARY_ERR_ARG, "scoary_lists_fill: bad argument");
+  const int TW = list_tw(N);
+  if (!TW) return fail(h, SCOARY_ERR_SIZE, "scoary_lists_fill: N too large for LDS label tiles");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const ListScratch L = list_scratch(G, N);
+  const char* sc = static_cast<const char*>(d_scratch);
+  const int32_t* len = reinterpret_cast<const int32_t*>(sc + L.len);
+  const int64_t* base = reinterpret_cast<const int64_t*>(sc + L.base);
+  const int32_t* padded = reinterpret_cast<const int32_t*>(sc + L.padded);
+  const int64_t Gp = scoary_tiled_genes(G);
+  const int Qn = (int)((N + 127) / 128);
+  const int gpw = kWave / list_lpg(TW), piece = 4 * list_lpg(TW), C = 64 / TW;
+  const int64_t nslots = L.nwg * gpw;
+  const int spb = 4 * (64 / C);                      // slots per block of four wavefronts
+  const dim3 grid((unsigned)((nslots + spb - 1) / spb));
+  KernelTimer kt(h, s, "k_lists_fill");
+#define FILL(CV)                                                                               \
+  hipLaunchKernelGGL((k_lists_fill<CV>), grid, dim3(256), 0, s,                                \
+                     reinterpret_cast<const uint4*>(d_tiled), Gp, (int)G, (int)N, Qn, len,     \
+                     d_order, d_flipped, base, padded, gpw, piece, (uint32_t)(TW * 4), nslots, \
+                     d_idx)
+  if (C == 4) FILL(4); else if (C == 8) FILL(8); else if (C == 16) FILL(16);
+  else if (C == 32) FILL(32); else FILL(64);
+#undef FILL
+  hipLaunchKernelGGL(k_lists_slack, dim3(1), dim3(256), 0, s, d_idx, entries);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+}  // extern "C"

@@ -19,20 +19,7 @@ namespace {
 // per 32 isolates per permutation: a gene present in 26 % of 2000 isolates
 // costs 41 ops per test instead of 137, a rare variant ~20x less.
 //
-// TW = tile row width in dwords (32 permutations each): 16 while a tile of 512
-// permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
-// N <= 5119, 4 (tiles of 128) up to N <= 10239, 2 (tiles of 64, two words per lane)
-// up to N <= 20479, 1 (tiles of 32, one word per lane) up to N <= 40959.  A gene takes
-// max(TW/4, 1) lanes and a wavefront 64 / that many genes of similar list length.
-__host__ __device__ constexpr int list_tw(int64_t N) {
-  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : (N <= 20479 ? 2 : (N <= 40959 ? 1 : 0))));
-}
-__host__ __device__ constexpr int list_lpg(int TW) { return TW >= 4 ? TW / 4 : 1; }   // lanes per gene
-__host__ __device__ constexpr int list_nw(int TW) { return TW >= 4 ? 4 : TW; }        // words per lane
-// dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
-__host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int TW) {
-  return ((N + 1) * TW + 3) / 4 * 4;
-}
+// list_tw / list_lpg / list_nw / list_tile_dwords: scoary_common.hpp
 
 // VGPR banks.  A VOP3 instruction whose src0 and src1 live in the same VGPR bank
 // (register index mod 4) issues in ~4.5 cycles instead of ~2.65 on gfx950
@@ -425,6 +412,13 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
   out[(int64_t)t * G + k] = o;
 }
 
+// lane id from v_mbcnt, opaque to the optimiser (see its use in k_permute_lists)
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 // 128 permutations per lane: LPG = TW/4 lanes per gene read the tile rows with
 // ds_read_b128, 64/LPG genes per wavefront; one address add serves four words.
 // ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, ... over the full
@@ -495,46 +489,61 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
                                                         const uint32_t* __restrict__ lidx,
                                                         const int32_t* __restrict__ lstart,
                                                         const int32_t* __restrict__ lngroups,
-                                                        const int32_t* __restrict__ lorder,
                                                         const uint2* __restrict__ lcrit, int G,
-                                                        int N, int64_t P, int ntiles,
-                                                        int groups_per_block,
-                                                        uint32_t* __restrict__ r) {
+                                                        int N, int64_t P, int T, int ntiles,
+                                                        int parts, int tiles_per_block,
+                                                        int groups_per_block, int64_t lidx_bytes,
+                                                        uint32_t* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
   scoary_bank_defs();                // assembler symbols for the operand-ordering .if blocks
   constexpr int TW = NW * LPG;       // tile row, dwords
   static_assert(NW == 4 || ((NW == 2 || NW == 1) && LPG == 1), "narrow rows: one lane per gene");
   constexpr int GPW = kWave / LPG;   // genes per wavefront
-  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int lg = lane / LPG, col = lane % LPG;
+  // A block owns one trait, a contiguous range of its label tiles (a "part") and a chunk
+  // of wave groups: it walks the tiles one after the other and keeps the exceedance
+  // counts of its genes in ONE register across them -- group kk of a wavefront lives in
+  // lane (kk mod LPG) of every gene's lane group, 16 bits for kk < LPG and the upper 16
+  // for LPG <= kk < 2*LPG -- so every (part, trait, gene) count is written exactly once,
+  // with a plain store (no atomics: one per (gene, tile) before, 316 MB of write traffic
+  // for a 2 MB result at the headline config).
+  const int t = blockIdx.x / parts, part = blockIdx.x % parts;
+  const int tile_lo = part * tiles_per_block, tile_hi = min(ntiles, tile_lo + tiles_per_block);
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: loops over groups stay scalar
+  const int col = lane % LPG;
+  const int ngroups = (G + GPW - 1) / GPW;         // wave groups of GPW genes
+  const int q_lo = blockIdx.y * groups_per_block;
+  const int q_hi = min(ngroups, q_lo + groups_per_block);
+  uint32_t acc = 0u;
+  const uint32_t lane_off = (uint32_t)lane * 16u;   // 16-byte vectors: tile loads and index loads
 
-  const int tile_dwords = (N + 1) * TW;
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
   const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW);
+  if (tile != tile_lo) __syncthreads();            // every wavefront is done with the previous tile
   {
     // tile -> LDS by LDS-DMA (global_load_lds_dwordx4): a wavefront moves 64 x 16 B
     // per instruction straight into LDS (destination = wave-uniform base + 16*lane),
     // no VGPR round trip and no ds_write pass
     const uint4* src4 = reinterpret_cast<const uint4*>(src);
     const int n4 = (int)(list_tile_dwords(N, TW) / 4);   // HBM tiles are padded to 16 bytes
+    // address = wave-uniform base (SGPR pair) + zero-extended 32-bit lane offset: the
+    // saddr form of the load, no 64-bit per-lane address held across the kernel
+    // (inline asm: the builtin only takes a per-lane 64-bit address; M0 = LDS destination)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds;
     for (int i = wave * kWave; i < n4; i += nwaves * kWave)
       if (i + lane < n4)
-        __builtin_amdgcn_global_load_lds(src4 + i + lane, tile_lds + (size_t)i * 4, 16, 0, 0);
-    __builtin_amdgcn_s_waitcnt(0);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :
+                     : "s"(lds0 + (uint32_t)i * 16u), "v"(lane_off), "s"(src4 + i)
+                     : "memory", "m0");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
 
-  // LPG == 1: an entry is used as the LDS address as it is -- the tile is the kernel's only LDS
-  // object and sits at LDS address 0
-  if constexpr (LPG == 1)
-    if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds != 0u)
-      __builtin_trap();
-  const int ngroups = (G + GPW - 1) / GPW;         // wave groups of GPW genes
-  const int q_lo = blockIdx.y * groups_per_block;
-  const int q_hi = min(ngroups, q_lo + groups_per_block);
-  for (int q = q_lo + wave; q < q_hi; q += nwaves) {
-    const int slot = min(q * GPW + lg, G - 1);
-    const bool have = q * GPW + lg < G;
+  // LPG == 1: an entry is used as the LDS address as it is -- the tile is the kernel's only
+  // LDS object and sits at LDS address 0 (checked on the host: no static LDS in this kernel)
+  int kk = 0;                                      // this wavefront's kk-th group of the chunk
+  for (int q = q_lo + wave; q < q_hi; q += nwaves, ++kk) {
     const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);   // 32-entry steps
     // interleaved lists (piece = TW entries): the wavefront's 64 lanes read 64
     // consecutive 16-byte index vectors per piece
@@ -577,12 +586,14 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     // list re-read its last piece (valid rows, never summed).
     const int last = max(nsuper * (8 / LPG) - 1, 0);
     int piece = 0;                                   // piece whose vector is ring[piece % 4]
-    const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(Ent);   // scalar base + 32-bit lane offset
     // buffer load: group base in the resource descriptor (SGPRs), piece offset in the scalar
     // offset, lane offset in one VGPR -- no per-load 64-bit VALU address arithmetic
     // (v_lshl_add_u64 per load otherwise, ~10 cycles each beside the v_bitop3 stream)
+    // num_records = the bytes from the group's base to the end of the index array: a
+    // read past the end (groups without entries still issue their prologue loads) returns 0
+    const int64_t gbytes = lidx_bytes - (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 128;
     const __amdgpu_buffer_rsrc_t lists_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<Ent*>(gbase), 0, 0x7fffffff, 0x00020000);
+        const_cast<Ent*>(gbase), 0, (int)min(gbytes, (int64_t)0x7fffffff), 0x00020000);
     auto load_piece = [&](int p) -> Ent {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(lists_rsrc, lane_off,
                                                             min(p, last) * (kWave * (int)sizeof(Ent)), 0);
@@ -649,6 +660,11 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
 #undef STEP
 #undef SUBSTEP
 #undef FA4
+    // the lane's gene within the group, recomputed here (volatile asm: not hoisted) rather
+    // than held in a register across the list walk -- the walk uses every VGPR there is
+    const int lg = fresh_lane() / LPG;
+    const int slot = min(q * GPW + lg, G - 1);
+    const bool have = q * GPW + lg < G;
     const uint2 cr = lcrit[(int64_t)t * G + slot];
     const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
     const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
@@ -670,8 +686,28 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     if (!have) cnt = 0;
 #pragma unroll
     for (int off = LPG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if (have && col == 0 && cnt) atomicAdd(&r[(int64_t)t * G + lorder[slot]], (uint32_t)cnt);
+    if (col == (kk & (LPG - 1))) acc += (uint32_t)cnt << (kk >= LPG ? 16 : 0);
   }
+  }  // tiles of this block
+  const int64_t gs = (int64_t)ngroups * GPW;        // slots, padded to whole wave groups
+  uint32_t* out = partial + ((int64_t)part * T + t) * gs;
+  int kk = 0;
+  for (int q = q_lo + wave; q < q_hi; q += nwaves, ++kk)
+    if (col == (kk & (LPG - 1)))
+      out[(int64_t)q * GPW + fresh_lane() / LPG] = kk >= LPG ? acc >> 16 : acc & 0xffffu;
+}
+
+// r[t][gene of slot k] += sum over the parts of partial[part][t][k]
+__global__ __launch_bounds__(256) void k_lists_reduce(const uint32_t* __restrict__ partial,
+                                                      int parts, int T, int64_t gs, int G,
+                                                      const int32_t* __restrict__ order,
+                                                      uint32_t* __restrict__ r) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (k >= G) return;
+  uint32_t sum = 0u;
+  for (int p = 0; p < parts; ++p) sum += partial[((int64_t)p * T + t) * gs + k];
+  r[(int64_t)t * G + order[k]] += sum;
 }
 
 }  // namespace
@@ -744,59 +780,115 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
 }
 
 extern "C++" {
+// Launch geometry of k_permute_lists (also sizes the scratch): wave groups per block,
+// gene chunks, tile parts per trait, tiles per block.
+struct ListGeom {
+  int64_t ntiles, ngroups, gs, gpb, chunks, parts, tpb, parts_cap;
+};
+static ListGeom list_geom(int num_cu, int64_t G, int64_t T, int64_t N, int64_t P, int64_t entries) {
+  ListGeom g{};
+  const int TW = list_tw(N), LPG = list_lpg(TW), GPW = kWave / LPG;
+  const int64_t tile_perms = TW * 32;
+  g.ntiles = (P + tile_perms - 1) / tile_perms;
+  g.ngroups = (G + GPW - 1) / GPW;
+  g.gs = g.ngroups * GPW;
+  // one accumulator register holds 2*LPG groups per wavefront (16-bit halves x LPG lanes),
+  // and a 16-bit count holds 65535 permutations
+  const int64_t gpb_cap = 16 * 2 * LPG;
+  const int64_t tpb_cap = 65535 / tile_perms;
+  const int64_t min_parts = (g.ntiles + tpb_cap - 1) / tpb_cap;
+  g.parts_cap = min_parts > 3 ? min_parts : 3;      // <= 3 partial results + r: write traffic <= 4x the result
+  int64_t parts_max = g.ntiles < g.parts_cap ? g.ntiles : g.parts_cap;
+  if (parts_max < 1) parts_max = 1;
+  static const int64_t target_rounds = getenv("SCOARY_LISTS_ROUNDS") ? atoll(getenv("SCOARY_LISTS_ROUNDS")) : 6;
+  const int64_t target_blocks = (int64_t)num_cu * target_rounds;
+  // chunks: the accumulator capacity, index lists of a chunk <= ~2 MB (they stay in an
+  // XCD's 4 MB L2 while the (trait, part) blocks of the chunk walk them tile after tile),
+  // and enough blocks to fill the CUs a few times over; at least one group per wavefront
+  int64_t chunks = (g.ngroups + gpb_cap - 1) / gpb_cap;
+  const int64_t by_l2 = (entries * 4 + (2 << 20) - 1) / (2 << 20);
+  if (chunks < by_l2) chunks = by_l2;
+  const int64_t by_blocks = (target_blocks + T * parts_max - 1) / (T * parts_max);
+  if (chunks < by_blocks) chunks = by_blocks;
+  if (chunks > 65535) chunks = 65535;
+  if (chunks < 1) chunks = 1;
+  g.gpb = (g.ngroups + chunks - 1) / chunks;
+  g.gpb = (g.gpb + 15) / 16 * 16;
+  if (g.gpb > gpb_cap) g.gpb = gpb_cap;
+  g.chunks = (g.ngroups + g.gpb - 1) / g.gpb;
+  int64_t parts = (target_blocks + T * g.chunks - 1) / (T * g.chunks);
+  if (parts > parts_max) parts = parts_max;
+  if (parts < min_parts) parts = min_parts;
+  if (parts < 1) parts = 1;
+  g.tpb = (g.ntiles + parts - 1) / parts;
+  g.parts = (g.ntiles + g.tpb - 1) / g.tpb;
+  return g;
+}
+
 template <int TW, int KC, int KD>
 static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* d_tiles,
-                                const uint32_t* d_lidx, const int32_t* d_lstart,
+                                const uint32_t* d_lidx, int64_t entries, const int32_t* d_lstart,
                                 const int32_t* d_lngroups, const int32_t* d_lorder,
                                 const uint8_t* d_lflipped, const uint32_t* d_crit,
-                                const int32_t* d_margins, uint32_t* d_lcrit, int64_t G, int64_t T,
+                                const int32_t* d_margins, uint32_t* d_scratch, int64_t G, int64_t T,
                                 int64_t N, int64_t P, uint32_t* d_r) {
+  uint32_t* d_lcrit = d_scratch;                       // [T][G][2]
+  uint32_t* d_partial = d_scratch + 2 * T * G;         // [parts][T][gs]
   {
     KernelTimer kt(h, s, "k_lists_crit");
     hipLaunchKernelGGL(k_lists_crit, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
                        reinterpret_cast<const uint2*>(d_crit), d_margins, d_lorder, d_lflipped,
                        (int)G, KD, reinterpret_cast<uint2*>(d_lcrit));
   }
-  const int64_t tile_perms = TW * 32;
-  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  constexpr int GPW = kWave / list_lpg(TW);     // genes per wavefront
-  const int64_t ngroups = (G + GPW - 1) / GPW;
-  // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index
-  // lists (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the
-  // chunk run; each chunk a multiple of 16 wave groups
-  int64_t chunks = ((int64_t)h->num_cu * 16 + ntiles * T - 1) / (ntiles * T);
-  const int64_t by_l2 = (G * N / 4 * 4 + (2 << 20) - 1) / (2 << 20);   // ~N/4 entries x 4 B per gene
-  if (chunks < by_l2) chunks = by_l2;
-  if (chunks > 65535) chunks = 65535;
-  if (chunks < 1) chunks = 1;
-  int64_t gpb = (ngroups + chunks - 1) / chunks;
-  gpb = (gpb + 15) / 16 * 16;
-  chunks = (ngroups + gpb - 1) / gpb;
+  const ListGeom g = list_geom(h->num_cu, G, T, N, P, entries);
+  if (T * g.parts > 0x7fffffffLL || g.chunks > 65535)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: grid too large");
   const size_t lds = (size_t)list_tile_dwords(N, TW) * sizeof(uint32_t);
+  const void* fn = reinterpret_cast<const void*>(&k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>);
   if (!(h->lists_lds_optin & TW)) {   // once per handle (= per device) and tile width
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // list entries of the one-lane-per-gene kernels are absolute LDS addresses: the label
+    // tile must be the kernel's only LDS object (dynamic LDS then starts at address 0)
+    hipFuncAttributes attr;
+    HIP_TRY(h, hipFuncGetAttributes(&attr, fn));
+    if (attr.sharedSizeBytes != 0)
+      return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: k_permute_lists has static LDS; the "
+                                      "label tile would not sit at LDS address 0");
+    HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     h->lists_lds_optin |= TW;
   }
-  KernelTimer kt(h, s, "k_permute_lists");
-  hipLaunchKernelGGL((k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>), dim3((unsigned)(ntiles * T), (unsigned)chunks),
-                     dim3(1024), lds, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                     reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P, (int)ntiles,
-                     (int)gpb, d_r);
+  {
+    KernelTimer kt(h, s, "k_permute_lists");
+    hipLaunchKernelGGL((k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>),
+                       dim3((unsigned)(T * g.parts), (unsigned)g.chunks), dim3(1024), lds, s, d_tiles,
+                       d_lidx, d_lstart, d_lngroups, reinterpret_cast<const uint2*>(d_lcrit), (int)G,
+                       (int)N, P, (int)T, (int)g.ntiles, (int)g.parts, (int)g.tpb, (int)g.gpb,
+                       (entries + kListSlack) * (int64_t)sizeof(uint32_t), d_partial);
+  }
+  {
+    KernelTimer kt(h, s, "k_lists_reduce");
+    hipLaunchKernelGGL(k_lists_reduce, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                       d_partial, (int)g.parts, (int)T, g.gs, (int)G, d_lorder, d_r);
+  }
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }
 }  // extern "C++"
 
+int64_t scoary_permute_lists_scratch_bytes(int64_t G, int64_t T, int64_t N, int64_t P) {
+  if (G < 1 || T < 1 || N < 1 || P < 1 || !list_tw(N)) return 0;
+  const ListGeom g = list_geom(256, G, T, N, P, 0);
+  return (2 * T * G + g.parts_cap * T * g.gs) * (int64_t)sizeof(uint32_t);
+}
+
 int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_t* d_lidx,
-                         const int32_t* d_lstart, const int32_t* d_lngroups,
+                         int64_t entries, const int32_t* d_lstart, const int32_t* d_lngroups,
                          const int32_t* d_lorder, const uint8_t* d_lflipped,
-                         const uint32_t* d_crit, const int32_t* d_margins, uint32_t* d_lcrit,
+                         const uint32_t* d_crit, const int32_t* d_margins, void* d_scratch,
                          int64_t G, int64_t T, int64_t N, int64_t P, uint32_t* d_r,
                          scoary_stream_t stream) {
   if (!h) return SCOARY_ERR_ARG;
   if (!d_tiles || !d_lidx || !d_lstart || !d_lngroups || !d_lorder || !d_lflipped || !d_crit ||
-      !d_margins || !d_lcrit || !d_r || G < 1 || T < 1 || N < 1 || P < 1)
+      !d_margins || !d_scratch || !d_r || G < 1 || T < 1 || N < 1 || P < 1 || entries < 0)
     return fail(h, SCOARY_ERR_ARG, "scoary_permute_lists: bad argument");
   const int TW = list_tw(N);
   if (!TW)
@@ -804,21 +896,18 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   if (T > 65535) return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: T > 65535");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  uint32_t* sc = static_cast<uint32_t*>(d_scratch);
   // counter planes KC: lists hold <= N/2 entries; compare planes KD: 2N+3 <= 2^KD
-  if (TW == 16)
-    return launch_permute_lists<16, 11, 13>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                                            d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  if (TW == 8)
-    return launch_permute_lists<8, 12, 14>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                                           d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  if (TW == 4)
-    return launch_permute_lists<4, 13, 15>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                                           d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  if (TW == 2)
-    return launch_permute_lists<2, 14, 16>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                                           d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
-  return launch_permute_lists<1, 15, 17>(h, s, d_tiles, d_lidx, d_lstart, d_lngroups, d_lorder,
-                                         d_lflipped, d_crit, d_margins, d_lcrit, G, T, N, P, d_r);
+#define LAUNCH(TWV, KCV, KDV)                                                                    \
+  return launch_permute_lists<TWV, KCV, KDV>(h, s, d_tiles, d_lidx, entries, d_lstart, d_lngroups, \
+                                             d_lorder, d_lflipped, d_crit, d_margins, sc, G, T, N, \
+                                             P, d_r)
+  if (TW == 16) LAUNCH(16, 11, 13);
+  if (TW == 8) LAUNCH(8, 12, 14);
+  if (TW == 4) LAUNCH(4, 13, 15);
+  if (TW == 2) LAUNCH(2, 14, 16);
+  LAUNCH(1, 15, 17);
+#undef LAUNCH
 }
 
 }  // extern "C"

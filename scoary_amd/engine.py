@@ -39,11 +39,68 @@ class GeneMatrix:
 
 
 class GeneLists:
-    """Minority index lists of a gene matrix on the device (scoary_lists_build)."""
+    """Minority index lists of a gene matrix on the device (scoary_lists_plan / _fill)."""
 
     def __init__(self, idx, start, ngroups, order, flipped, entries):
         self.idx, self.start, self.ngroups = idx, start, ngroups
         self.order, self.flipped, self.entries = order, flipped, entries
+
+
+class Workspace:
+    """Device buffers of one associate() step (engine.workspace)."""
+
+    def __init__(self, eng, genes, T, permutations, use_lists, perm_buffer=None):
+        torch = _torch()
+        G, N = genes.G, genes.N
+        if use_lists is None:
+            use_lists = genes.lists is not None and eng.lists_supported(N)
+        self.key = (G, N, int(T), int(permutations), bool(use_lists and permutations > 0))
+        self.counts = eng._empty((T, G, 4), torch.int32)
+        self.margins = eng._empty((T, 2), torch.int32)
+        self.p = eng._empty((T, G), torch.float64)
+        self.odds = eng._empty((T, G), torch.float64)
+        self.crit = eng._empty((T, G, 2), torch.int32) if permutations > 0 else None
+        self.r = eng._empty((T, G), torch.int32) if permutations > 0 else None
+        self.tiles = self.scratch = self.perms = None
+        self.batch = 0
+        if permutations > 0 and use_lists:
+            self.batch = eng.list_batch(T, N, permutations)
+            nb0 = min(self.batch, permutations)
+            self.tiles = eng._empty((int(eng.lib.scoary_list_tiles_words(N, nb0, T)),), torch.int32)
+            self.scratch = eng.permute_lists_scratch(G, T, N, nb0)
+        elif permutations > 0:
+            if perm_buffer is not None:
+                self.perms = perm_buffer
+            else:
+                self.perms = eng._empty((T, eng.perm_batch(T, N, permutations), eng.row_words(N)),
+                                        torch.int32)
+
+    def fits(self, genes, T, permutations, use_lists):
+        return self.key == (genes.G, genes.N, int(T), int(permutations),
+                            bool(use_lists and permutations > 0))
+
+
+class StepGraph:
+    """A captured associate() step (engine.capture)."""
+
+    def __init__(self, eng, graph, stream):
+        self.eng, self.graph, self.stream = eng, graph, stream
+
+    def launch(self):
+        eng = self.eng
+        eng._check(eng.lib.scoary_graph_launch(eng.h, self.graph, eng._stream()),
+                   "scoary_graph_launch")
+
+    def close(self):
+        if self.graph:
+            self.eng.lib.scoary_graph_destroy(self.graph)
+            self.graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class AssociationEngine:
@@ -141,18 +198,33 @@ class AssociationEngine:
         buf[:, :2 * W] = rows64.view(np.uint32).reshape(R, 2 * W)
         return torch.from_numpy(buf.view(np.int32)).to(self.device)
 
-    def build_lists(self, genes, rows64):
-        """Attach the minority index lists of ``rows64`` (host (G, W64) uint64,
-        the same genes as ``genes``) for the list-driven permutation kernel."""
+    def build_lists(self, genes):
+        """Attach the minority index lists of ``genes`` (spec S6) for the list-driven
+        permutation kernel.  Built on the device from the tiled matrix that is
+        already in HBM (scoary_lists_plan + scoary_lists_fill): nothing crosses
+        PCIe but the 8-byte entry count."""
         torch = _torch()
-        from . import io_native
-        lanes, stride, gpw, classes, piece = self.list_params(genes.N)
+        lanes, _stride, _gpw, _classes, _piece = self.list_params(genes.N)
         if not lanes:
             raise ValueError("N=%d is too large for the list-driven kernel" % genes.N)
-        d = io_native.build_lists(rows64, genes.N, stride, gpw, classes, piece)
-        dev = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(self.device)  # noqa: E731
-        genes.lists = GeneLists(dev(d["idx"]), dev(d["start"]), dev(d["ngroups"]),
-                                dev(d["order"]), dev(d["flipped"]), d["entries"])
+        G, N = genes.G, genes.N
+        scratch = self._empty((int(self.lib.scoary_lists_scratch_bytes(G, N)) // 8 + 1,),
+                              torch.int64)
+        start = self._empty((G,), torch.int32)
+        ngroups = self._empty((G,), torch.int32)
+        order = self._empty((G,), torch.int32)
+        flipped = self._empty((G,), torch.uint8)
+        entries = ctypes.c_int64()
+        self._check(self.lib.scoary_lists_plan(
+            self.h, self._ptr(genes.tiled), G, N, self._ptr(scratch), self._ptr(start),
+            self._ptr(ngroups), self._ptr(order), self._ptr(flipped), ctypes.byref(entries),
+            self._stream()), "scoary_lists_plan")
+        total = int(entries.value)
+        idx = self._empty((total + int(self.lib.scoary_lists_slack_entries()),), torch.int32)
+        self._check(self.lib.scoary_lists_fill(
+            self.h, self._ptr(genes.tiled), G, N, self._ptr(scratch), self._ptr(order),
+            self._ptr(flipped), total, self._ptr(idx), self._stream()), "scoary_lists_fill")
+        genes.lists = GeneLists(idx, start, ngroups, order, flipped, total)
         return genes.lists
 
     def list_params(self, N):
@@ -175,25 +247,30 @@ class AssociationEngine:
             ctypes.c_uint64(seed), self._ptr(out), self._stream()), "scoary_perm_generate_tiles")
         return out
 
-    def permute_lists(self, genes, tiles, crit, margins, P, r, scratch=None):
+    def permute_lists_scratch(self, G, T, N, P):
+        """Scratch tensor for permute_lists (list-order regions + per-part counts)."""
         torch = _torch()
+        nbytes = int(self.lib.scoary_permute_lists_scratch_bytes(G, T, N, P))
+        return self._empty(((nbytes + 3) // 4,), torch.int32)
+
+    def permute_lists(self, genes, tiles, crit, margins, P, r, scratch=None):
         L = genes.lists
         T = crit.shape[0]
         if scratch is None:
-            scratch = self._empty((T, genes.G, 2), torch.int32)
+            scratch = self.permute_lists_scratch(genes.G, T, genes.N, P)
         self._check(self.lib.scoary_permute_lists(
-            self.h, self._ptr(tiles), self._ptr(L.idx), self._ptr(L.start), self._ptr(L.ngroups),
-            self._ptr(L.order), self._ptr(L.flipped), self._ptr(crit), self._ptr(margins),
-            self._ptr(scratch), genes.G, T, genes.N, P, self._ptr(r), self._stream()),
-            "scoary_permute_lists")
+            self.h, self._ptr(tiles), self._ptr(L.idx), L.entries, self._ptr(L.start),
+            self._ptr(L.ngroups), self._ptr(L.order), self._ptr(L.flipped), self._ptr(crit),
+            self._ptr(margins), self._ptr(scratch), genes.G, T, genes.N, P, self._ptr(r),
+            self._stream()), "scoary_permute_lists")
         return r
 
     # -- a3: counts -----------------------------------------------------------
-    def counts(self, genes, traits, masks):
+    def counts(self, genes, traits, masks, out=None):
         torch = _torch()
         T = traits.shape[0]
-        counts = self._empty((T, genes.G, 4), torch.int32)
-        margins = self._empty((T, 2), torch.int32)
+        counts, margins = out if out is not None else (
+            self._empty((T, genes.G, 4), torch.int32), self._empty((T, 2), torch.int32))
         self._check(self.lib.scoary_counts(self.h, self._ptr(genes.tiled), self._ptr(traits),
                                            self._ptr(masks), genes.G, T, genes.N,
                                            self._ptr(counts), self._ptr(margins), self._stream()),
@@ -201,18 +278,21 @@ class AssociationEngine:
         return counts, margins
 
     # -- a5: Fisher -----------------------------------------------------------
-    def fisher(self, tables, want_crit=True):
+    def fisher(self, tables, want_crit=True, out=None):
         """tables: int32 device tensor [..., 4] -> (p, odds, crit) shaped [...]."""
         torch = _torch()
         tables = tables.contiguous()
         shape = tables.shape[:-1]
         M = int(np.prod(shape)) if len(shape) else 1
-        p = self._empty(shape, torch.float64)
-        odds = self._empty(shape, torch.float64)
-        crit = self._empty(tuple(shape) + (2,), torch.int32) if want_crit else None
+        if out is not None:
+            p, odds, crit = out
+        else:
+            p = self._empty(shape, torch.float64)
+            odds = self._empty(shape, torch.float64)
+            crit = self._empty(tuple(shape) + (2,), torch.int32) if want_crit else None
         self._check(self.lib.scoary_fisher(self.h, self._ptr(tables), M, self._ptr(p),
                                            self._ptr(odds),
-                                           self._ptr(crit) if want_crit else None,
+                                           self._ptr(crit) if crit is not None else None,
                                            self._stream()), "scoary_fisher")
         return p, odds, crit
 
@@ -230,8 +310,10 @@ class AssociationEngine:
                     "scoary_perm_generate")
         return out
 
-    def permute(self, genes, perms, crit, r):
-        T, P = perms.shape[0], perms.shape[1]
+    def permute(self, genes, perms, crit, r, P=None):
+        T = perms.shape[0]
+        if P is None:
+            P = perms.shape[1]
         self._check(self.lib.scoary_permute(self.h, self._ptr(genes.tiled), self._ptr(perms),
                                             self._ptr(crit), genes.G, T, genes.N, P,
                                             self._ptr(r), self._stream()), "scoary_permute")
@@ -244,63 +326,91 @@ class AssociationEngine:
         return int(max(1, min(P, budget_bytes // max(per, 1))))
 
     # -- the whole hot path ----------------------------------------------------
+    def list_batch(self, T, N, permutations, budget_bytes=8 << 30):
+        """Permutations per label-tile batch of the list-driven path (multiple of
+        512, tiles under budget_bytes)."""
+        per = max(int(self.lib.scoary_list_tiles_words(N, 512, T)) * 4, 1)    # bytes / 512 perms
+        return int(max(512, min(-(-permutations // 512) * 512, (budget_bytes // per) * 512)))
+
+    def workspace(self, genes, T, permutations=0, use_lists=None, perm_buffer=None):
+        """Every device buffer one associate() step needs, allocated once: steps that
+        reuse it allocate nothing (a precondition for hipGraph capture, and what
+        small launch-bound workloads need anyway)."""
+        return Workspace(self, genes, T, permutations, use_lists, perm_buffer)
+
     def associate(self, genes, traits, masks, permutations=0, seed=0, perm_buffer=None,
-                  use_lists=None, tiles_buffer=None):
+                  use_lists=None, workspace=None):
         """counts -> Fisher -> (optional) permutation exceedance counts.
         Returns dict of device tensors: counts [T,G,4], margins [T,2],
-        p / odds [T,G], r [T,G] (uint32 bit pattern in int32) or None."""
+        p / odds [T,G], r [T,G] (uint32 bit pattern in int32) or None.  With
+        ``workspace`` the result tensors are the workspace's (overwritten by the
+        next step that uses it)."""
         torch = _torch()
+        T = traits.shape[0]
         if use_lists is None:
             use_lists = genes.lists is not None and self.lists_supported(genes.N)
-        counts, margins = self.counts(genes, traits, masks)
-        r = None
+        ws = workspace
+        if ws is None:
+            ws = Workspace(self, genes, T, permutations, use_lists, perm_buffer)
+        elif not ws.fits(genes, T, permutations, use_lists):
+            raise ValueError("workspace was made for another problem shape")
+        counts, margins = self.counts(genes, traits, masks, out=(ws.counts, ws.margins))
         if permutations > 0 and use_lists:
-            T = traits.shape[0]
-            per = int(self.lib.scoary_list_tiles_words(genes.N, 512, T)) * 4   # bytes / 512 perms
-            per = max(per, 1)
-            batch = int(max(512, min(-(-permutations // 512) * 512, ((8 << 30) // per) * 512)))
             # The first batch of label tiles needs only the trait margins, not the
             # Fisher pass: generate it on a side stream while k_fisher runs.
             main = torch.cuda.current_stream(self.device)
             side = self._side_stream()
             side.wait_stream(main)
-            nb0 = min(batch, permutations)
-            need = int(self.lib.scoary_list_tiles_words(genes.N, nb0, T))
-            buf = tiles_buffer[:need] if (tiles_buffer is not None and
-                                          tiles_buffer.numel() >= need) else None
+            nb0 = min(ws.batch, permutations)
             with torch.cuda.stream(side):
-                tiles = self.perm_generate_tiles(masks, margins, genes.N, nb0, 0, seed, out=buf)
-            tiles.record_stream(main)
-            p, odds, crit = self.fisher(counts, want_crit=True)
-            r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
+                self.perm_generate_tiles(masks, margins, genes.N, nb0, 0, seed, out=ws.tiles)
+            p, odds, crit = self.fisher(counts, out=(ws.p, ws.odds, ws.crit))
+            ws.r.zero_()
             main.wait_stream(side)
             done = 0
             while done < permutations:
-                nb = min(batch, permutations - done)
+                nb = min(ws.batch, permutations - done)
                 if done > 0:
-                    tiles = self.perm_generate_tiles(masks, margins, genes.N, nb, done, seed)
-                self.permute_lists(genes, tiles, crit, margins, nb, r)
+                    self.perm_generate_tiles(masks, margins, genes.N, nb, done, seed, out=ws.tiles)
+                self.permute_lists(genes, ws.tiles, crit, margins, nb, ws.r, scratch=ws.scratch)
                 done += nb
             return {"counts": counts, "margins": margins, "p": p, "odds": odds, "crit": crit,
-                    "r": r}
-        p, odds, crit = self.fisher(counts, want_crit=permutations > 0)
+                    "r": ws.r}
+        p, odds, crit = self.fisher(counts, out=(ws.p, ws.odds, ws.crit))
+        r = None
         if permutations > 0:
-            T = traits.shape[0]
-            r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
-            if perm_buffer is not None:
-                batch = perm_buffer.shape[1]
-            else:
-                batch = self.perm_batch(T, genes.N, permutations)
+            r = ws.r
+            r.zero_()
+            batch = ws.perms.shape[1]
             done = 0
             while done < permutations:
                 nb = min(batch, permutations - done)
-                buf = None
-                if perm_buffer is not None:
-                    buf = perm_buffer[:, :nb] if nb == batch else None
-                perms = self.perm_generate(masks, margins, genes.N, nb, done, seed, out=buf)
-                self.permute(genes, perms, crit, r)
+                self.perm_generate(masks, margins, genes.N, nb, done, seed, out=ws.perms)
+                self.permute(genes, ws.perms[:, :nb] if nb == batch else ws.perms, crit, r, P=nb)
                 done += nb
         return {"counts": counts, "margins": margins, "p": p, "odds": odds, "crit": crit, "r": r}
+
+    def capture(self, genes, traits, masks, permutations, seed, workspace, use_lists=None):
+        """Record one associate() step into a hipGraph (scoary_graph_*): returns
+        (StepGraph, result dict).  The results live in ``workspace``; ``launch()``
+        recomputes them with a single graph launch.  The step is run once eagerly
+        first (kernel attributes, side stream and lazy module loads happen outside the
+        capture)."""
+        torch = _torch()
+        self.associate(genes, traits, masks, permutations=permutations, seed=seed,
+                       use_lists=use_lists, workspace=workspace)
+        torch.cuda.synchronize(self.device)
+        stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(stream):
+            self._check(self.lib.scoary_graph_begin(self.h, self._stream()), "scoary_graph_begin")
+            try:
+                res = self.associate(genes, traits, masks, permutations=permutations, seed=seed,
+                                     use_lists=use_lists, workspace=workspace)
+            finally:
+                g = ctypes.c_void_p()
+                rc = self.lib.scoary_graph_end(self.h, self._stream(), ctypes.byref(g))
+            self._check(rc, "scoary_graph_end")
+        return StepGraph(self, g, stream), res
 
     # -- --collapse support (SURVEY 8f-4) -----------------------------------------
     def row_hash(self, genes, masks):

@@ -546,7 +546,7 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED):
         gm = table.on_device(eng) if (a, b) == (0, G) else eng.tile_rows(table.rows64[a:b], N)
         if permutations > 0 and gm.lists is None and eng.lists_supported(N):
             # list-driven permutation kernel: cost follows each gene's minority count
-            eng.build_lists(gm, table.rows64[a:b])
+            eng.build_lists(gm)
         res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed)
         return dist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
 

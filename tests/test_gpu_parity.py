@@ -286,11 +286,10 @@ def test_headline_config_properties(eng, orc):
     genes[101] = genes[100]                 # duplicate
     genes[103] = 1 - genes[102]             # complement
     tb, mb = _bits(eng, traits)
-    from scoary_amd.engine import pack_bits_rows
     gm = eng.pack_dense(genes)
     res = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=seed,
                         use_lists=False)
-    eng.build_lists(gm, pack_bits_rows(genes))
+    eng.build_lists(gm)
     res_l = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=seed,
                           use_lists=True)
     assert np.array_equal(res_l["r"].cpu().numpy(), res["r"].cpu().numpy())
@@ -343,7 +342,7 @@ def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
     seed = 99 + N
     dense = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=False)["r"].cpu().numpy()
-    eng.build_lists(gm, pack_bits_rows(genes))
+    eng.build_lists(gm)
     assert eng.lists_supported(N)
     lists = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=True)["r"].cpu().numpy()
     assert np.array_equal(lists, dense)
@@ -402,7 +401,7 @@ def test_capacity_config_shard_vs_oracle_subsample(eng, orc):
     gm = eng.pack_dense(genes)
     res = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=11,
                         use_lists=False)                    # chunked dense kernel
-    eng.build_lists(gm, pack_bits_rows(genes))
+    eng.build_lists(gm)
     res_l = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=11,
                           use_lists=True)                   # 4-lane list kernel
     assert np.array_equal(res_l["r"].cpu().numpy(), res["r"].cpu().numpy())
@@ -434,7 +433,7 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_fisher(h, p, 0, p, p, null, null) == -1
     assert lib.scoary_permute(h, p, p, p, 1, 70000, 10, 10, p, null) == -3          # T > 65535
     assert lib.scoary_perm_generate(h, p, p, 1, 10, 2**33, 0, 0, 1, p, null) == -3   # index >= 2^32
-    assert lib.scoary_permute_lists(h, p, p, p, p, p, p, p, p, p, 4, 1, 40960, 10, p, null) == -3
+    assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, p, p, p, 4, 1, 40960, 10, p, null) == -3
     assert b"LDS" in lib.scoary_last_error(h)
     assert lib.scoary_tree_pairs(h, p, 3, 40, p, p, 1, 1, 2, p, null) == -3          # stack_depth > 32
     assert lib.scoary_counts(null, p, p, p, 1, 1, 1, p, p, null) == -1
@@ -448,3 +447,92 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_list_params(20480, params) == 0 and list(params) == [1, 4, 64, 64, 4]
     assert lib.scoary_list_params(40960, params) == -3 and params[0] == 0
     assert lib.scoary_list_max_isolates() == 40959
+
+
+# ------------------------------------------- spec S6: device list builder -----
+@pytest.mark.parametrize("G,N", [(1, 1), (5, 31), (203, 333), (1000, 500), (3000, 2000), (700, 2559),
+                                 (900, 2560), (650, 5000), (300, 5120), (257, 10000), (130, 10240),
+                                 (100, 20479), (70, 20480), (40, 40959)])
+def test_device_list_builder_equals_host_builder(eng, G, N):
+    """scoary_lists_plan + scoary_lists_fill (device, product path) write the same
+    arrays -- order, start, ngroups, flipped and every index entry -- as the host
+    builder scoary_lists_build (the checker; an independent implementation of spec
+    S6), for all five tile widths, ties in the length sort, empty and full genes and
+    a ragged last wave group."""
+    from scoary_amd import io_native
+    from scoary_amd.engine import pack_bits_rows
+    rng = np.random.default_rng(G * 31 + N)
+    genes = (rng.random((G, N)) < rng.uniform(0.0, 1.0, (G, 1))).astype(np.uint8)
+    if G > 4:
+        genes[0] = 0
+        genes[1] = 1
+        genes[3] = genes[2]                      # equal lengths: the sort must be stable
+        genes[G - 1] = genes[2]
+    gm = eng.pack_dense(genes)
+    L = eng.build_lists(gm)
+    lanes, stride, gpw, classes, piece = eng.list_params(N)
+    H = io_native.build_lists(pack_bits_rows(genes), N, stride, gpw, classes, piece)
+    assert L.entries == H["entries"]
+    assert np.array_equal(L.order.cpu().numpy(), H["order"])
+    assert np.array_equal(L.flipped.cpu().numpy(), H["flipped"])
+    assert np.array_equal(L.start.cpu().numpy(), H["start"])
+    assert np.array_equal(L.ngroups.cpu().numpy(), H["ngroups"])
+    got = L.idx.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got[:L.entries], H["idx"][:L.entries])
+    assert not got[L.entries:].any()             # slack entries are zero
+
+
+def test_device_list_builder_baseline_shapes(eng):
+    """Device-built lists == host-built lists at the BASELINE list shapes: cfg2
+    (10 000 x 500), cfg3 (50 000 x 2000, 5 % core genes) and a cfg4 slice (rare
+    variants, N = 5000)."""
+    from scoary_amd import io_native, synth
+    from scoary_amd.engine import pack_bits_rows
+    for name, G in (("cfg2", None), ("cfg3", None), ("cfg4", 30000)):
+        genes, _traits, _P, _seed = synth.make_config(name, G=G)
+        N = genes.shape[1]
+        gm = eng.pack_dense(genes)
+        L = eng.build_lists(gm)
+        lanes, stride, gpw, classes, piece = eng.list_params(N)
+        H = io_native.build_lists(pack_bits_rows(genes), N, stride, gpw, classes, piece)
+        assert L.entries == H["entries"], name
+        assert np.array_equal(L.order.cpu().numpy(), H["order"]), name
+        assert np.array_equal(L.start.cpu().numpy(), H["start"]), name
+        assert np.array_equal(L.idx.cpu().numpy().view(np.uint32)[:L.entries],
+                              H["idx"][:L.entries]), name
+
+
+# ------------------------------------------------ workspace / hipGraph -----
+@pytest.mark.parametrize("use_lists", [True, False])
+def test_workspace_and_graph_replay_equal_eager(eng, orc, use_lists):
+    """A step through a reusable workspace, and the same step captured into a
+    hipGraph (scoary_graph_*) and replayed, give the results of the eager path and
+    of the oracle; replays are idempotent (r is re-zeroed inside the graph)."""
+    import torch
+    rng = np.random.default_rng(77)
+    G, N, T, P = 900, 400, 2, 700
+    genes, traits = _random_case(rng, G, N, T)
+    tb, mb = _bits(eng, traits)
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    eng.build_lists(gm)
+    eager = eng.associate(gm, trv, mkv, permutations=P, seed=3, use_lists=use_lists)
+    want_r = eager["r"].cpu().numpy().copy()
+    want_p = eager["p"].cpu().numpy().copy()
+    ws = eng.workspace(gm, T, P, use_lists=use_lists)
+    for _ in range(2):
+        res = eng.associate(gm, trv, mkv, permutations=P, seed=3, use_lists=use_lists, workspace=ws)
+        assert np.array_equal(res["r"].cpu().numpy(), want_r)
+    graph, res = eng.capture(gm, trv, mkv, P, 3, ws, use_lists=use_lists)
+    for _ in range(3):
+        ws.r.fill_(-1)
+        ws.p.fill_(0.0)
+        graph.launch()
+        torch.cuda.synchronize()
+        assert np.array_equal(res["r"].cpu().numpy(), want_r)
+        assert np.array_equal(res["p"].cpu().numpy(), want_p)
+    graph.close()
+    assert np.array_equal(want_r.view(np.uint32),
+                          orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, 3).T)
+    with pytest.raises(ValueError):
+        eng.associate(gm, trv, mkv, permutations=P + 1, seed=3, use_lists=use_lists, workspace=ws)

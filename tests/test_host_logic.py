@@ -466,8 +466,9 @@ def test_io_library_exports_every_declared_symbol():
 def test_minority_lists_builder(gpw, classes, stride, piece):
     """scoary_lists_build (host native): per gene the positions of its minority
     value, padded with N to a multiple of 32 and to the wave group's longest list,
-    genes ordered by descending length, entry e of slot k from residue class
-    (k + e) mod classes (LDS bank trick), entries premultiplied by the row stride;
+    genes ordered by descending length, entries in the bank-rotation order of spec S6
+    (entry e of slot k from residue class (k + e) mod classes while every class has
+    positions left), entries premultiplied by the row stride;
     piece > 0: the group's lists interleaved in pieces, last group stored in full."""
     from scoary_amd import io_native
     from scoary_amd.engine import pack_bits_rows
@@ -513,6 +514,14 @@ def test_minority_lists_builder(gpw, classes, stride, piece):
         for c in range(classes):
             sub = real[cls == c]
             assert np.all(np.diff(sub) > 0)                         # ascending within a class
+        # spec S6 in full: positions sorted by rank-within-class * classes + ((class - k) mod classes)
+        wc = want % classes
+        rho = np.zeros(len(want), dtype=np.int64)
+        for c in range(classes):
+            rho[wc == c] = np.arange(int((wc == c).sum()))
+        key = rho * classes + ((wc - k) % classes)
+        assert len(set(key.tolist())) == len(key)
+        assert np.array_equal(real, want[np.argsort(key)])
     if piece:                                                       # missing genes of the last group
         k0 = (G - 1) // gpw * gpw
         e = np.arange(ng[k0] * 32)

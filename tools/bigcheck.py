@@ -16,6 +16,6 @@ for (G, N, T, P, kind) in [(200000, 5000, 1, 512, "rare"), (30000, 10000, 50, 12
     gm = eng.pack_dense(genes)
     trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
     t = time.time(); d = eng.associate(gm, trv, mkv, permutations=P, seed=5, use_lists=False)["r"]; torch.cuda.synchronize(); td = time.time() - t
-    eng.build_lists(gm, pack_bits_rows(genes))
+    eng.build_lists(gm)
     t = time.time(); l = eng.associate(gm, trv, mkv, permutations=P, seed=5, use_lists=True)["r"]; torch.cuda.synchronize(); tl = time.time() - t
     print(G, N, T, P, kind, "equal:", bool(torch.equal(d, l)), "dense %.3f s lists %.3f s" % (td, tl), "r sum", int(l.sum()))

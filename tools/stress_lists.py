@@ -35,7 +35,7 @@ for case in range(cases):
     gm = eng.pack_dense(genes)
     trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
     d = eng.associate(gm, trv, mkv, permutations=P, seed=case, use_lists=False)["r"]
-    eng.build_lists(gm, pack_bits_rows(genes))
+    eng.build_lists(gm)
     l = eng.associate(gm, trv, mkv, permutations=P, seed=case, use_lists=True)["r"]
     ok = bool(torch.equal(d, l))
     bad += not ok
