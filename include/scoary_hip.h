@@ -143,10 +143,11 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
  *   d_lidx / d_lstart / d_lngroups / d_lorder / d_lflipped : the index lists of the
  *             gene matrix, built on the device by scoary_lists_plan + scoary_lists_fill
  *             (below); `entries` = the entry count scoary_lists_plan returned
- *   d_scratch : scoary_permute_lists_scratch_bytes(G, T, N, P) bytes (list-order
- *             rejection regions + per-part exceedance counts; one block owns a
- *             (trait, part of the tiles, gene chunk) and writes its counts once, a
- *             small second kernel adds the <= 3 parts into d_r -- no atomics)
+ *   d_scratch : scoary_permute_lists_scratch_bytes(G, T, N, P) bytes: the rejection
+ *             regions in list order and one 16-bit exceedance count per (trait,
+ *             tile, list slot) -- the kernel writes them with plain stores and a
+ *             small second kernel (k_lists_reduce) sums the tiles into d_r; no
+ *             atomics (a device-scope atomic is a 32-byte memory-side write)
  *   d_r     : uint32 [T][G], += like scoary_permute */
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T);
 int64_t scoary_list_tile_words(int64_t N);   /* dwords per (trait, tile) */

@@ -490,45 +490,42 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
                                                         const int32_t* __restrict__ lstart,
                                                         const int32_t* __restrict__ lngroups,
                                                         const uint2* __restrict__ lcrit, int G,
-                                                        int N, int64_t P, int T, int ntiles,
-                                                        int parts, int tiles_per_block,
+                                                        int N, int64_t P, int ntiles,
                                                         int groups_per_block, int64_t lidx_bytes,
-                                                        uint32_t* __restrict__ partial) {
+                                                        uint16_t* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
   scoary_bank_defs();                // assembler symbols for the operand-ordering .if blocks
   constexpr int TW = NW * LPG;       // tile row, dwords
   static_assert(NW == 4 || ((NW == 2 || NW == 1) && LPG == 1), "narrow rows: one lane per gene");
   constexpr int GPW = kWave / LPG;   // genes per wavefront
-  // A block owns one trait, a contiguous range of its label tiles (a "part") and a chunk
-  // of wave groups: it walks the tiles one after the other and keeps the exceedance
-  // counts of its genes in ONE register across them -- group kk of a wavefront lives in
-  // lane (kk mod LPG) of every gene's lane group, 16 bits for kk < LPG and the upper 16
-  // for LPG <= kk < 2*LPG -- so every (part, trait, gene) count is written exactly once,
-  // with a plain store (no atomics: one per (gene, tile) before, 316 MB of write traffic
-  // for a 2 MB result at the headline config).
-  const int t = blockIdx.x / parts, part = blockIdx.x % parts;
-  const int tile_lo = part * tiles_per_block, tile_hi = min(ntiles, tile_lo + tiles_per_block);
+  // A block = one label tile (trait, 32*TW permutations) in LDS x one chunk of wave groups.
+  // blockIdx.x (trait, tile) runs fastest, so the ~num_cu blocks in flight walk the SAME
+  // chunk of index lists against different tiles: a list byte comes from HBM once and
+  // from L2 for everyone else.  (Round 2 built the alternative -- a block walking several
+  // tiles and keeping its counts in a register, one store per (gene, trait): the lists are
+  // then re-streamed once per tile by blocks that no longer share them, -4 % at the
+  // headline config and -15 % on rare variants; profiles/r02_ab_tileloop.txt.)
+  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: loops over groups stay scalar
   const int col = lane % LPG;
   const int ngroups = (G + GPW - 1) / GPW;         // wave groups of GPW genes
   const int q_lo = blockIdx.y * groups_per_block;
   const int q_hi = min(ngroups, q_lo + groups_per_block);
-  uint32_t acc = 0u;
   const uint32_t lane_off = (uint32_t)lane * 16u;   // 16-byte vectors: tile loads and index loads
+  // per-(trait, tile) exceedance counts of every list slot: plain 16-bit stores, summed
+  // over the tiles by k_lists_reduce (one device-scope atomicAdd per (gene, tile) cost a
+  // 32-byte memory-side write each: 316 MB for a 2 MB result at the headline config)
+  uint16_t* out = partial + (int64_t)blockIdx.x * ((int64_t)ngroups * GPW);
 
-  for (int tile = tile_lo; tile < tile_hi; ++tile) {
-  const uint32_t* src = tiles + (int64_t)(t * ntiles + tile) * list_tile_dwords(N, TW);
-  if (tile != tile_lo) __syncthreads();            // every wavefront is done with the previous tile
+  const uint32_t* src = tiles + (int64_t)blockIdx.x * list_tile_dwords(N, TW);
   {
     // tile -> LDS by LDS-DMA (global_load_lds_dwordx4): a wavefront moves 64 x 16 B
-    // per instruction straight into LDS (destination = wave-uniform base + 16*lane),
-    // no VGPR round trip and no ds_write pass
+    // per instruction straight into LDS (destination = M0 + 16*lane), no VGPR round trip
+    // and no ds_write pass.  Address = wave-uniform base (SGPR pair) + 32-bit lane offset:
+    // the saddr form (inline asm: the builtin only takes a per-lane 64-bit address).
     const uint4* src4 = reinterpret_cast<const uint4*>(src);
     const int n4 = (int)(list_tile_dwords(N, TW) / 4);   // HBM tiles are padded to 16 bytes
-    // address = wave-uniform base (SGPR pair) + zero-extended 32-bit lane offset: the
-    // saddr form of the load, no 64-bit per-lane address held across the kernel
-    // (inline asm: the builtin only takes a per-lane 64-bit address; M0 = LDS destination)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds;
     for (int i = wave * kWave; i < n4; i += nwaves * kWave)
       if (i + lane < n4)
@@ -542,8 +539,8 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
 
   // LPG == 1: an entry is used as the LDS address as it is -- the tile is the kernel's only
   // LDS object and sits at LDS address 0 (checked on the host: no static LDS in this kernel)
-  int kk = 0;                                      // this wavefront's kk-th group of the chunk
-  for (int q = q_lo + wave; q < q_hi; q += nwaves, ++kk) {
+  {
+  for (int q = q_lo + wave; q < q_hi; q += nwaves) {
     const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);   // 32-entry steps
     // interleaved lists (piece = TW entries): the wavefront's 64 lanes read 64
     // consecutive 16-byte index vectors per piece
@@ -686,27 +683,22 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     if (!have) cnt = 0;
 #pragma unroll
     for (int off = LPG / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if (col == (kk & (LPG - 1))) acc += (uint32_t)cnt << (kk >= LPG ? 16 : 0);
+    if (col == 0) out[(int64_t)q * GPW + lg] = (uint16_t)cnt;      // cnt <= 32*TW <= 512
   }
-  }  // tiles of this block
-  const int64_t gs = (int64_t)ngroups * GPW;        // slots, padded to whole wave groups
-  uint32_t* out = partial + ((int64_t)part * T + t) * gs;
-  int kk = 0;
-  for (int q = q_lo + wave; q < q_hi; q += nwaves, ++kk)
-    if (col == (kk & (LPG - 1)))
-      out[(int64_t)q * GPW + fresh_lane() / LPG] = kk >= LPG ? acc >> 16 : acc & 0xffffu;
+  }
 }
 
-// r[t][gene of slot k] += sum over the parts of partial[part][t][k]
-__global__ __launch_bounds__(256) void k_lists_reduce(const uint32_t* __restrict__ partial,
-                                                      int parts, int T, int64_t gs, int G,
+// r[t][gene of slot k] += sum over the tiles of partial[t][tile][k]
+__global__ __launch_bounds__(256) void k_lists_reduce(const uint16_t* __restrict__ partial,
+                                                      int ntiles, int64_t gs, int G,
                                                       const int32_t* __restrict__ order,
                                                       uint32_t* __restrict__ r) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int t = blockIdx.y;
   if (k >= G) return;
+  const uint16_t* in = partial + (int64_t)t * ntiles * gs + k;
   uint32_t sum = 0u;
-  for (int p = 0; p < parts; ++p) sum += partial[((int64_t)p * T + t) * gs + k];
+  for (int tile = 0; tile < ntiles; ++tile) sum += in[(int64_t)tile * gs];
   r[(int64_t)t * G + order[k]] += sum;
 }
 
@@ -780,48 +772,28 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
 }
 
 extern "C++" {
-// Launch geometry of k_permute_lists (also sizes the scratch): wave groups per block,
-// gene chunks, tile parts per trait, tiles per block.
+// Launch geometry of k_permute_lists (also sizes the scratch)
 struct ListGeom {
-  int64_t ntiles, ngroups, gs, gpb, chunks, parts, tpb, parts_cap;
+  int64_t ntiles, ngroups, gs, gpb, chunks;
 };
 static ListGeom list_geom(int num_cu, int64_t G, int64_t T, int64_t N, int64_t P, int64_t entries) {
   ListGeom g{};
-  const int TW = list_tw(N), LPG = list_lpg(TW), GPW = kWave / LPG;
+  const int TW = list_tw(N), GPW = kWave / list_lpg(TW);
   const int64_t tile_perms = TW * 32;
   g.ntiles = (P + tile_perms - 1) / tile_perms;
   g.ngroups = (G + GPW - 1) / GPW;
   g.gs = g.ngroups * GPW;
-  // one accumulator register holds 2*LPG groups per wavefront (16-bit halves x LPG lanes),
-  // and a 16-bit count holds 65535 permutations
-  const int64_t gpb_cap = 16 * 2 * LPG;
-  const int64_t tpb_cap = 65535 / tile_perms;
-  const int64_t min_parts = (g.ntiles + tpb_cap - 1) / tpb_cap;
-  g.parts_cap = min_parts > 3 ? min_parts : 3;      // <= 3 partial results + r: write traffic <= 4x the result
-  int64_t parts_max = g.ntiles < g.parts_cap ? g.ntiles : g.parts_cap;
-  if (parts_max < 1) parts_max = 1;
-  static const int64_t target_rounds = getenv("SCOARY_LISTS_ROUNDS") ? atoll(getenv("SCOARY_LISTS_ROUNDS")) : 6;
-  const int64_t target_blocks = (int64_t)num_cu * target_rounds;
-  // chunks: the accumulator capacity, index lists of a chunk <= ~2 MB (they stay in an
-  // XCD's 4 MB L2 while the (trait, part) blocks of the chunk walk them tile after tile),
-  // and enough blocks to fill the CUs a few times over; at least one group per wavefront
-  int64_t chunks = (g.ngroups + gpb_cap - 1) / gpb_cap;
+  // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index lists
+  // (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the chunk run;
+  // each chunk a multiple of 16 wave groups (one per wavefront)
+  int64_t chunks = ((int64_t)num_cu * 16 + g.ntiles * T - 1) / (g.ntiles * T);
   const int64_t by_l2 = (entries * 4 + (2 << 20) - 1) / (2 << 20);
   if (chunks < by_l2) chunks = by_l2;
-  const int64_t by_blocks = (target_blocks + T * parts_max - 1) / (T * parts_max);
-  if (chunks < by_blocks) chunks = by_blocks;
   if (chunks > 65535) chunks = 65535;
   if (chunks < 1) chunks = 1;
   g.gpb = (g.ngroups + chunks - 1) / chunks;
   g.gpb = (g.gpb + 15) / 16 * 16;
-  if (g.gpb > gpb_cap) g.gpb = gpb_cap;
   g.chunks = (g.ngroups + g.gpb - 1) / g.gpb;
-  int64_t parts = (target_blocks + T * g.chunks - 1) / (T * g.chunks);
-  if (parts > parts_max) parts = parts_max;
-  if (parts < min_parts) parts = min_parts;
-  if (parts < 1) parts = 1;
-  g.tpb = (g.ntiles + parts - 1) / parts;
-  g.parts = (g.ntiles + g.tpb - 1) / g.tpb;
   return g;
 }
 
@@ -833,7 +805,7 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
                                 const int32_t* d_margins, uint32_t* d_scratch, int64_t G, int64_t T,
                                 int64_t N, int64_t P, uint32_t* d_r) {
   uint32_t* d_lcrit = d_scratch;                       // [T][G][2]
-  uint32_t* d_partial = d_scratch + 2 * T * G;         // [parts][T][gs]
+  uint16_t* d_partial = reinterpret_cast<uint16_t*>(d_scratch + 2 * T * G);   // [T][ntiles][gs]
   {
     KernelTimer kt(h, s, "k_lists_crit");
     hipLaunchKernelGGL(k_lists_crit, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
@@ -841,7 +813,7 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
                        (int)G, KD, reinterpret_cast<uint2*>(d_lcrit));
   }
   const ListGeom g = list_geom(h->num_cu, G, T, N, P, entries);
-  if (T * g.parts > 0x7fffffffLL || g.chunks > 65535)
+  if (T * g.ntiles > 0x7fffffffLL || g.chunks > 65535)
     return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: grid too large");
   const size_t lds = (size_t)list_tile_dwords(N, TW) * sizeof(uint32_t);
   const void* fn = reinterpret_cast<const void*>(&k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>);
@@ -859,15 +831,15 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   {
     KernelTimer kt(h, s, "k_permute_lists");
     hipLaunchKernelGGL((k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>),
-                       dim3((unsigned)(T * g.parts), (unsigned)g.chunks), dim3(1024), lds, s, d_tiles,
+                       dim3((unsigned)(T * g.ntiles), (unsigned)g.chunks), dim3(1024), lds, s, d_tiles,
                        d_lidx, d_lstart, d_lngroups, reinterpret_cast<const uint2*>(d_lcrit), (int)G,
-                       (int)N, P, (int)T, (int)g.ntiles, (int)g.parts, (int)g.tpb, (int)g.gpb,
+                       (int)N, P, (int)g.ntiles, (int)g.gpb,
                        (entries + kListSlack) * (int64_t)sizeof(uint32_t), d_partial);
   }
   {
     KernelTimer kt(h, s, "k_lists_reduce");
     hipLaunchKernelGGL(k_lists_reduce, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
-                       d_partial, (int)g.parts, (int)T, g.gs, (int)G, d_lorder, d_r);
+                       d_partial, (int)g.ntiles, g.gs, (int)G, d_lorder, d_r);
   }
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
@@ -877,7 +849,7 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
 int64_t scoary_permute_lists_scratch_bytes(int64_t G, int64_t T, int64_t N, int64_t P) {
   if (G < 1 || T < 1 || N < 1 || P < 1 || !list_tw(N)) return 0;
   const ListGeom g = list_geom(256, G, T, N, P, 0);
-  return (2 * T * G + g.parts_cap * T * g.gs) * (int64_t)sizeof(uint32_t);
+  return 2 * T * G * (int64_t)sizeof(uint32_t) + (T * g.ntiles * g.gs * (int64_t)sizeof(uint16_t) + 3) / 4 * 4;
 }
 
 int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_t* d_lidx,
