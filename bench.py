@@ -5,22 +5,30 @@ One "step" = one pass of the whole hot path over the headline synthetic batch
 (BASELINE.json configs[2]: 50k genes x 2000 isolates x 10 traits, 10k label
 permutations): contingency counts -> Fisher p + rejection regions -> label
 permutation generation -> permutation exceedance counts, inputs resident in
-HBM.  tests per step = G*T*P per GPU.
+HBM.  tests per step = G*T*P.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--scaling weak|strong]
 
-Multi-GPU: genes shard across ranks (every rank holds its own G-gene shard of a
-G*N-gene matrix: weak scaling); trait / permutation vectors are regenerated
-identically on every rank from the seed (no broadcast); the one exchange step
-of the path -- gathering per-gene results on rank 0 -- is an RCCL gather inside
-the timed region (asynchronous, overlapped with the next step's kernels).
+``--gpus N`` with N > 1 runs N ranks by itself (re-executes under
+``torch.distributed.run --nproc-per-node N``) unless it is already running under a
+launcher (WORLD_SIZE set), and refuses to run with fewer than N visible GPUs.
+
+Multi-GPU: genes shard across ranks -- weak scaling: every rank holds its own G-gene
+shard (a G*N-gene matrix); strong scaling: the config's G genes are split into
+contiguous shards (scoary_amd.dist.shard_bounds).  Trait / permutation vectors are
+regenerated identically on every rank from the seed (no broadcast); the one exchange
+step of the path -- gathering per-gene results on rank 0 -- is an RCCL gather inside the
+timed region (asynchronous, overlapped with the next step's kernels), and rank 0
+checks the records it received from every rank.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,24 +38,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-LISTS_DEFAULT = True         # list-driven kernel: 4.9 ms vs 16.1 ms (dense) on the headline config
+LISTS_DEFAULT = True         # list-driven kernel: 4.6 ms vs 16.1 ms (dense) on the headline config
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz (upper bound)
+# nominal integer-VALU peak: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (a wave64 op = 2 cycles)
+VALU_NOMINAL_LANE_OPS = 256 * 4 * 32 * 2.4e9
 # measured issue rates (lane-ops/s, whole chip): the dense kernel's op pair (v_and_b32 with an SGPR
 # operand + v_bcnt_u32_b32 accumulate, tools/valu_peak.hip) and the list kernel's v_bitop3_b32 with
 # VGPR operands in distinct banks (tools/valu_banks.hip: 2.5 cycles per wave-instruction at 8 waves
 # per SIMD, 2.8 at the 4 the list kernel runs with)
 VALU_PEAK_AND_BCNT = 4.1e13
 VALU_PEAK_BITOP3 = 6.2e13
+KERNEL_SOURCES = ("scoary_lists.hip", "scoary_assoc.hip", "scoary_common.hpp",
+                  "scoary_ctr_regs.inc", "scoary_vgpr_banks.inc")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4"])
-    ap.add_argument("--genes", type=int, default=None, help="override G (per GPU)")
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank its own G-gene shard; strong: the config's G genes "
+                         "split across the ranks")
+    ap.add_argument("--genes", type=int, default=None, help="override G (per GPU / total)")
     ap.add_argument("--permutations", type=int, default=None, help="override P")
     ap.add_argument("--isolates", type=int, default=None, help="override N (shape experiments)")
     ap.add_argument("--traits", type=int, default=None, help="override T (shape experiments)")
@@ -57,41 +71,91 @@ def parse():
                          "torch.distributed.run with one rank): a 1-GPU check of the N>1 code path")
     ap.add_argument("--kernel", default="auto", choices=["auto", "dense", "lists"],
                     help="permutation kernel: dense (k_permute_reg/chunked) or list-driven")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0,
-                    help="target CPU time of the cpu_baseline sample")
-    return ap.parse_args()
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step into a hipGraph and replay it (launch-bound configs); "
+                         "per-kernel times then come from extra eager steps after the timed region")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0,
+                    help="target wall time of each cpu_baseline sample")
+    ap.add_argument("--dry-exchange", action="store_true",
+                    help="CPU-only check of the launcher + exchange path (gloo, fabricated "
+                         "records, no kernels): what tests/test_dist_gloo.py drives")
+    return ap.parse_args(argv)
 
 
-def load_traffic(config, default_sizes, kernel="k_permute"):
-    """HBM bytes per k_permute launch from the committed PMC summary
-    (profiles/r*_pmc.json, produced by tools/profile.sh + tools/rocpd_summary.py
-    from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-    command).  None when no summary matches the workload being run."""
+# --------------------------------------------------------------- launcher -----
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def maybe_relaunch(args):
+    """--gpus N > 1 outside a launcher: run N ranks ourselves (one process per GPU)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if not args.dry_exchange:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# ------------------------------------------------------- counters on file -----
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for fn in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "scoary_amd", "csrc", fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def load_counters(config, default_sizes, kernel):
+    """PMC counters of the dominant kernel from the committed rocprofv3 summary
+    (profiles/r*_pmc.json: separate --pmc passes of this same command, tools/profile.sh +
+    tools/rocpd_summary.py).  Only a summary whose _meta.kernel_source_sha256 equals the
+    hash of the kernel sources in this tree is used -- counters of another kernel
+    version are refused, not reported.  Returns (dict | None, reason)."""
     import glob
     if not default_sizes:
-        return None, None, None
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
+        return None, "shape overridden on the command line: no committed PMC profile applies"
+    sha = kernel_source_sha()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
         except (OSError, ValueError):
             continue
-        if d.get("_meta", {}).get("workload") != config:
+        meta = d.get("_meta", {})
+        if meta.get("workload") != config:
             continue
         for k, v in d.items():
-            is_lists = k.startswith("k_permute_lists")
-            if k.startswith("k_permute") and is_lists == (kernel == "k_permute_lists") \
-                    and "hbm_traffic_bytes_per_launch" in v:
-                best = (v["hbm_traffic_bytes_per_launch"], os.path.relpath(path, ROOT),
-                        v.get("SQ_INSTS_VALU"))
-    return best if best else (None, None, None)
+            if k.startswith(kernel) and (kernel != "k_permute" or not k.startswith("k_permute_lists")) \
+                    and isinstance(v, dict) and "SQ_INSTS_VALU" in v:
+                if meta.get("kernel_source_sha256") != sha:
+                    stale = os.path.relpath(path, ROOT)
+                    continue
+                out = dict(v)
+                out["source"] = os.path.relpath(path, ROOT)
+                return out, None
+    if stale:
+        return None, ("%s was collected from other kernel sources (sha256 mismatch): re-run "
+                      "tools/profile.sh" % stale)
+    return None, "no PMC summary for %s / %s under profiles/" % (config, kernel)
 
 
-def cpu_baseline(genes, traits, N, seed, target_s):
-    """Time the CPU oracle (the C restatement, OpenMP over genes) on a bounded
-    sample of the same workload: all T traits, a gene subsample, P_s
-    permutations; whole path (counts + Fisher weights + permutations)."""
+# ------------------------------------------------------------ CPU baselines ---
+def cpu_baseline_port(genes, traits, N, seed, target_s):
+    """The C restatement (oracle/oracle.c, OpenMP over genes) on a bounded sample of the
+    same workload: all T traits, a gene subsample, P_s permutations; whole path."""
     from oracle import oracle as orc
     from scoary_amd.engine import pack_bits_rows
     cores = orc.num_threads()
@@ -111,11 +175,65 @@ def cpu_baseline(genes, traits, N, seed, target_s):
     dt = time.perf_counter() - t0
     return {"value": Gs * T * Ps / dt, "unit": "gene-permutation Fisher tests/s",
             "cores": cores, "kind": "port",
-            "sample": "oracle/oracle.c orc_permute_r (counts + Fisher weights + label "
-                      "permutations + exceedance), %d genes x %d isolates x %d traits x %d "
+            "sample": "oracle/oracle.c orc_permute_r (bit-packed popcount counts + Fisher weights + "
+                      "label permutations + exceedance), %d genes x %d isolates x %d traits x %d "
                       "permutations, %d OpenMP threads, %.1f s" % (Gs, N, T, Ps, cores, dt)}
 
 
+def cpu_baseline_scipy(eng, genes, traits, N, seed, target_s):
+    """The reference-structured CPU path (oracle/scipy_baseline.py: per-isolate Python
+    counting + memoised scipy.stats.fisher_exact over a multiprocessing.Pool of
+    os.cpu_count() stride domains; scoary/methods.py:791-857, :1076-1078) on a gene
+    subsample x trait 0 x 20 permutations, CHECKED against the GPU on the same sample and
+    extrapolated linearly to tests/s."""
+    from oracle import oracle as orc
+    from scoary_amd.engine import pack_bits_rows
+    Ps = 20
+    tr = traits[0]
+    mb = pack_bits_rows((tr != 2).astype(np.uint8)[None])
+    npos = int((tr == 1).sum())
+    labels = np.stack([np.unpackbits(orc.perm_labels(seed, 0, pi, mb[0], npos, N).view(np.uint8),
+                                     bitorder="little")[:N] for pi in range(Ps)])
+    G = genes.shape[0]
+    # candidates: <= 8192 genes spread over the matrix; the baseline process sizes its sample
+    # from them (4-gene probe -> about target_s seconds on all cores).  It runs in a fresh
+    # interpreter: a multiprocessing Pool must not be forked from this process (HIP context,
+    # runtime threads).
+    import tempfile
+    cand = np.unique(np.linspace(0, G - 1, min(G, 8192)).astype(np.int64))
+    with tempfile.TemporaryDirectory() as tmp:
+        fin, fout = os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")
+        np.savez(fin, genes=genes[cand], trait=tr, labels=labels)
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        subprocess.run([sys.executable, "-m", "oracle.scipy_baseline", fin, fout, str(target_s)],
+                       check=True, cwd=ROOT, env=env, timeout=600)
+        d = np.load(fout)
+        sub = cand[d["order"]]
+        counts, p, r, dt, n = d["counts"], d["p"], d["r"], float(d["dt"]), int(d["n"])
+    Gs = len(sub)
+    # the GPU on the same sample, same labels (spec S4, same seed, trait 0)
+    gm = eng.pack_dense(genes[sub])
+    tb = pack_bits_rows((tr == 1).astype(np.uint8)[None])
+    res = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=Ps, seed=seed,
+                        use_lists=False)
+    gc = res["counts"].cpu().numpy()[0]
+    gp = res["p"].cpu().numpy()[0]
+    gr = res["r"].cpu().numpy().view(np.uint32)[0]
+    ok = bool(np.array_equal(gc, counts) and np.array_equal(gr.astype(np.int64), r)
+              and np.max(np.abs(gp - p)) < 1e-12)
+    tests = Gs * (Ps + 1)
+    return {"value": tests / dt, "unit": "gene-permutation Fisher tests/s", "cores": n,
+            "kind": "scipy-restatement", "matches_gpu": ok,
+            "sample": "oracle/scipy_baseline.py: per-isolate Python counting + memoised "
+                      "scipy.stats.fisher_exact, multiprocessing.Pool(%d) over stride domains "
+                      "range(k, G, %d) (reference structure, scoary/methods.py:791-857, :1076-1078); "
+                      "%d genes x %d isolates x trait 0 x (1 + %d permutations) = %d tests in %.2f s "
+                      "(pool start-up excluded), extrapolated linearly; counts / r equal and "
+                      "|dp| < 1e-12 against the GPU on this sample: %s"
+                      % (n, n, Gs, N, Ps, tests, dt, ok)}
+
+
+# ------------------------------------------------------------------ exchange --
 class Exchange:
     """The path's one exchange step: the per-gene records of every shard are
     gathered on rank 0 over RCCL/xGMI (north_star: "only an RCCL gather of
@@ -123,13 +241,16 @@ class Exchange:
     buffers are reused, so step i's gather overlaps step i+1's kernels; every
     gather has completed before the closing barrier of the timed region."""
 
-    def __init__(self, torch, eng, world, rank, T, G):
+    def __init__(self, torch, eng, world, rank, T, G, bounds=None):
         from scoary_amd import dist as sdist
         self.sdist, self.world, self.rank, self.G = sdist, world, rank, G
+        # weak scaling: every rank sends G genes (G*world in all); strong: shard_bounds(G)
+        self.total = G * world if bounds is None else bounds[-1][1]
         self.pending, self.step_no, self.kind = [], 0, "gather"
         self.recv = [None, None]
         if rank == 0:
-            self.recv = [torch.empty((world, T, G, sdist.REC_WORDS), dtype=torch.int32,
+            cap = sdist.max_shard(self.total, world)
+            self.recv = [torch.empty((world, T, cap, sdist.REC_WORDS), dtype=torch.int32,
                                      device=eng.device) for _ in range(2)]
 
     def drain(self, keep=0):
@@ -142,7 +263,7 @@ class Exchange:
         rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
         if self.kind == "gather":
             try:
-                _, finish = sdist.gather_genes(rec, self.G * self.world, dst=0, async_op=True,
+                _, finish = sdist.gather_genes(rec, self.total, dst=0, async_op=True,
                                                recv=self.recv[self.step_no % 2])
                 self.pending.append(finish)
             except (RuntimeError, NotImplementedError) as e:   # backend without gather
@@ -151,8 +272,27 @@ class Exchange:
                           file=sys.stderr)
                 self.kind = "all_gather"
         if self.kind == "all_gather":
-            res["gathered"] = sdist.all_gather_genes(rec, self.G * self.world)
+            res["gathered"] = sdist.all_gather_genes(rec, self.total)
         self.step_no += 1
+
+    def check(self, T, nval):
+        """Rank 0, after the last drain: the receive buffer of the last step holds one
+        block per rank, every record a plausible result of THIS workload -- the four
+        counts of every (trait, gene) add up to the trait's valid isolates (a
+        size-independent property only a real record satisfies).  Returns the number of
+        ranks whose block passed."""
+        if self.rank != 0 or self.kind != "gather":
+            return None
+        sdist = self.sdist
+        last = self.recv[(self.step_no - 1) % 2]
+        bounds = sdist.shard_bounds(self.total, self.world)
+        ok = 0
+        for rk, (a, b) in enumerate(bounds):
+            counts = last[rk, :, :b - a, 0:4].sum(dim=2).cpu().numpy()     # [T, shard]
+            if counts.shape == (T, b - a) and np.array_equal(
+                    counts, np.broadcast_to(np.asarray(nval)[:, None], counts.shape)):
+                ok += 1
+        return ok
 
 
 def measured_copy_peak(device):
@@ -176,107 +316,177 @@ def measured_copy_peak(device):
 
 
 def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
-    """The `roofline` object: operand-bandwidth model, measured HBM
-    traffic and VALU instruction count from the committed PMC passes."""
+    """The `roofline` object.  What binds the permutation kernel is integer-VALU issue,
+    not HBM, so: bound = "valu", achieved = lane-ops/s from the
+    SQ_INSTS_VALU count of the committed PMC pass of THIS kernel version (sha-checked)
+    and the live hipEvent duration, peak = the nominal SIMD peak (frac <= 1 by
+    construction); the measured v_bitop3 ceiling, the SURVEY 8d operand-bandwidth figure
+    and the measured HBM traffic ride along."""
     W64 = (N + 63) // 64
     tests_per_launch = G * T * (P if use_lists else min(P, pbatch))
     launches_per_step = 1 if use_lists else -(-P // pbatch)
-    alg_bytes = 16.0 * W64 * tests_per_launch        # SURVEY 8d: 16*W bytes / test
-    achieved = alg_bytes / (k3_ms * 1e-3) / 1e9
+    operand_bytes = 16.0 * W64 * tests_per_launch        # SURVEY 8d: 16*W bytes / test
     default_sizes = (args.genes is None and args.permutations is None
                      and args.isolates is None and args.traits is None)
-    traffic, traffic_src, valu_insts = load_traffic(args.config, default_sizes, k3_name)
-    w32 = -(-N // 32)
-    valu_ops = tests_per_launch * (2.0 * w32 + 6)     # dense-kernel op model (reference point)
+    ctr, why = load_counters(args.config, default_sizes, k3_name)
+    sec = k3_ms * 1e-3
+    valu = traffic = None
+    if ctr:
+        valu = ctr["SQ_INSTS_VALU"] * 64.0                # lane-ops per launch
+        traffic = ctr.get("hbm_traffic_bytes_per_launch")
     copy_gbs = measured_copy_peak(eng.device)
+    measured_peak = VALU_PEAK_BITOP3 if use_lists else VALU_PEAK_AND_BCNT
     return {
-        "bound": "hbm",
+        "bound": "valu",
         "kernel": k3_name,
-        "achieved": achieved,
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic,
-        "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024",
-        "traffic_source": traffic_src,
-        "traffic_gbs": None if not traffic else traffic / (k3_ms * 1e-3) / 1e9,
-        "measured_copy_peak_gbs": copy_gbs,            # torch D2D copy of 1 GiB, read + write
-        "frac_of_measured_copy": achieved / copy_gbs,
-        "algorithmic_bytes_per_launch": alg_bytes,
-        "model": "operand bytes 16*ceil(N/64) B per test (SURVEY 8d); frac > 1 means the "
-                 "kernel left the HBM-bound regime (operands reused from VGPR/SGPR)",
+        "achieved": None if valu is None else valu / sec / 1e12,
+        "peak": VALU_NOMINAL_LANE_OPS / 1e12,
+        "unit": "T lane-ops/s (SQ_INSTS_VALU x 64 / kernel time; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz)",
+        "frac": None if valu is None else valu / sec / VALU_NOMINAL_LANE_OPS,
+        "frac_of_measured_op_peak": None if valu is None else valu / sec / measured_peak,
+        "measured_op_peak": measured_peak / 1e12,
+        "measured_op_peak_source": "tools/valu_banks.hip (v_bitop3_b32, 8 waves/SIMD)" if use_lists
+                                   else "tools/valu_peak.hip (v_and_b32 + v_bcnt_u32_b32)",
+        "ops_per_test": None if valu is None else valu / tests_per_launch,
+        "counters_source": ctr["source"] if ctr else None,
+        "counters_refused": why,
         "kernel_ms": k3_ms,
         "launches_per_step": launches_per_step,
-        "tests_per_s_kernel": tests_per_launch / (k3_ms * 1e-3),
-        "dense_model_valu_frac_of_2.4GHz_simd32_peak":
-            None if use_lists else valu_ops / (k3_ms * 1e-3) / VALU_LANE_OPS_PER_S,
-        # what actually binds: VALU instruction issue (SURVEY 8d, figure iii).  Instruction
-        # count from the committed SQ_INSTS_VALU pass, duration measured live; the ceiling
-        # is the measured chip-wide issue rate of the kernel's own op (see the constants).
-        "valu": None if not valu_insts else {
-            "wave_insts_per_launch": valu_insts,
-            "ops_per_test": valu_insts * 64.0 / tests_per_launch,
-            "lane_ops_per_s": valu_insts * 64.0 / (k3_ms * 1e-3),
-            "peak_lane_ops_per_s": VALU_PEAK_BITOP3 if use_lists else VALU_PEAK_AND_BCNT,
-            "peak_source": "tools/valu_banks.hip (v_bitop3_b32, 8 waves/SIMD)" if use_lists
-                           else "tools/valu_peak.hip (v_and_b32 + v_bcnt_u32_b32)",
-            "frac": valu_insts * 64.0 / (k3_ms * 1e-3)
-                    / (VALU_PEAK_BITOP3 if use_lists else VALU_PEAK_AND_BCNT),
-            "source": traffic_src,
-            "clock_note": "the list kernel runs at the socket power cap: 1.37 kW, shader clock "
-                          "2.15 of 2.4 GHz (profiles/r01_clock_power.txt)" if use_lists else None},
+        "tests_per_s_kernel": tests_per_launch / sec,
+        # HBM side: measured traffic (PMC, gfx950-corrected) against the 8 TB/s peak
+        "traffic": traffic,
+        "traffic_unit": "bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024",
+        "write_bytes": None if not ctr else ctr.get("WRITE_SIZE_bytes"),
+        "hbm_frac": None if not traffic else traffic / sec / 1e9 / HBM_PEAK_GBS,
+        "hbm_peak_gbs": HBM_PEAK_GBS,
+        "measured_copy_peak_gbs": copy_gbs,
+        # SURVEY 8d figure (i): operand bandwidth, 16*ceil(N/64) B per test -- > 1 means the
+        # operands are reused on chip (the kernel left the HBM-bound regime)
+        "operand_bw_gbs": operand_bytes / sec / 1e9,
+        "operand_bw_frac": operand_bytes / sec / 1e9 / HBM_PEAK_GBS,
+        "operand_bytes_per_launch": operand_bytes,
+        "clock_note": "the list kernel runs at the socket power cap: ~1.37 kW, shader clock ~2.15 of "
+                      "2.4 GHz (profiles/r01_clock_power.txt)" if use_lists else None,
     }
+
+
+def dry_exchange(args, world, rank):
+    """CPU-only: the launcher, process group, Exchange pipeline and rank-0 check with
+    fabricated records (gloo)."""
+    import types
+    import torch
+    import torch.distributed as dist
+    from scoary_amd import dist as sdist
+    sdist.init_from_env()
+    T, G, nval = 2, 7, [11, 13]
+    bounds = sdist.shard_bounds(G, world) if args.scaling == "strong" else None
+    Gs = G if bounds is None else bounds[rank][1] - bounds[rank][0]
+    ex = Exchange(torch, types.SimpleNamespace(device="cpu"), world, rank, T, G, bounds=bounds)
+    for step in range(args.steps):
+        counts = torch.zeros((T, Gs, 4), dtype=torch.int32)
+        for t in range(T):
+            counts[t, :, 0] = nval[t] - 3
+            counts[t, :, 1] = 1 + (rank + step) % 2
+            counts[t, :, 2] = 2 - (rank + step) % 2
+        ex.submit({"counts": counts, "p": torch.full((T, Gs), 0.5, dtype=torch.float64),
+                   "odds": torch.ones((T, Gs), dtype=torch.float64),
+                   "r": torch.full((T, Gs), rank, dtype=torch.int32)})
+    ex.drain()
+    dist.barrier()
+    ok = ex.check(T, nval)
+    if rank == 0:
+        print(json.dumps({"dry_exchange": True, "n_gpus": world, "rccl_ranks": ok,
+                          "scaling": args.scaling, "exchange": ex.kind, "steps": args.steps}))
+        if ok != world:
+            raise SystemExit("dry exchange: only %s of %d ranks delivered valid records" % (ok, world))
+    dist.destroy_process_group()
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
+    maybe_relaunch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_exchange:
+        return dry_exchange(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
+
     sharded = world > 1 or (args.exercise_exchange and "RANK" in os.environ)
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if sharded:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from scoary_amd import synth
+    from scoary_amd import dist as sdist
     from scoary_amd.engine import AssociationEngine, pack_bits_rows
 
-    # every rank: its own gene shard (different seed offset), same traits
-    genes, traits, P, seed = synth.make_config(args.config, G=args.genes, N=args.isolates,
-                                               T=args.traits)
-    if rank > 0:
+    c = synth.CONFIGS[args.config]
+    G_cfg = args.genes or (c["G"] // 8 if args.config == "cfg5" else c["G"])   # cfg5: the per-GPU shard
+    bounds = None
+    genes, traits, P, seed = synth.make_config(args.config, G=G_cfg, N=args.isolates, T=args.traits)
+    if args.scaling == "strong" and world > 1:
+        # the config's genes, split: every rank generates the same matrix and keeps its rows
+        bounds = sdist.shard_bounds(G_cfg, world)
+        a, b = bounds[rank]
+        genes = np.ascontiguousarray(genes[a:b])
+    elif rank > 0:
+        # weak: every rank its own G-gene shard (different seed offset), same traits
         rng = np.random.default_rng(seed + 1000 * rank)
         genes = synth.make_genes(genes.shape[0], genes.shape[1], rng,
                                  kind="rare" if args.config == "cfg4" else "uniform",
-                                 core_frac=0.05 if args.config == "cfg3" else 0.0)
+                                 core_frac=0.05 if args.config in ("cfg3", "cfg5") else 0.0)
     if args.permutations:
         P = args.permutations
     G, N = genes.shape
     T = traits.shape[0]
+    G_total = G_cfg if bounds is not None else G * world
 
     eng = AssociationEngine(local_rank)
-    gm = eng.pack_dense(genes)                     # bit-packed once into HBM
-    trv = eng.vecrows(pack_bits_rows((traits == 1).astype(np.uint8)), N)
-    mkv = eng.vecrows(pack_bits_rows((traits != 2).astype(np.uint8)), N)
-    use_lists = args.kernel == "lists" or (args.kernel == "auto" and LISTS_DEFAULT
-                                           and eng.lists_supported(N))
-    if use_lists:
-        eng.build_lists(gm)    # once per dataset, like the packing
+    rows64 = pack_bits_rows(genes)                 # host packing: excluded like file parsing
+    tbits = pack_bits_rows((traits == 1).astype(np.uint8))
+    mbits = pack_bits_rows((traits != 2).astype(np.uint8))
+    torch.cuda.synchronize()
+
+    def setup():
+        gm_ = eng.tile_rows(rows64, N)             # H2D of the packed bits + device tiling
+        trv_, mkv_ = eng.vecrows(tbits, N), eng.vecrows(mbits, N)
+        ul = args.kernel == "lists" or (args.kernel == "auto" and LISTS_DEFAULT
+                                        and eng.lists_supported(N))
+        if ul:
+            eng.build_lists(gm_)                   # on the device, from the tiled matrix
+        torch.cuda.synchronize()
+        return gm_, trv_, mkv_, ul
+    setup()                                        # first call pays module loads; time the second
+    t0 = time.perf_counter()
+    gm, trv, mkv, use_lists = setup()
+    setup_ms = (time.perf_counter() - t0) * 1e3
+
     pbatch = eng.perm_batch(T, N, P)
-    perm_buf = torch.empty((T, pbatch, eng.row_words(N)), dtype=torch.int32, device=eng.device)
-    exchange = Exchange(torch, eng, world, rank, T, G) if sharded else None
+    ws = eng.workspace(gm, T, P, use_lists=use_lists)
+    exchange = Exchange(torch, eng, world, rank, T, G, bounds=bounds) if sharded else None
+    graph = graph_res = None
+    if args.graph:
+        graph, graph_res = eng.capture(gm, trv, mkv, P, seed, ws, use_lists=use_lists)
 
     def step():
-        res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, perm_buffer=perm_buf,
-                            use_lists=use_lists)
+        if graph is not None:
+            graph.launch()
+            res = graph_res
+        else:
+            res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=use_lists,
+                                workspace=ws)
         if exchange:
             exchange.submit(res)
         return res
@@ -290,16 +500,27 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    eng.set_timing(True)
+    if graph is None:
+        eng.set_timing(True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         step()
+        ev[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else None
+    if graph is not None:                           # per-kernel times: a few eager steps afterwards
+        eng.set_timing(True)
+        for _ in range(5):
+            eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=use_lists, workspace=ws)
+        torch.cuda.synchronize()
     k3_name = "k_permute_lists" if use_lists else "k_permute"
     k3_ms = eng.kernel_ms(k3_name)
     names = ("k_margins", "k_counts", "k_fisher") + (
-        ("k_perm_generate_tiles", "k_lists_crit", "k_permute_lists") if use_lists else
+        ("k_perm_generate_tiles", "k_lists_crit", "k_permute_lists", "k_lists_reduce") if use_lists else
         ("k_perm_generate", "k_permute"))
     kernel_ms = {k: eng.kernel_ms(k) for k in names}
     eng.set_timing(False)
@@ -308,33 +529,52 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    nval = (traits != 2).sum(1)
+    rccl_ranks = exchange.check(T, nval) if exchange else None
+    if exchange and rank == 0 and exchange.kind == "gather" and rccl_ranks != world:
+        raise SystemExit("bench.py: rank 0 received valid records from %s of %d ranks" % (rccl_ranks, world))
 
     if rank == 0:
+        tests_per_step = G_total * T * P
         out = {
             "metric": "gene x permutation Fisher tests/sec",
-            "value": G * T * P * world * args.steps / dt,
+            "value": tests_per_step * args.steps / dt,
             "unit": "tests/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_median": median_ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "u32 bit-words (bit-sliced adders / AND + popcount), f64 for Fisher p",
             "data": "synthetic",
-            "config": {"workload": "%s: %d genes x %d isolates x %d traits, --permute %d per GPU; "
+            "config": {"workload": "%s: %d genes x %d isolates x %d traits, --permute %d %s; "
                                    "counts + Fisher + label permutations + exceedance counts"
-                                   % (args.config, G, N, T, P),
-                       "genes_per_gpu": G, "isolates": N, "traits": T, "permutations": P,
-                       "parallelism": "gene-shard x%d" % world,
+                                   % (args.config, G_total if bounds is not None else G, N, T, P,
+                                      "in all (split across the GPUs)" if bounds is not None else "per GPU"),
+                       "genes_per_gpu": G, "genes_total": G_total, "isolates": N, "traits": T,
+                       "permutations": P, "parallelism": "gene-shard x%d" % world,
+                       "hip_graph": bool(graph),
                        "exchange": ("rccl %s of per-gene records" % exchange.kind) if exchange
                        else "none (single GPU)"},
+            "rccl_ranks": rccl_ranks,
+            # once per data set, outside the timed region: H2D of the packed bits + device tiling +
+            # device list build + trait vectors (host bit-packing and parsing excluded)
+            "setup_ms": setup_ms,
+            "value_incl_setup": tests_per_step * args.steps / (dt + setup_ms * 1e-3),
+            "value_single_step_incl_setup": tests_per_step / (dt / args.steps + setup_ms * 1e-3),
             "roofline": roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms),
             "kernel_ms": kernel_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(genes, traits, N, seed, args.cpu_seconds)
+            try:
+                out["cpu_baseline"] = cpu_baseline_scipy(eng, genes, traits, N, seed, args.cpu_seconds)
+            except Exception as e:                        # the GPU line must not die with the CPU leg
+                out["cpu_baseline"] = {"value": None, "kind": "scipy-restatement",
+                                       "error": "%s: %s" % (type(e).__name__, e)}
+            out["cpu_baseline_port"] = cpu_baseline_port(genes, traits, N, seed, args.cpu_seconds)
         print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()

@@ -199,3 +199,36 @@ def test_bench_exchange_pipeline_gloo():
     assert kind == "gather"
     assert counts == [4000, 4100] and r == [4007, 4107] and pv == [4000.0, 4100.0]
     assert got[1] is None
+
+
+def test_bench_launcher_runs_its_own_ranks_gloo():
+    """`python bench.py --gpus 2` outside a launcher re-executes itself under
+    torch.distributed.run with two ranks.  --dry-exchange keeps it on
+    CPU: gloo process group, the bench Exchange pipeline with fabricated records, and
+    rank 0's check that a valid block arrived from every rank -- weak and strong."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for scaling in ("weak", "strong"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                              "--dry-exchange", "--steps", "3", "--scaling", scaling],
+                             capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == scaling
+        assert d["exchange"] == "gather"
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """--gpus N with fewer than N devices must fail loudly, not run one rank and report
+    n_gpus: 1 (what round 1 did)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert "--gpus 64" in out.stderr and "visible" in out.stderr

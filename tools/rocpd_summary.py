@@ -64,7 +64,15 @@ def main():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_traffic_bytes_per_launch"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
             v["hbm_traffic_bytes_per_launch_raw"] = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+            v["WRITE_SIZE_bytes"] = v["WRITE_SIZE"] * 1024
+            v["FETCH_SIZE_bytes_corrected"] = 2 * v["FETCH_SIZE"] * 1024
+    sha = None
+    sha_path = os.path.join(src, "kernel_source_sha256.txt")
+    if os.path.exists(sha_path):
+        sha = open(sha_path).read().strip()
     pmc["_meta"] = {"workload": sys.argv[3] if len(sys.argv) > 3 else "cfg3",
+                    # sha256 over scoary_amd/csrc/{bench.KERNEL_SOURCES} at profile time
+                    "kernel_source_sha256": sha,
                     "source": "tools/profile.sh -> rocprofv3 --pmc (separate passes)",
                     "traffic_formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch"}
     with open(prefix + "_pmc.json", "w") as f:
