@@ -54,27 +54,24 @@ __device__ __forceinline__ uint32_t bit_majn(uint32_t a, uint32_t b, uint32_t c)
   asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x8e" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
-// Bit-sliced rejection-region test (spec S5) on KC counter planes: bit j of the
-// result = ((count_j - base) mod 2^KD) < span.  Three LUT ops per plane.
-template <int KC, int KD>
-__device__ __forceinline__ uint32_t region_lt(const uint32_t (&c)[16], uint32_t base,
-                                              uint32_t span) {
-  uint32_t borrow = 0u, lt = 0u;   // d = u - base ; lt = (d < span)
+// Bit-sliced compare of the KC counter planes against a per-lane constant: bit j of the
+// result = (count_j < thr), the borrow of count - thr -- one LUT op per plane.  thr may use
+// KC+1 bits (the counts themselves stay below 2^KC: plane KC of the count is zero).
+template <int KC>
+__device__ __forceinline__ uint32_t count_lt(const uint32_t (&c)[16], uint32_t thr) {
+  uint32_t borrow = 0u;
 #pragma unroll
-  for (int k = 0; k < KD; ++k) {
-    const uint32_t bk = (uint32_t)__builtin_amdgcn_sbfe((int)base, k, 1);   // 0 / ~0
-    const uint32_t sk = (uint32_t)__builtin_amdgcn_sbfe((int)span, k, 1);
-    uint32_t dk;
-    if (k < KC) {
-      dk = bit_xor3(c[k], bk, borrow);
-      borrow = bit_majn(c[k], bk, borrow);
-    } else {
-      dk = bk ^ borrow;
-      borrow |= bk;
-    }
-    lt = bit_majn(dk, sk, lt);
-  }
-  return lt;
+  for (int k = 0; k < KC; ++k)
+    borrow = bit_majn(c[k], (uint32_t)__builtin_amdgcn_sbfe((int)thr, k, 1), borrow);   // 0 / ~0 masks
+  return borrow | (uint32_t)__builtin_amdgcn_sbfe((int)thr, KC, 1);
+}
+// Rejection-region test (spec S5) in terms of the LIST count u: the acceptance set is an
+// interval [lo, hi1) of u (k_lists_crit), so a permutation is in the region iff
+// u < lo or u >= hi1 -- two compare chains, 2 ops per plane (the modular form
+// ((u - base) mod M) >= span this replaces took three).
+template <int KC>
+__device__ __forceinline__ uint32_t region_bits(const uint32_t (&c)[16], uint32_t lo, uint32_t hi1) {
+  return count_lt<KC>(c, lo) | ~count_lt<KC>(c, hi1);
 }
 // Counter plane K of permutation word W, pinned to one physical VGPR
 // (scoary_ctr_regs.inc) whose bank is never the bank of a row word W: the full
@@ -385,29 +382,31 @@ __global__ __launch_bounds__(kWave * 4) void k_perm_generate_tiles_wg4(
   }
 }
 
-// Per (trait, list slot): the rejection region in terms of the LIST count u
-// (u = a for a ones-list, npos - a for a zeros-list), modulo M = 2^KD:
-//   in region  <=>  always | ((((u - base) mod M) >= span) ^ invert)
-// out[t][slot] = { base, span | invert << 30 | always << 31 }.
+// Per (trait, list slot): the ACCEPTANCE interval of the two-sided test in terms of the
+// LIST count u (u = a for a ones-list, npos - a for a zeros-list), as [lo, hi1):
+//   crit = (base, span): accept a in [base, base + span)          (k_fisher; span 0 = reject all)
+//   ones-list : u in [base, base + span)
+//   zeros-list: u in [npos - base - span + 1, npos - base + 1)
+// 0 <= lo <= hi1 <= npos + 1 <= N + 1 < 2^(KC+1).  span 0 gives lo = hi1 = 0: u >= 0 always,
+// every permutation is in the region (r = P, spec S5).
 __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ crit,
                                                     const int32_t* __restrict__ margins,
                                                     const int32_t* __restrict__ order,
                                                     const uint8_t* __restrict__ flipped, int G,
-                                                    int KD, uint2* __restrict__ out) {
+                                                    uint2* __restrict__ out) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int t = blockIdx.y;
   if (k >= G) return;
   const int g = order[k];
   const uint2 c = crit[(int64_t)t * G + g];
-  const uint32_t M = 1u << KD;
   uint2 o;
   if (c.y == 0u) {
-    o = make_uint2(0u, 1u << 31);
+    o = make_uint2(0u, 0u);
   } else if (!flipped[g]) {
-    o = make_uint2(c.x & (M - 1), c.y);
+    o = make_uint2(c.x, c.x + c.y);
   } else {
     const uint32_t npos = (uint32_t)margins[2 * t];
-    o = make_uint2((npos - c.x + 1u) & (M - 1), (M - c.y) | (1u << 30));
+    o = make_uint2(npos - c.x - c.y + 1u, npos - c.x + 1u);
   }
   out[(int64_t)t * G + k] = o;
 }
@@ -484,7 +483,7 @@ struct Carry4 { uint32_t w[4]; };
 // wavefront, NW permutation words per lane (4; 2 / 1 for the 2- / 1-dword rows of
 // N > 10239 / 20479, one lane per gene).  Lists are walked in sub-steps of 4 entries: lane j of a gene
 // group holds entries 4j..4j+3 of each 4*LPG-entry piece.
-template <int LPG, int NW, int KC, int KD>
+template <int LPG, int NW, int KC>
 __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
                                                         const uint32_t* __restrict__ lidx,
                                                         const int32_t* __restrict__ lstart,
@@ -614,8 +613,14 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     }                                                                        \
     return s4(MINE);                                                         \
   }()
-    for (int sg = 0; sg < nsuper; sg += 4) {
-      const Carry4 zero = {{0u, 0u, 0u, 0u}};
+    // Carries are kept pending level by level (weights 4, 8, ..., 64 inside a region of four
+    // steps) and only the top one ripples through the upper planes.  kDeep: one more pending
+    // level -- regions of eight steps, the two weight-128 carries meet in plane 7 and the
+    // ripple starts at plane 8 -- where the four extra VGPRs are available.
+    constexpr bool kDeep = LPG == 4;
+    constexpr int kRegion = kDeep ? 8 : 4;
+    const Carry4 zero = {{0u, 0u, 0u, 0u}};
+    for (int sg = 0; sg < nsuper; sg += kRegion) {
 #define STEP(K)                                   /* 32 listed isolates */ \
   [&]() -> Carry4 {                                                         \
     if (sg + (K) >= nsuper) return zero;                                    \
@@ -635,13 +640,21 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const Carry4 e1 = FA4(3, d2, d3);                                       \
     return FA4(4, e0, e1);                       /* weight 32 */            \
   }()
-      const Carry4 f0 = STEP(0), f1 = STEP(1);
-      const Carry4 g0 = FA4(5, f0, f1);
-      const Carry4 f2 = STEP(2), f3 = STEP(3);
-      const Carry4 g1 = FA4(5, f2, f3);
-      Carry4 carry = FA4(6, g0, g1);
+#define QUAD(K0)                                  /* four steps -> carry of weight 128 */ \
+  [&]() -> Carry4 {                                                         \
+    const Carry4 f0 = STEP(K0), f1 = STEP((K0) + 1);                        \
+    const Carry4 g0 = FA4(5, f0, f1);                                       \
+    const Carry4 f2 = STEP((K0) + 2), f3 = STEP((K0) + 3);                  \
+    const Carry4 g1 = FA4(5, f2, f3);                                       \
+    return FA4(6, g0, g1);                                                  \
+  }()
+      Carry4 carry = QUAD(0);
+      if constexpr (kDeep) {
+        const Carry4 h1 = sg + 4 < nsuper ? QUAD(4) : zero;
+        carry = FA4(7, carry, h1);
+      }
 #define RIPPLE(K)                                                       \
-  if constexpr (K < KC) {                                               \
+  if constexpr (K < KC && K >= (kDeep ? 8 : 7)) {                       \
     Carry4 nc = {{c0[K] & carry.w[0], c1[K] & carry.w[1], c2[K] & carry.w[2], c3[K] & carry.w[3]}}; \
     Ctr<0, K>::xor2(c0[K], carry.w[0]);                                 \
     if constexpr (NW > 1) Ctr<1, K>::xor2(c1[K], carry.w[1]);           \
@@ -654,6 +667,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
       RIPPLE(7) RIPPLE(8) RIPPLE(9) RIPPLE(10) RIPPLE(11) RIPPLE(12) RIPPLE(13) RIPPLE(14)
 #undef RIPPLE
     }
+#undef QUAD
 #undef STEP
 #undef SUBSTEP
 #undef FA4
@@ -663,9 +677,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const int slot = min(q * GPW + lg, G - 1);
     const bool have = q * GPW + lg < G;
     const uint2 cr = lcrit[(int64_t)t * G + slot];
-    const uint32_t base = cr.x, span = cr.y & 0x3fffffffu;
-    const uint32_t inv = (cr.y >> 30) & 1u ? 0xffffffffu : 0u;
-    const uint32_t always = (cr.y >> 31) ? 0xffffffffu : 0u;
+    const uint32_t lo = cr.x, hi1 = cr.y;            // acceptance interval of the list count
     uint32_t valid[4];                                // permutations of this tile that exist
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -673,12 +685,11 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
       valid[w] = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
     }
     int cnt = 0;
-    cnt += __popc((((~region_lt<KC, KD>(c0, base, span)) ^ inv) | always) & valid[0]);
-    if constexpr (NW > 1)
-      cnt += __popc((((~region_lt<KC, KD>(c1, base, span)) ^ inv) | always) & valid[1]);
+    cnt += __popc(region_bits<KC>(c0, lo, hi1) & valid[0]);
+    if constexpr (NW > 1) cnt += __popc(region_bits<KC>(c1, lo, hi1) & valid[1]);
     if constexpr (NW > 2) {
-      cnt += __popc((((~region_lt<KC, KD>(c2, base, span)) ^ inv) | always) & valid[2]);
-      cnt += __popc((((~region_lt<KC, KD>(c3, base, span)) ^ inv) | always) & valid[3]);
+      cnt += __popc(region_bits<KC>(c2, lo, hi1) & valid[2]);
+      cnt += __popc(region_bits<KC>(c3, lo, hi1) & valid[3]);
     }
     if (!have) cnt = 0;
 #pragma unroll
@@ -797,7 +808,7 @@ static ListGeom list_geom(int num_cu, int64_t G, int64_t T, int64_t N, int64_t P
   return g;
 }
 
-template <int TW, int KC, int KD>
+template <int TW, int KC>
 static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* d_tiles,
                                 const uint32_t* d_lidx, int64_t entries, const int32_t* d_lstart,
                                 const int32_t* d_lngroups, const int32_t* d_lorder,
@@ -810,13 +821,13 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
     KernelTimer kt(h, s, "k_lists_crit");
     hipLaunchKernelGGL(k_lists_crit, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
                        reinterpret_cast<const uint2*>(d_crit), d_margins, d_lorder, d_lflipped,
-                       (int)G, KD, reinterpret_cast<uint2*>(d_lcrit));
+                       (int)G, reinterpret_cast<uint2*>(d_lcrit));
   }
   const ListGeom g = list_geom(h->num_cu, G, T, N, P, entries);
   if (T * g.ntiles > 0x7fffffffLL || g.chunks > 65535)
     return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: grid too large");
   const size_t lds = (size_t)list_tile_dwords(N, TW) * sizeof(uint32_t);
-  const void* fn = reinterpret_cast<const void*>(&k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>);
+  const void* fn = reinterpret_cast<const void*>(&k_permute_lists<list_lpg(TW), list_nw(TW), KC>);
   if (!(h->lists_lds_optin & TW)) {   // once per handle (= per device) and tile width
     // list entries of the one-lane-per-gene kernels are absolute LDS addresses: the label
     // tile must be the kernel's only LDS object (dynamic LDS then starts at address 0)
@@ -830,7 +841,7 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   }
   {
     KernelTimer kt(h, s, "k_permute_lists");
-    hipLaunchKernelGGL((k_permute_lists<list_lpg(TW), list_nw(TW), KC, KD>),
+    hipLaunchKernelGGL((k_permute_lists<list_lpg(TW), list_nw(TW), KC>),
                        dim3((unsigned)(T * g.ntiles), (unsigned)g.chunks), dim3(1024), lds, s, d_tiles,
                        d_lidx, d_lstart, d_lngroups, reinterpret_cast<const uint2*>(d_lcrit), (int)G,
                        (int)N, P, (int)g.ntiles, (int)g.gpb,
@@ -869,16 +880,16 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   uint32_t* sc = static_cast<uint32_t*>(d_scratch);
-  // counter planes KC: lists hold <= N/2 entries; compare planes KD: 2N+3 <= 2^KD
-#define LAUNCH(TWV, KCV, KDV)                                                                    \
-  return launch_permute_lists<TWV, KCV, KDV>(h, s, d_tiles, d_lidx, entries, d_lstart, d_lngroups, \
-                                             d_lorder, d_lflipped, d_crit, d_margins, sc, G, T, N, \
-                                             P, d_r)
-  if (TW == 16) LAUNCH(16, 11, 13);
-  if (TW == 8) LAUNCH(8, 12, 14);
-  if (TW == 4) LAUNCH(4, 13, 15);
-  if (TW == 2) LAUNCH(2, 14, 16);
-  LAUNCH(1, 15, 17);
+  // counter planes KC: lists hold <= N/2 entries, N/2 < 2^KC (and N + 1 < 2^(KC+1))
+#define LAUNCH(TWV, KCV)                                                                        \
+  return launch_permute_lists<TWV, KCV>(h, s, d_tiles, d_lidx, entries, d_lstart, d_lngroups,   \
+                                        d_lorder, d_lflipped, d_crit, d_margins, sc, G, T, N, P, \
+                                        d_r)
+  if (TW == 16) LAUNCH(16, 11);
+  if (TW == 8) LAUNCH(8, 12);
+  if (TW == 4) LAUNCH(4, 13);
+  if (TW == 2) LAUNCH(2, 14);
+  LAUNCH(1, 15);
 #undef LAUNCH
 }
 
