@@ -129,6 +129,21 @@ int scoary_permute(scoary_handle h, const uint32_t *d_tiled,
                    int64_t T, int64_t N, int64_t P, uint32_t *d_r,
                    scoary_stream_t stream);
 
+/* ---- a7 with the reference's sequential early abort (scoary/methods.py:1348-1365) ----
+ * Opt-in (--permute-early-abort): every (gene, trait) consumes the permutations in index
+ * order, r counting the ones in the rejection region; from permutation index i >= 30 on, the
+ * first i with r >= d_thr[i] stops that gene: d_nstop[t][g] = i + 1 and Empirical_p =
+ * (r + 1) / (i + 2) (`emp_p = (r+1.0)/(i+2.0)`, :1362); genes that never stop keep
+ * d_nstop = 0 and get (r + 1) / (P_total + 1) (:1365).  d_thr[i] = smallest r with
+ * 1 - binom.cdf(r, i, 0.1) < 0.05 (:1361) for 30 <= i < P_total, 0xffffffff below 30
+ * (uint32 [P_total], built by the caller).  Call once per batch of permutations
+ * [perm_base, perm_base + P) in ascending order; the caller zeroes d_r and d_nstop (uint32
+ * [T][G]) before the first batch.  d_perms: vecrows [T][P][Wp] (scoary_perm_generate). */
+int scoary_permute_seq(scoary_handle h, const uint32_t *d_tiled, const uint32_t *d_perms,
+                       const uint32_t *d_crit, const uint32_t *d_thr, int64_t G, int64_t T,
+                       int64_t N, int64_t P, int64_t perm_base, uint32_t *d_r,
+                       uint32_t *d_nstop, scoary_stream_t stream);
+
 /* ---- a7/a8, list-driven variant -------------------------------------------
  * Same result as scoary_perm_generate + scoary_permute (d_r is bit-identical),
  * different data flow: genes as lists of the isolates that carry their
@@ -239,7 +254,8 @@ int scoary_gather_bits(scoary_handle h, const uint32_t *d_rows, int64_t R, int64
  * The binary tree is a stack program over its K tips (children order is
  * irrelevant to the result):  op >= 0: push tip `op`;  op == -1: merge the two
  * top entries;  op <= -2: merge the top entry with tip (-2 - op).
- * `stack_depth` = the deepest the stack gets (host computes it; <= 32).
+ * `stack_depth` = the deepest the stack gets (host computes it; <= 32).  K <= 32767
+ * (pair counts are packed into 14-bit fields; more tips: SCOARY_ERR_SIZE).
  * Tip k of evaluation (g, l) is in state  (gene bit k of row g ? A : a) +
  * (label bit k of row l ? B : b); d_gene_bits uint32 [G][Wt], d_label_bits
  * uint32 [L][Wt], Wt = (K+31)/32.

@@ -30,6 +30,14 @@ int scoary_gpa_parse(scoary_gpa_t g, const uint8_t *keep);
  * line ends into ranges parsed in parallel; if a cut turns out to lie inside a quoted
  * cell (a range does not stop where the next one starts) the body is parsed in one piece. */
 int scoary_gpa_parse_mt(scoary_gpa_t g, const uint8_t *keep, int64_t threads, int64_t min_chunk);
+/* One process of several (one rank per GPU under torchrun): the body is cut at line ends
+ * into `nparts` byte ranges and only range `part` is parsed (with `threads` threads), so
+ * that the ranks read a large table together instead of each reading all of it.  Rows come
+ * back in file order within the part; the caller concatenates the parts in rank order.
+ * Returns -6 if a part boundary turned out to lie inside a quoted multi-line cell: every
+ * rank must then fall back to scoary_gpa_parse (the ranks have to agree on that). */
+int scoary_gpa_parse_part(scoary_gpa_t g, const uint8_t *keep, int64_t part, int64_t nparts,
+                          int64_t threads, int64_t min_chunk);
 void scoary_gpa_close(scoary_gpa_t g);
 const char *scoary_gpa_error(scoary_gpa_t g);
 

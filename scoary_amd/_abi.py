@@ -31,6 +31,8 @@ SIGNATURES = {
     "scoary_fisher": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "scoary_perm_generate": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp, _vp]),
     "scoary_permute": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "scoary_permute_seq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp,
+                                  _vp]),
     "scoary_list_tiles_words": (_i64, [_i64, _i64, _i64]),
     "scoary_list_tile_words": (_i64, [_i64]),
     "scoary_list_params": (_i32, [_i64, _vp]),

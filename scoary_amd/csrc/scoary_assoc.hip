@@ -352,6 +352,72 @@ __global__ __launch_bounds__(64) void k_permute_chunked(const uint4* __restrict_
   if (g < G && cnt) atomicAdd(&r[(int64_t)t * G + g], cnt);
 }
 
+// The reference's SEQUENTIAL estimator with early abort (scoary/methods.py:1348-1365), for the
+// Fisher statistic (opt-in, --permute-early-abort): a lane = one (gene, trait) walks ALL the
+// permutations in index order -- no permutation chunks across blocks -- with the running
+// count r; from permutation index i >= 30 on, the first i with r >= thr[i] (thr[i] = smallest
+// r with 1 - binom.cdf(r, i, 0.1) < 0.05, built on the host exactly as the reference
+// evaluates it) freezes the lane: nstop = i + 1, Empirical_p = (r + 1) / (i + 2).  Lanes that
+// never stop end with nstop = 0 and (r + 1) / (P + 1).  The state (r, nstop) lives in HBM
+// between batches of permutations; a wavefront leaves a batch as soon as all its lanes have
+// stopped.  Same CQ-quad register chunks x PB permutations per pass as k_permute_chunked.
+template <int CQ, int PB>
+__global__ __launch_bounds__(64) void k_permute_seq(const uint4* __restrict__ tiled,
+                                                    const uint32_t* __restrict__ perms,
+                                                    const uint2* __restrict__ crit,
+                                                    const uint32_t* __restrict__ thr, int G, int Gp,
+                                                    int Qp, int64_t P, int64_t perm_base,
+                                                    uint32_t* __restrict__ r,
+                                                    uint32_t* __restrict__ nstop) {
+  const int t = blockIdx.y;
+  const int g = blockIdx.x * kWave + threadIdx.x;
+  const bool have = g < G;
+  const uint2 cr = have ? crit[(int64_t)t * G + g] : make_uint2(0u, 0u);
+  uint32_t run = have ? r[(int64_t)t * G + g] : 0u;
+  uint32_t stop = have ? nstop[(int64_t)t * G + g] : 1u;       // padding lanes: stopped
+  const int nchunks = Qp / CQ;
+  const int np = (int)P;
+  const uint4* pbase = reinterpret_cast<const uint4*>(perms + (int64_t)t * P * ((int64_t)Qp * 4));
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+  for (int i0 = 0; i0 < np; i0 += PB) {
+    if (__ballot(stop == 0u) == 0) break;                      // every lane of the wavefront is done
+    uint32_t acc[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[j] = 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int c = 0; c < nchunks; ++c) {
+      uint4 gw[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) gw[q] = tiled[(int64_t)(c * CQ + q) * Gp + min(g, Gp - 1)];
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const int i = min(i0 + j, np - 1);
+        const uint4* pr = pbase + (int64_t)i * Qp + c * CQ;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+          const uint4 s = pr[q];  // wave-uniform -> s_load
+          bcnt_acc(acc[j], gw[q].x & s.x);
+          bcnt_acc(acc[j], gw[q].y & s.y);
+          bcnt_acc(acc[j], gw[q].z & s.z);
+          bcnt_acc(acc[j], gw[q].w & s.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      if (i0 + j < np && stop == 0u) {
+        const int64_t i = perm_base + i0 + j;                  // global permutation index
+        run += ((acc[j] - cr.x) >= cr.y) ? 1u : 0u;
+        if (i >= 30 && run >= thr[i]) stop = (uint32_t)(i + 1);
+      }
+    }
+  }
+  if (have) {
+    r[(int64_t)t * G + g] = run;
+    nstop[(int64_t)t * G + g] = stop;
+  }
+}
+
 template <int RQ, int GL>
 void launch_permute_reg(dim3 grid, hipStream_t s, const uint32_t* tiled, const uint32_t* perms,
                         const uint32_t* crit, int G, int Gp, int64_t P, int pchunk, uint32_t* r) {
@@ -513,6 +579,41 @@ int scoary_permute(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_p
     else LAUNCH_CHUNK(1, 16);
 #undef LAUNCH_CHUNK
   }
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_permute_seq(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_perms,
+                       const uint32_t* d_crit, const uint32_t* d_thr, int64_t G, int64_t T,
+                       int64_t N, int64_t P, int64_t perm_base, uint32_t* d_r, uint32_t* d_nstop,
+                       scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_perms || !d_crit || !d_thr || !d_r || !d_nstop || G < 1 || T < 1 || N < 1 ||
+      P < 1 || perm_base < 0)
+    return fail(h, SCOARY_ERR_ARG, "scoary_permute_seq: bad argument");
+  if (T > 65535 || P > 0x7fffffffLL || perm_base + P > 0xffffffffLL)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_permute_seq: T > 65535 or permutation index >= 2^32");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+  KernelTimer kt(h, s, "k_permute_seq");
+  const dim3 grid((unsigned)(Gp / kWave), (unsigned)T);
+  const uint4* t4 = reinterpret_cast<const uint4*>(d_tiled);
+  const uint2* c2 = reinterpret_cast<const uint2*>(d_crit);
+  // tiled rows come in the register sizes of kRegQuads (any of 1, 2, 4, 6 ... quads) or in
+  // multiples of kChunkQuads: chunk = the largest of 8 / 4 / 2 / 1 quads that divides Qp
+  if (Qp % 8 == 0)
+    hipLaunchKernelGGL((k_permute_seq<8, 8>), grid, dim3(kWave), 0, s, t4, d_perms, c2, d_thr, (int)G,
+                       (int)Gp, (int)Qp, P, perm_base, d_r, d_nstop);
+  else if (Qp % 4 == 0)
+    hipLaunchKernelGGL((k_permute_seq<4, 8>), grid, dim3(kWave), 0, s, t4, d_perms, c2, d_thr, (int)G,
+                       (int)Gp, (int)Qp, P, perm_base, d_r, d_nstop);
+  else if (Qp % 2 == 0)
+    hipLaunchKernelGGL((k_permute_seq<2, 8>), grid, dim3(kWave), 0, s, t4, d_perms, c2, d_thr, (int)G,
+                       (int)Gp, (int)Qp, P, perm_base, d_r, d_nstop);
+  else
+    hipLaunchKernelGGL((k_permute_seq<1, 8>), grid, dim3(kWave), 0, s, t4, d_perms, c2, d_thr, (int)G,
+                       (int)Gp, (int)Qp, P, perm_base, d_r, d_nstop);
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }

@@ -250,56 +250,43 @@ void parse_range(const scoary_gpa* g, const std::vector<int32_t>& slot, size_t b
 // Record starts for `k` ranges of the body: the guessed cuts are moved to the
 // character after the next line end.  A cut that falls inside a quoted cell is
 // caught later: the range before it then does not stop exactly there.
-std::vector<size_t> guess_cuts(const scoary_gpa* g, size_t body, int64_t k) {
+std::vector<size_t> guess_cuts(const scoary_gpa* g, size_t body, size_t end, int64_t k) {
   std::vector<size_t> cuts{body};
-  const size_t total = g->size - body;
+  const size_t total = end - body;
   for (int64_t i = 1; i < k; ++i) {
     size_t q = body + (size_t)((double)total * (double)i / (double)k);
-    while (q < g->size && g->data[q] != '\n' && g->data[q] != '\r') ++q;
-    if (q >= g->size) break;
+    while (q < end && g->data[q] != '\n' && g->data[q] != '\r') ++q;
+    if (q >= end) break;
     q = (g->data[q] == '\r' && q + 1 < g->size && g->data[q + 1] == '\n') ? q + 2 : q + 1;
-    if (q > cuts.back() && q < g->size) cuts.push_back(q);
+    if (q > cuts.back() && q < end) cuts.push_back(q);
   }
-  cuts.push_back(g->size);
+  cuts.push_back(end);
   return cuts;
 }
-}  // namespace
 
-int scoary_gpa_parse_mt(scoary_gpa_t g, const uint8_t* keep, int64_t threads, int64_t min_chunk) {
-  if (!g || !g->data) return -1;
-  const int64_t ncols = (int64_t)g->header.size();
-  const int64_t nstr = ncols - g->startcol;
-  std::vector<int32_t> slot(nstr, -1);  // strain column -> bit index
-  int64_t kept = 0;
-  for (int64_t c = 0; c < nstr; ++c)
-    if (!keep || keep[c]) slot[c] = (int32_t)kept++;
-  g->strains = kept;
-  g->words = (kept + 63) / 64;
-  g->rows = 0;
-  g->bits.clear();
-  g->meta_len.clear();
-  g->meta.clear();
-  const size_t body = g->pos;
+// Parses the records of [lo, hi) (lo, hi at record starts) in up to `threads` ranges.  Returns
+// false if a guessed cut -- an inner one, or `hi` itself when it is not the end of the file --
+// turned out to lie inside a quoted cell (a range does not stop where the next one starts).
+bool parse_span(const scoary_gpa* g, const std::vector<int32_t>& slot, size_t lo, size_t hi,
+                int64_t threads, int64_t min_chunk, std::vector<Piece>* pieces) {
   if (min_chunk < 1) min_chunk = 1;
-  int64_t k = (int64_t)((g->size - body) / (size_t)min_chunk);
+  int64_t k = (int64_t)((hi - lo) / (size_t)min_chunk);
   if (k > threads) k = threads;
   if (k < 1) k = 1;
-  std::vector<size_t> cuts = guess_cuts(g, body, k);
-  std::vector<Piece> pieces(cuts.size() - 1);
-#pragma omp parallel for schedule(static, 1) num_threads((int)pieces.size())
-  for (int64_t i = 0; i < (int64_t)pieces.size(); ++i)
-    parse_range(g, slot, cuts[i], cuts[i + 1], &pieces[i]);
-  // a range must stop exactly where the next one started (or at its own bad row);
-  // otherwise a guessed cut was inside a quoted cell: parse in one piece instead
-  bool ok = true;
-  for (size_t i = 0; i + 1 < pieces.size() && ok; ++i) {
-    if (pieces[i].bad_cells >= 0) break;
-    ok = pieces[i].stop == cuts[i + 1];
+  std::vector<size_t> cuts = guess_cuts(g, lo, hi, k);
+  pieces->assign(cuts.size() - 1, Piece());
+#pragma omp parallel for schedule(static, 1) num_threads((int)pieces->size())
+  for (int64_t i = 0; i < (int64_t)pieces->size(); ++i)
+    parse_range(g, slot, cuts[i], cuts[i + 1], &(*pieces)[i]);
+  for (size_t i = 0; i < pieces->size(); ++i) {
+    if ((*pieces)[i].bad_cells >= 0) return true;     // a malformed row: reported by the caller
+    if ((*pieces)[i].stop != cuts[i + 1] && (i + 1 < pieces->size() || hi < g->size)) return false;
   }
-  if (!ok) {
-    pieces.assign(1, Piece());
-    parse_range(g, slot, body, g->size, &pieces[0]);
-  }
+  return true;
+}
+
+int finish_pieces(scoary_gpa* g, std::vector<Piece>& pieces) {
+  const int64_t ncols = (int64_t)g->header.size();
   for (auto& pc : pieces) {
     g->bits.insert(g->bits.end(), pc.bits.begin(), pc.bits.end());
     g->meta_len.insert(g->meta_len.end(), pc.meta_len.begin(), pc.meta_len.end());
@@ -312,6 +299,52 @@ int scoary_gpa_parse_mt(scoary_gpa_t g, const uint8_t* keep, int64_t threads, in
     }
   }
   return 0;
+}
+
+std::vector<int32_t> begin_parse(scoary_gpa* g, const uint8_t* keep) {
+  const int64_t nstr = (int64_t)g->header.size() - g->startcol;
+  std::vector<int32_t> slot(nstr, -1);  // strain column -> bit index
+  int64_t kept = 0;
+  for (int64_t c = 0; c < nstr; ++c)
+    if (!keep || keep[c]) slot[c] = (int32_t)kept++;
+  g->strains = kept;
+  g->words = (kept + 63) / 64;
+  g->rows = 0;
+  g->bits.clear();
+  g->meta_len.clear();
+  g->meta.clear();
+  return slot;
+}
+}  // namespace
+
+int scoary_gpa_parse_mt(scoary_gpa_t g, const uint8_t* keep, int64_t threads, int64_t min_chunk) {
+  if (!g || !g->data) return -1;
+  std::vector<int32_t> slot = begin_parse(g, keep);
+  const size_t body = g->pos;
+  std::vector<Piece> pieces;
+  // a range must stop exactly where the next one started (or at its own bad row);
+  // otherwise a guessed cut was inside a quoted cell: parse in one piece instead
+  if (!parse_span(g, slot, body, g->size, threads, min_chunk, &pieces)) {
+    pieces.assign(1, Piece());
+    parse_range(g, slot, body, g->size, &pieces[0]);
+  }
+  return finish_pieces(g, pieces);
+}
+
+int scoary_gpa_parse_part(scoary_gpa_t g, const uint8_t* keep, int64_t part, int64_t nparts,
+                          int64_t threads, int64_t min_chunk) {
+  if (!g || !g->data || nparts < 1 || part < 0 || part >= nparts) return -1;
+  std::vector<int32_t> slot = begin_parse(g, keep);
+  const size_t body = g->pos;
+  const std::vector<size_t> outer = guess_cuts(g, body, g->size, nparts);
+  const int64_t have = (int64_t)outer.size() - 1;        // small files give fewer parts
+  if (part >= have) return 0;                            // nothing for this part
+  std::vector<Piece> pieces;
+  if (!parse_span(g, slot, outer[part], outer[part + 1], threads, min_chunk, &pieces)) {
+    g->err = "a part boundary lies inside a quoted cell: parse the file in one piece";
+    return -6;
+  }
+  return finish_pieces(g, pieces);
 }
 
 int scoary_gpa_parse(scoary_gpa_t g, const uint8_t* keep) {

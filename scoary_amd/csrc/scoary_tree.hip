@@ -107,9 +107,10 @@ __global__ __launch_bounds__(256) void k_row_hash(const uint4* __restrict__ tile
 // each maximised on its own (classes.py:407-453).  That rule is exactly an
 // integer max over two packed keys
 //     ks = total << 16 | supporting      ko = total << 16 | opposing
-// (counts <= tips/2 < 2^15, so adding two keys never carries between fields),
-// with "unreachable" = a large negative key that stays negative through one
-// addition and is re-clamped after every merge.  A pairing of a left and a
+// (counts <= tips/2 < 2^14 -- launch_tree rejects more than 32767 tips -- so adding two
+// keys never carries between fields and every reachable key is < 2^30), with
+// "unreachable" = -2^30, which therefore stays negative through one addition with a
+// reachable key and is re-clamped after every merge.  A pairing of a left and a
 // right state is then TWO integer adds, choosing between pairings TWO v_max.
 struct TreeNode {
   int ks[5], ko[5];
@@ -528,7 +529,9 @@ static int launch_tree(scoary_handle h, const char* what, bool exceed_mode, cons
       stack_depth < 1 || (exceed_mode ? (!d_obs || !d_exceed) : !d_out3))
     return fail(h, SCOARY_ERR_ARG, std::string(what) + ": bad argument");
   if (stack_depth > 32) return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": stack_depth > 32");
-  if (K > 65534) return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": more than 65534 tips");
+  // packed keys: total << 16 | count with total <= K/2; K <= 32767 keeps every reachable
+  // key below 2^30, so that kTreeNone + reachable stays negative (the "unreachable" test)
+  if (K > 32767) return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": more than 32767 tips");
   const int64_t threads = G * L;
   if ((threads + kWave - 1) / kWave > 0x7fffffffLL)
     return fail(h, SCOARY_ERR_SIZE, std::string(what) + ": G*L too large for one launch");

@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-REC_WORDS = 9   # int32 words per (trait, gene): 4 counts, p (2), odds (2), r (1)
+REC_WORDS = 10  # int32 words per (trait, gene): 4 counts, p (2), odds (2), r (1), nstop (1)
 
 
 def _torch():
@@ -37,17 +37,21 @@ def max_shard(G, world):
     return -(-int(G) // int(world))
 
 
-def pack_records(counts, p, odds, r):
-    """counts int32 [T,Gs,4], p/odds float64 [T,Gs], r int32 [T,Gs] or None ->
-    int32 [T,Gs,9] (bit patterns preserved)."""
+def pack_records(counts, p, odds, r, nstop=None):
+    """counts int32 [T,Gs,4], p/odds float64 [T,Gs], r int32 [T,Gs] or None, nstop int32
+    [T,Gs] or None (the permutation count a gene's sequential estimator stopped at, 0 = it
+    ran to the end; only with --permute-early-abort) -> int32 [T,Gs,10] (bit patterns
+    preserved)."""
     torch = _torch()
     T, Gs = p.shape
     if r is None:
         r = torch.zeros((T, Gs), dtype=torch.int32, device=p.device)
+    if nstop is None:
+        nstop = torch.zeros((T, Gs), dtype=torch.int32, device=p.device)
     def i32(x):
         return x.reshape(-1).clone().view(torch.int32).view(T, Gs, 2)
     return torch.cat([counts.reshape(T, Gs, 4), i32(p), i32(odds),
-                      r.reshape(T, Gs, 1)], dim=2).contiguous()
+                      r.reshape(T, Gs, 1), nstop.reshape(T, Gs, 1)], dim=2).contiguous()
 
 
 def unpack_records(rec):
@@ -58,7 +62,8 @@ def unpack_records(rec):
         return rec[:, :, lo:lo + 2].reshape(-1).clone().view(torch.float64).view(T, G)
     return {"counts": rec[:, :, 0:4].reshape(-1).clone().view(T, G, 4),
             "p": f64(4), "odds": f64(6),
-            "r": rec[:, :, 8].reshape(-1).clone().view(T, G)}
+            "r": rec[:, :, 8].reshape(-1).clone().view(T, G),
+            "nstop": rec[:, :, 9].reshape(-1).clone().view(T, G)}
 
 
 def is_distributed():
@@ -155,6 +160,45 @@ def gather_genes(rec_local, G, dst=0, group=None, async_op=False, recv=None):
     return work, finish
 
 
+def all_gather_host_rows(rows, group=None):
+    """rows: this rank's (R_k, W) numpy array (R_k differs between ranks) -> the (sum R_k, W)
+    concatenation in rank order on every rank.  Used to put the bit rows of a table the
+    ranks parsed in byte ranges back together; goes over RCCL on GPU tensors when a GPU
+    backend is up, gloo otherwise."""
+    torch = _torch()
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    as64 = np.ascontiguousarray(rows).view(np.int64) if rows.dtype == np.uint64 else np.ascontiguousarray(rows)
+    n = torch.tensor([as64.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts = counts.cpu().tolist()
+    cap, W = max(counts + [1]), as64.shape[1]
+    send = torch.zeros((cap, W), dtype=torch.from_numpy(as64[:0]).dtype, device=dev)
+    send[:as64.shape[0]] = torch.from_numpy(as64).to(dev)
+    recv = torch.empty((world * cap, W), dtype=send.dtype, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, cap, W).cpu().numpy()
+    out = np.concatenate([recv[r, :counts[r]] for r in range(world)], axis=0)
+    return (out.view(np.uint64) if rows.dtype == np.uint64 else out), counts
+
+
+def all_gather_objects(obj, group=None):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (pickled; small host metadata)."""
+    import torch.distributed as dist
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def barrier(group=None):
+    """Process-group barrier; no-op for a single process."""
+    if is_distributed():
+        import torch.distributed as dist
+        dist.barrier(group=group)
+
+
 def shutdown():
     """Leave the process group (if any) before the interpreter exits."""
     if _initialized():
@@ -168,7 +212,7 @@ def _initialized():
 
 
 def associate_sharded(local_compute, G, group=None):
-    """Run ``local_compute(start, stop) -> int32 records [T, stop-start, 9]`` on
+    """Run ``local_compute(start, stop) -> int32 records [T, stop-start, REC_WORDS]`` on
     this rank's gene shard and gather the records of all ranks (every rank gets
     the full result: the host-side B/BH needs the globally sorted p)."""
     world, rank = world_rank()
@@ -182,4 +226,5 @@ def numpy_records(rec):
     d = unpack_records(rec)
     out = {k: v.cpu().numpy() for k, v in d.items()}
     out["r"] = out["r"].view(np.uint32)
+    out["nstop"] = out["nstop"].view(np.uint32)
     return out

@@ -319,6 +319,30 @@ class AssociationEngine:
                                             self._ptr(r), self._stream()), "scoary_permute")
         return r
 
+    def permute_sequential(self, genes, masks, margins, crit, permutations, seed, thr):
+        """The reference's sequential estimator with early abort on the Fisher statistic
+        (scoary_permute_seq): returns (r, nstop) int32 device tensors [T, G]; Empirical_p =
+        (r + 1) / ((nstop or P) + 1).  ``thr``: host array of abort thresholds per
+        permutation index (tree._abort_thresholds)."""
+        torch = _torch()
+        T = masks.shape[0]
+        r = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
+        nstop = torch.zeros((T, genes.G), dtype=torch.int32, device=self.device)
+        th = np.minimum(np.asarray(thr, dtype=np.int64), 0xffffffff).astype(np.uint32)
+        d_thr = torch.from_numpy(th.view(np.int32)).to(self.device)
+        batch = self.perm_batch(T, genes.N, permutations, budget_bytes=1 << 30)
+        buf = self._empty((T, batch, self.row_words(genes.N)), torch.int32)
+        done = 0
+        while done < permutations:
+            nb = min(batch, permutations - done)
+            self.perm_generate(masks, margins, genes.N, nb, done, seed, out=buf)
+            self._check(self.lib.scoary_permute_seq(
+                self.h, self._ptr(genes.tiled), self._ptr(buf), self._ptr(crit), self._ptr(d_thr),
+                genes.G, T, genes.N, nb, done, self._ptr(r), self._ptr(nstop), self._stream()),
+                "scoary_permute_seq")
+            done += nb
+        return r, nstop
+
     def perm_batch(self, T, N, P, budget_bytes=8 << 30):
         """Permutations per generate/permute round so the label buffer stays
         under budget_bytes."""

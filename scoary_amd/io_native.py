@@ -108,8 +108,13 @@ class GpaError(Exception):
     pass
 
 
+class GpaPartBoundary(GpaError):
+    """A part boundary of a sharded read lies inside a quoted cell (scoary_gpa_parse_part
+    returned -6): every rank has to read the whole file instead."""
+
+
 def read_gpa(path, delimiter, startcol, allowed=None, threads=None, min_chunk=8 << 20,
-             need_cols=None):
+             need_cols=None, part=None):
     """-> (header, meta_rows, rows64, kept_strains): the file's header cells,
     for every data row the text of columns [0, startcol), the presence bits of
     the kept strain columns as rows64, and the kept strain names.  ``allowed``:
@@ -117,7 +122,10 @@ def read_gpa(path, delimiter, startcol, allowed=None, threads=None, min_chunk=8 
     ``threads`` / ``min_chunk``: parallel body parse (scoary_gpa_parse_mt); the
     default lets the library use its OpenMP thread count.  ``need_cols``: None
     (decode every text cell) or a callable header -> columns < startcol whose
-    text is wanted; the other cells of meta_rows are left as ""."""
+    text is wanted; the other cells of meta_rows are left as "".  ``part`` = (k, n):
+    parse only the k-th of n byte ranges of the body (scoary_gpa_parse_part; one rank of n
+    under torchrun) -- raises GpaPartBoundary if the ranks must fall back to whole-file
+    reads."""
     L = _load()
     h = ctypes.c_void_p()
     rc = L.scoary_gpa_open(os.fsencode(path), delimiter.encode()[0:1], int(startcol),
@@ -135,7 +143,16 @@ def read_gpa(path, delimiter, startcol, allowed=None, threads=None, min_chunk=8 
         if allowed is not None:
             keep = np.array([1 if s in allowed else 0 for s in strains], dtype=np.uint8)
         kp = keep.ctypes.data_as(ctypes.c_void_p) if keep is not None else None
-        if threads is None:
+        if part is not None:
+            L.scoary_gpa_parse_part.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+            L.scoary_gpa_parse_part.restype = ctypes.c_int
+            rc = L.scoary_gpa_parse_part(h, kp, int(part[0]), int(part[1]),
+                                         int(threads or min(32, os.cpu_count() or 1)),
+                                         int(min_chunk))
+            if rc == -6:
+                raise GpaPartBoundary(L.scoary_gpa_error(h).decode())
+        elif threads is None:
             rc = L.scoary_gpa_parse(h, kp)
         else:
             rc = L.scoary_gpa_parse_mt(h, kp, int(threads), int(min_chunk))

@@ -230,8 +230,16 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
     through Python's csv module."""
     opened = None
     if writereducedset:
-        opened = open(ReduceSet(genefile, delimiter, grabcols, startcol, allowed_isolates,
-                                time, outdir), "r", newline=None)
+        # under torchrun only rank 0 writes the reduced table; the other ranks wait for it
+        # (all ranks writing the same path with mode "w" raced each other's reads)
+        from . import dist as _dist
+        world, rank = _dist.world_rank()
+        name = _reduced_name(outdir, time)
+        if rank == 0:
+            ReduceSet(genefile, delimiter, grabcols, startcol, allowed_isolates, time, outdir)
+        if world > 1:
+            _dist.barrier()
+        opened = open(name, "r", newline=None)
         genefile = opened
     from . import io_native
     path = getattr(genefile, "name", None)
@@ -248,8 +256,8 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
                 except ValueError:
                     first = [0, 1, 2]
                 return first + list(grabcols)
-            header, meta_rows, bits, kept_native = io_native.read_gpa(
-                path, delimiter, startcol, allowed_isolates, need_cols=wanted)
+            header, meta_rows, bits, kept_native = _read_gpa_ranks(
+                io_native, path, delimiter, startcol, allowed_isolates, wanted)
         except io_native.GpaError as e:
             if "startcol" in str(e):
                 sys.exit("The startcol (-s) you have specified does not seem to correspond to "
@@ -310,6 +318,7 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
     index, ids, nugn, ann, source = {}, [], [], [], []
     extra = {header[c] + "_name": [] for c in grabcols}
     dense_rows = []
+    all_rows = []        # presence of every FILE row (the tree stage uses these, see the return)
 
     def take(q, r, present):
         try:
@@ -342,7 +351,7 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
             take(q, r, None)
         rows64 = bits[np.array(source, dtype=np.int64)] if ids else bits[:0]
         table = GeneTable(ids, nugn, ann, kept_strains, rows64, extra)
-        dense = table.dense()
+        file_rows64 = np.ascontiguousarray(bits, dtype=np.uint64)     # EVERY file row, see below
     else:
         for r, q in enumerate(rows_iter):
             try:
@@ -352,12 +361,18 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
                          "this file is a proper Roary file using the specified delimiter "
                          "(default is ',').")
             take(q, r, present)
+            all_rows.append(present)
         dense = np.array(dense_rows, dtype=np.uint8).reshape(len(ids), len(keep))
         table = GeneTable(ids, nugn, ann, kept_strains, pack_bits_rows(dense), extra)
+        file_rows64 = pack_bits_rows(np.array(all_rows, dtype=np.uint8).reshape(len(all_rows), len(keep)))
     if opened is not None:
         opened.close()
-    return {"Roarydic": table, "Zero_ones_matrix": _LazyZeroOnes(dense), "Strains": kept_strains,
-            "Extracols": extracols, "Firstcolnames": firstcolnames}
+    # Zero_ones_matrix comes from every row of the FILE, not from the de-duplicated table: the
+    # reference appends each (variable) row as it reads it and only the dict entry of a
+    # repeated identifier is overwritten (scoary/methods.py:445-497), so repeated identifiers
+    # (VCF multi-allelic sites in non-Roary files) count once per row in the Hamming distances.
+    return {"Roarydic": table, "Zero_ones_matrix": _LazyZeroOnes(file_rows64, len(kept_strains)),
+            "Strains": kept_strains, "Extracols": extracols, "Firstcolnames": firstcolnames}
 
 
 class _LazyZeroOnes:
@@ -365,12 +380,18 @@ class _LazyZeroOnes:
     variable genes.  Only the tree builder wants it, so the list-of-lists is
     built on first use."""
 
-    def __init__(self, dense):
-        self._dense, self._lists = dense, None
+    def __init__(self, rows64, nstrains):
+        self._rows64, self._n, self._lists = rows64, nstrains, None
+
+    def file_rows(self):
+        """(file rows, N) uint8 presence of every row of the gene file (what the
+        reference's zero_ones_line loop sees, before the all-0 / all-1 filter)."""
+        by = np.ascontiguousarray(self._rows64).view(np.uint8).reshape(self._rows64.shape[0], -1)
+        return np.unpackbits(by, axis=1, bitorder="little")[:, :self._n]
 
     def _get(self):
         if self._lists is None:
-            d = self._dense
+            d = self.file_rows()
             tot = d.sum(axis=1) if d.size else np.zeros(0)
             var = (tot > 0) & (tot < d.shape[1])
             self._lists = d[var].T.tolist() if d.shape[1] else []
@@ -386,6 +407,44 @@ class _LazyZeroOnes:
         return self._get()[k]
 
 
+def _read_gpa_ranks(io_native, path, delimiter, startcol, allowed_isolates, wanted):
+    """The native reader, shared between the ranks of a torchrun launch: every rank parses
+    one byte range of the body (cut at line ends) and the bit rows / text columns are put
+    back together with one all-gather each, instead of every rank tokenising the whole file
+    (the reference's workers all receive the one parsed dict, scoary/methods.py:1083-1097;
+    here the file is the thing that is big).  A boundary inside a quoted multi-line cell, or
+    SCOARY_SHARDED_READ=0, makes every rank read the whole file."""
+    from . import dist as _dist
+    world, rank = _dist.world_rank()
+    if world > 1 and os.environ.get("SCOARY_SHARDED_READ", "1") != "0":
+        part, status = None, "ok"
+        try:
+            part = io_native.read_gpa(path, delimiter, startcol, allowed_isolates,
+                                      need_cols=wanted, part=(rank, world))
+        except io_native.GpaPartBoundary:
+            status = "boundary"
+        except io_native.GpaError as e:
+            status = "error:" + str(e)
+        statuses = _dist.all_gather_objects(status)
+        if "boundary" not in statuses:
+            # (after a boundary inside a quoted cell the NEXT rank starts mid-cell and sees a
+            # malformed row: its error means nothing, the whole-file read below decides)
+            errs = [x[6:] for x in statuses if x.startswith("error:")]
+            if errs:
+                raise io_native.GpaError(errs[0])    # a malformed row: every rank leaves together
+            header, meta_rows, bits, kept = part
+            bits, counts = _dist.all_gather_host_rows(bits)
+            meta_rows = [row for rows in _dist.all_gather_objects(meta_rows) for row in rows]
+            log.info("Read the gene presence/absence file in %d byte ranges (rows per rank: %s)"
+                     % (world, ", ".join(str(c) for c in counts)))
+            return header, meta_rows, bits, kept
+    return io_native.read_gpa(path, delimiter, startcol, allowed_isolates, need_cols=wanted)
+
+
+def _reduced_name(outdir, time):
+    return "%sgene_presence_absence_reduced%s.csv" % (outdir, time)
+
+
 def ReduceSet(genefile, delimiter, grabcols, startcol=14, allowed_isolates=None, time="",
               outdir="./"):
     """-r/-w: write the column subset of the table (methods.py:510-544)."""
@@ -393,7 +452,7 @@ def ReduceSet(genefile, delimiter, grabcols, startcol=14, allowed_isolates=None,
     header = next(reader)
     cols = list(range(startcol)) + [c for c in range(len(header)) if header[c] in allowed_isolates]
     log.info("Writing gene presence absence file for the reduced set of isolates")
-    name = "%sgene_presence_absence_reduced%s.csv" % (outdir, time)
+    name = _reduced_name(outdir, time)
     with open(name, "w") as out:
         w = csv.writer(out, delimiter=delimiter)
         w.writerow([header[c] for c in cols])
@@ -529,10 +588,13 @@ def _pattern_groups(table, maskrow, idx, hashes):
     return inv.reshape(-1)
 
 
-def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED):
+def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False):
     """Whole hot path for all traits; under torchrun (world > 1) every rank
     takes a contiguous gene shard and the per-gene records are all-gathered
-    over RCCL (scoary_amd.dist), so every rank returns the full arrays."""
+    over RCCL (scoary_amd.dist), so every rank returns the full arrays.
+    ``early_abort``: the reference's sequential estimator (scoary/methods.py:1360-1363)
+    on the Fisher statistic instead of the fixed-P count: out["nstop"] then holds the
+    permutation count every gene stopped at (0 = ran to the end)."""
     import torch
     from . import dist
     eng = get_engine()
@@ -544,9 +606,16 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED):
         if b <= a:
             return torch.zeros((T, 0, dist.REC_WORDS), dtype=torch.int32, device=eng.device)
         gm = table.on_device(eng) if (a, b) == (0, G) else eng.tile_rows(table.rows64[a:b], N)
-        if permutations > 0 and gm.lists is None and eng.lists_supported(N):
+        if permutations > 0 and not early_abort and gm.lists is None and eng.lists_supported(N):
             # list-driven permutation kernel: cost follows each gene's minority count
             eng.build_lists(gm)
+        if early_abort and permutations > 0:
+            from . import tree as T_
+            res = eng.associate(gm, trv, mkv, permutations=0)
+            crit = eng.fisher(res["counts"], want_crit=True)[2]
+            r, nstop = eng.permute_sequential(gm, mkv, res["margins"], crit, permutations, seed,
+                                              T_._abort_thresholds(permutations))
+            return dist.pack_records(res["counts"], res["p"], res["odds"], r, nstop)
         res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed)
         return dist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
 
@@ -556,14 +625,15 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED):
     return out
 
 
-def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEED):
+def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEED,
+                  early_abort=False):
     """Counts, Fisher's exact test and B/BH correction for every trait x gene
     (methods.py:757-928).  ``permutations`` >= 10 additionally attaches the
     Fisher-statistic ``Empirical_p`` (= (r+1)/(P+1), methods.py:1365) to every
     row -- the north_star's replacement for the tree-statistic Permute loop."""
     table = _as_table(genedic)
     names, tarr = _trait_arrays(traitsdic, table.strains)
-    dev = _associate(table, tarr, permutations if permutations >= 10 else 0, seed)
+    dev = _associate(table, tarr, permutations if permutations >= 10 else 0, seed, early_abort)
     collapse_hashes = None
     if collapse:
         eng = get_engine()
@@ -581,7 +651,10 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
         p_all, or_all = dev["p"][t], dev["odds"][t]
         emp = None
         if dev["r"] is not None:
-            emp = (dev["r"][t].astype(np.float64) + 1.0) / (permutations + 1.0)
+            # (r+1)/(P+1), :1365; with --permute-early-abort a gene that stopped after n
+            # permutations gets (r+1)/(n+1) = the reference's (r+1.0)/(i+2.0), :1362
+            n_used = np.where(dev["nstop"][t] > 0, dev["nstop"][t], permutations).astype(np.float64)
+            emp = (dev["r"][t].astype(np.float64) + 1.0) / (n_used + 1.0)
 
         if not collapse:
             rows_idx, members, names_out = idx, None, [table.ids[i] for i in idx]
@@ -1025,6 +1098,12 @@ def ScoaryArgumentParser(argv=None):
     a.add_argument("-e", "--permute", type=int, default=0,
                    help="Number of trait-label permutations per gene for empirical p-values "
                    "(0 = off, minimum 10)")
+    a.add_argument("--permute-early-abort", dest="permute_early_abort", action="store_true",
+                   default=False,
+                   help="With --no_pairwise --permute: use the reference's sequential estimator "
+                   "with early abort for the Fisher-statistic permutations -- a gene stops after "
+                   "i >= 30 permutations once 1 - binom.cdf(r, i, 0.1) < 0.05 and gets "
+                   "(r+1)/(i+2) (large empirical p-values become coarse, like the reference's)")
     a.add_argument("--no_pairwise", action="store_true", default=False,
                    help="Population-structure-naive analysis only (Fisher's test, odds ratios)")
     a.add_argument("--collapse", action="store_true", default=False,
@@ -1118,7 +1197,7 @@ def main(**kwargs):
                 log.info("Creating Hamming distance matrix based on gene presence/absence")
                 from . import tree as T
                 log.info("Building UPGMA tree from distance matrix")
-                upgmatree = T.upgma(get_engine(), genedic.dense(), strains)
+                upgmatree = T.upgma(get_engine(), gd["Zero_ones_matrix"].file_rows(), strains)
             elif args.no_pairwise:
                 log.info("Ignoring relatedness among input sample and performing only "
                          "population structure-naive analysis.")
@@ -1148,7 +1227,8 @@ def main(**kwargs):
         # default mode: tree-statistic permutations of the surviving genes, done
         # in the pairwise stage like the reference does.
         res = Setup_results(genedic, traitsdic, args.collapse,
-                            permutations=args.permute if args.no_pairwise else 0, seed=seed)
+                            permutations=args.permute if args.no_pairwise else 0, seed=seed,
+                            early_abort=getattr(args, "permute_early_abort", False))
         t_stats = _time.time()
         if args.upgma_tree and upgmatree is not None and rank == 0:
             StoreUPGMAtreeToFile(upgmatree, args.outdir, time=stamp)

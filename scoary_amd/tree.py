@@ -284,9 +284,8 @@ def read_newick(path):
     """Read a Newick file into nested two-element lists of tip names + the
     list of tip names (scoary/nwkhandler.py:10-40).  Branch lengths, support
     values and internal names are ignored; quotes around names are stripped; a
-    node with more than two children is resolved left to right
-    ((a, b), c) ...  -- ete3's own polytomy resolution is not available here
-    (documented divergence for non-binary input trees)."""
+    node with more than two children is resolved in ete3's order
+    (_resolve_polytomy)."""
     with open(path) as f:
         text = f.read().strip()
     text = text[:text.index(";")] if ";" in text else text
@@ -307,12 +306,7 @@ def read_newick(path):
                 pos += 1
             if not kids:
                 raise SystemExit("Corrupted or non-existing custom tree file? empty group")
-            node = kids[0]
-            for k in kids[1:]:
-                node = [node, k]
-            if len(kids) == 1:
-                node = kids[0]
-            stack[-1].append(node)
+            stack[-1].append(_resolve_polytomy(kids))
         elif ch == ",":
             pos += 1
         elif ch.isspace():
@@ -334,13 +328,24 @@ def read_newick(path):
                     pos += 1
             stack[-1].append(label)
             members.append(label)
-    top = stack[0]
-    if len(top) != 1:
-        node = top[0]
-        for k in top[1:]:
-            node = [node, k]
-        top = [node]
-    return top[0], members
+    return _resolve_polytomy(stack[0]), members
+
+
+def _resolve_polytomy(kids):
+    """Children [k0, k1, ..., kn] of one node -> nested pairs the way the reference's
+    ``myTree.resolve_polytomy(recursive=True)`` (ete3, scoary/nwkhandler.py:19) arranges
+    them: the first child stays at the top, every further child becomes the sibling of a new
+    first child, the last two children are paired --
+        [a, b, c]    -> [[b, c], a]
+        [a, b, c, d] -> [[[c, d], b], a]
+    (ete3 is not installed here: restated from ete3's TreeNode.resolve_polytomy, which adds
+    n-2 nested first children and then hands the original children out top-down.)"""
+    if len(kids) == 1:
+        return kids[0]
+    node = [kids[-2], kids[-1]]
+    for k in reversed(kids[:-2]):
+        node = [node, k]
+    return node
 
 
 # ---------------------------------------------------------------------------

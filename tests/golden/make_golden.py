@@ -482,6 +482,10 @@ def main():
                            gd4["Roarydic"], td4, False)
         manifest["vcf_firstcolnames"] = gd4["Firstcolnames"]
         manifest["vcf_strains"] = gd4["Strains"]
+        # every FILE row enters the tree-building matrix, also rows whose identifier repeats
+        # (8 rows -> 5 identifiers here): scoary/methods.py:445-497
+        manifest["vcf_zero_ones_matrix"] = gd4["Zero_ones_matrix"]
+        manifest["vcf_file_rows"] = sum(1 for _ in open(mpa)) - 1
     finally:
         os.chdir(cwd)
 

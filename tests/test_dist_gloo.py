@@ -146,7 +146,7 @@ def test_gather_to_rank0_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = np.arange(2 * 11 * 9, dtype=np.int32).reshape(2, 11, 9)
+    want = np.arange(2 * 11 * 10, dtype=np.int32).reshape(2, 11, 10)
     assert all(np.array_equal(o, want) for o in got[0])
     assert got[1] == [None, None] and got[2] == [None, None]
 
@@ -232,3 +232,79 @@ def test_bench_refuses_more_gpus_than_visible():
                          capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode != 0
     assert "--gpus 64" in out.stderr and "visible" in out.stderr
+
+
+# ------------------------------------------------ rank-sharded table read -----
+def _read_worker(rank, world, port, path, outq):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import logging
+    from scoary_amd import dist as sd
+    from scoary_amd import methods as m
+    sd.init_from_env()
+    seen = []
+
+    class Grab(logging.Handler):
+        def emit(self, rec):
+            seen.append(rec.getMessage())
+    m.log.addHandler(Grab())
+    m.log.setLevel(logging.INFO)
+    with open(path, "r", newline=None) as f:
+        gd = m.Csv_to_dic_Roary(f, ",", [3], startcol=14)
+    t = gd["Roarydic"]
+    outq.put((rank, list(t.ids), list(t.annotation), t.rows64.copy(), gd["Strains"],
+              any("byte ranges" in s for s in seen)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _sharded_read(path, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_read_worker, args=(r, world, port, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((x[0], x[1:]) for x in (q.get(timeout=180) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_ranks_read_the_table_in_byte_ranges_gloo(exampledir, tmp_path):
+    """Under torchrun every rank tokenises one byte range of the gene presence/absence
+    file and the parts are all-gathered: the table every rank ends up
+    with equals the single-process read -- identifiers, text columns, bit rows -- for 2 and
+    3 ranks; a file whose part boundary falls inside a quoted multi-line cell makes the
+    ranks agree to read it whole."""
+    from scoary_amd import methods as m
+    path = os.path.join(exampledir, "Gene_presence_absence.csv")
+    with open(path, "r", newline=None) as f:
+        want = m.Csv_to_dic_Roary(f, ",", [3], startcol=14)
+    wt = want["Roarydic"]
+    for world in (2, 3):
+        got = _sharded_read(path, world)
+        for rank in range(world):
+            ids, ann, rows64, strains, sharded = got[rank]
+            assert sharded, "rank %d did not take the sharded path" % rank
+            assert ids == list(wt.ids) and ann == list(wt.annotation) and strains == want["Strains"]
+            assert np.array_equal(rows64, wt.rows64)
+    # a quoted cell with line breaks across the middle of the file
+    header = ["Gene", "Non-unique Gene name", "Annotation"] + ["c%d" % i for i in range(11)] + ["s1", "s2", "s3"]
+    rows = [",".join(header)]
+    for i in range(40):
+        ann = '"line one\nline two\n' + "x\n" * 400 + 'end"' if i == 20 else "plain"
+        rows.append(",".join(["g%d" % i, "", ann] + [""] * 11 + ["1", "0" if i % 3 else "1", "1" if i % 2 else ""]))
+    tricky = tmp_path / "tricky.csv"
+    tricky.write_text("\n".join(rows) + "\n")
+    with open(tricky, "r", newline=None) as f:
+        w2 = m.Csv_to_dic_Roary(f, ",", [], startcol=14)
+    got = _sharded_read(str(tricky), 2)
+    for rank in range(2):
+        ids, ann, rows64, strains, sharded = got[rank]
+        assert not sharded                                  # fell back, on both ranks
+        assert ids == list(w2["Roarydic"].ids) and len(ids) == 40
+        assert np.array_equal(rows64, w2["Roarydic"].rows64)
+        assert ann[20].startswith("line one\nline two")

@@ -202,6 +202,33 @@ def test_cli_permute_fisher_empirical_p(exampledir, tmp_path):
             assert d[13] == repr(want), (trait, d[0], d[13], want)
 
 
+def test_cli_permute_early_abort_flag(exampledir, tmp_path):
+    """--permute-early-abort: the Fisher-statistic Empirical_p column follows the
+    reference's sequential rule (scoary/methods.py:1360-1363) -- genes whose running count
+    crosses the binomial bound stop early and get the coarse (r+1)/(i+2), the significant
+    ones still get (r+1)/(P+1); without the flag nothing stops."""
+    P, seed = 300, 99
+    common = _inputs(exampledir) + ["--no_pairwise", "-e", str(P), "--seed", str(seed),
+                                    "-c", "I", "-p", "1.0"]
+    plain = run_cli(common, tmp_path / "a")
+    abort = run_cli(common + ["--permute-early-abort"], tmp_path / "b")
+    rows_p = list(csv.reader(io.StringIO(plain["Tetracycline_resistance.results.csv"])))
+    rows_a = list(csv.reader(io.StringIO(abort["Tetracycline_resistance.results.csv"])))
+    assert rows_p[0] == rows_a[0] and rows_a[0][13] == "Empirical_p"
+    ep = {d[0]: float(d[13]) for d in rows_p[1:]}
+    ea = {d[0]: float(d[13]) for d in rows_a[1:]}
+    assert set(ep) == set(ea)
+    grid = {(r + 1.0) / (P + 1.0) for r in range(P + 1)}
+    assert all(v in grid for v in ep.values())                    # fixed-P estimator
+    coarse = [g for g, v in ea.items() if v not in grid]
+    assert len(coarse) > 100                                       # most genes stop early
+    assert all(ea[g] > 0.1 for g in coarse)                        # only unpromising ones do
+    top = rows_p[1][0]                                             # the best hit never stops
+    assert ea[top] == ep[top] == 1.0 / (P + 1.0)
+    for d in rows_a[1:]:                                           # every other column unchanged
+        assert d[:13] == next(x for x in rows_p[1:] if x[0] == d[0])[:13]
+
+
 def test_permute_call_site_matches_oracle(exampledir):
     from oracle import oracle as orc
     from scoary_amd import methods as m

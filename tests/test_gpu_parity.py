@@ -536,3 +536,62 @@ def test_workspace_and_graph_replay_equal_eager(eng, orc, use_lists):
                           orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, 3).T)
     with pytest.raises(ValueError):
         eng.associate(gm, trv, mkv, permutations=P + 1, seed=3, use_lists=use_lists, workspace=ws)
+
+
+# ------------------------------ opt-in early abort on the Fisher statistic -----
+@pytest.mark.parametrize("G,N,T,P", [(120, 90, 2, 200), (70, 700, 1, 333), (40, 2100, 2, 130)])
+def test_permute_sequential_early_abort_vs_oracle(eng, orc, G, N, T, P):
+    """--permute-early-abort (scoary_permute_seq): the reference's sequential estimator
+    (scoary/methods.py:1348-1365) applied to the Fisher statistic.  The oracle leg states
+    it independently: per permutation the Fisher p of the permuted table (spec-S4 labels)
+    against the observed p, then the reference's loop (oracle.empirical_p_with_abort, which
+    calls binom.cdf per step like the reference).  r, the stopping point and the estimate
+    agree for every (gene, trait); batching the permutations changes nothing."""
+    from scoary_amd import tree as T_
+    rng = np.random.default_rng(G + N + P)
+    genes, traits = _random_case(rng, G, N, T)
+    genes[3] = (rng.random(N) < 0.5).astype(np.uint8)
+    traits[0] = np.where(rng.random(N) < 0.6, genes[3], traits[0])          # one strong association
+    tb, mb = _bits(eng, traits)
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    seed = 31 + P
+    res = eng.associate(gm, trv, mkv, permutations=0)
+    crit = eng.fisher(res["counts"], want_crit=True)[2]
+    thr = T_._abort_thresholds(P)
+    r, nstop = eng.permute_sequential(gm, mkv, res["margins"], crit, P, seed, thr)
+    r = r.cpu().numpy().view(np.uint32)
+    nstop = nstop.cpu().numpy().view(np.uint32)
+    got = (r + 1.0) / (np.where(nstop > 0, nstop, P) + 1.0)
+    counts = res["counts"].cpu().numpy()
+    p_obs = res["p"].cpu().numpy()
+    stopped = 0
+    for t in range(T):
+        npos = int((traits[t] == 1).sum())
+        labels = np.stack([np.unpackbits(orc.perm_labels(seed, t, pi, mb[t], npos, N).view(np.uint8),
+                                         bitorder="little")[:N] for pi in range(P)])      # (P, N)
+        valid = traits[t] != 2
+        a = labels[:, valid].astype(np.int64) @ genes[:, valid].T.astype(np.int64)        # (P, G)
+        for g in range(G):
+            c = counts[t, g]
+            if c[0] + c[2] == 0 or c[1] + c[3] == 0:        # never tested: every permutation "reaches" it
+                flags = np.ones(P, dtype=bool)
+            else:
+                n1, gm_ = c[0] + c[1], c[0] + c[2]
+                tab = np.stack([a[:, g], n1 - a[:, g], gm_ - a[:, g],
+                                c.sum() - n1 - gm_ + a[:, g]], axis=1).astype(np.int32)
+                _, pp = orc.fisher_many(tab)
+                flags = pp <= p_obs[t, g] * (1 + 1e-7)
+            want = orc.empirical_p_with_abort(flags)
+            assert got[t, g] == want, (t, g, got[t, g], want, nstop[t, g])
+            stopped += nstop[t, g] > 0
+    assert 0 < stopped < G * T          # both branches of the estimator occurred
+    # a one-batch run equals a many-batch run (state carried in d_r / d_nstop)
+    small = eng.perm_batch
+    try:
+        eng.perm_batch = lambda T__, N__, P__, budget_bytes=0: 37
+        r2, n2 = eng.permute_sequential(gm, mkv, res["margins"], crit, P, seed, thr)
+    finally:
+        eng.perm_batch = small
+    assert np.array_equal(r2.cpu().numpy().view(np.uint32), r)
+    assert np.array_equal(n2.cpu().numpy().view(np.uint32), nstop)

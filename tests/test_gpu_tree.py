@@ -288,3 +288,32 @@ def test_cli_pairwise_with_tree_permutations(exampledir, tmp_path):
             assert d[18] == repr(orc.empirical_p_with_abort(ex)), (trait, d[0])
             checked += 1
     assert checked >= 5
+
+
+def test_tree_tip_limit_and_large_caterpillar(eng, orc):
+    """pair counts are packed as total << 16 | count; with more than 32767 tips
+    a reachable key could reach 2^30 and pass for "unreachable + reachable".  The largest
+    accepted tree -- a 32767-tip caterpillar with alternating states, the shape that
+    maximises the pair count (16383) -- equals the oracle, and 32768 tips are refused
+    with SCOARY_ERR_SIZE instead of silently computing wrong maxima."""
+    import ctypes
+    import torch
+    from scoary_amd.engine import pack_bits_rows
+    K = 32767
+    ops = np.array([0] + [-2 - i for i in range(1, K)], dtype=np.int32)   # push tip 0; merge-with-tip i
+    g = (np.arange(K) % 2).astype(np.uint8)[None]                          # A a A a ...
+    lab = ((np.arange(K) // 2) % 2).astype(np.uint8)[None]                 # b b B B ...
+    state = np.where(g[0] == 1, np.where(lab[0] == 1, 0, 1), np.where(lab[0] == 1, 2, 3)).astype(np.uint8)
+    orc_ops = np.zeros(2 * K - 1, dtype=np.int32)                          # oracle dialect: push / merge only
+    orc_ops[1::2] = np.arange(1, K)
+    orc_ops[2::2] = -1
+    want = orc.tree_dp(orc_ops, state)
+    assert want[0] > 8000                                                  # thousands of pairs: the packed range
+    Wt = (K + 31) // 32
+    gb = torch.from_numpy(np.ascontiguousarray(pack_bits_rows(g).view(np.uint32)[:, :Wt]).view(np.int32)).cuda()
+    lb = torch.from_numpy(np.ascontiguousarray(pack_bits_rows(lab).view(np.uint32)[:, :Wt]).view(np.int32)).cuda()
+    out = eng.tree_pairs(torch.from_numpy(ops).cuda(), 1, gb, lb, K)
+    assert tuple(int(x) for x in out.cpu().numpy()[0, 0]) == want
+    p = ctypes.c_void_p(gb.data_ptr())
+    rc = eng.lib.scoary_tree_pairs(eng.h, p, 3, 1, p, p, 1, 1, 32768, p, None)
+    assert rc == -3 and b"32767" in eng.lib.scoary_last_error(eng.h)

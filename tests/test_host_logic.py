@@ -124,6 +124,18 @@ def test_non_roary_reader_vcf(exampledir, manifest):
     assert list(gd["Roarydic"]) == json.loads(str(z["all_genes"]))   # duplicate ids collapse
     assert gd["Firstcolnames"] == manifest["vcf_firstcolnames"]
     assert gd["Strains"] == manifest["vcf_strains"]
+    # the tree-building matrix holds every FILE row (8), not the 5 de-duplicated identifiers
+    # (the reference appends each row as it reads it, scoary/methods.py:445-497) -- both readers
+    assert len(gd["Roarydic"]) == 5 and manifest["vcf_file_rows"] == 8
+    assert [list(r) for r in gd["Zero_ones_matrix"]] == manifest["vcf_zero_ones_matrix"]
+    assert gd["Zero_ones_matrix"].file_rows().shape == (8, len(gd["Strains"]))
+    os.environ["SCOARY_PY_CSV"] = "1"
+    try:
+        with open(os.path.join(exampledir, "mutations_presence_absence.csv")) as f:
+            gd2 = m.Csv_to_dic_Roary(f, ",", [], startcol=manifest["vcf_startcol_1based"] - 1)
+    finally:
+        del os.environ["SCOARY_PY_CSV"]
+    assert [list(r) for r in gd2["Zero_ones_matrix"]] == manifest["vcf_zero_ones_matrix"]
 
 
 def test_traits_reader_rejects_bad_input():
@@ -454,7 +466,7 @@ def test_io_library_exports_every_declared_symbol():
         src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(scoary_(?:gpa|lists|vcf|upgma)_[a-z_]+)\s*\(", src)))
     lib = ctypes.CDLL(io_native.LIB_PATH)
-    assert len(names) == 18 and "scoary_vcf_convert" in names and "scoary_upgma_merges" in names
+    assert len(names) == 19 and "scoary_vcf_convert" in names and "scoary_upgma_merges" in names
     for n in names:
         assert hasattr(lib, n), n
 
@@ -561,3 +573,26 @@ def test_native_upgma_equals_numpy_loop_and_reference_goldens():
         cnt, names = counts_of(X), ["s%d" % i for i in range(n)]
         assert T.upgma_from_counts(cnt, X.shape[1], names, native=True) == \
             T.upgma_from_counts(cnt, X.shape[1], names, native=False)
+
+
+# ------------------------------------------------------------- custom trees ----
+def test_read_newick_resolves_polytomies_like_ete3(tmp_path):
+    """-n trees with more than two children per node: the reference calls ete3's
+    resolve_polytomy(recursive=True) (scoary/nwkhandler.py:19), which keeps the first child
+    at the top and nests the rest as a chain of new FIRST children, pairing the last two:
+    (a,b,c) -> [[b, c], a]; also below the root, where the rooted topology matters.  Branch
+    lengths, support values, internal labels and quotes are dropped."""
+    from scoary_amd import tree as T
+    cases = {
+        "(a,b,c);": [["b", "c"], "a"],
+        "(a,b,c,d);": [[["c", "d"], "b"], "a"],
+        "((a,b,c)X:0.1,d);": [[["b", "c"], "a"], "d"],
+        "((a:1,'b b':2,c:3,d)90:0.5,(e,f),g);": [[["e", "f"], "g"], [[["c", "d"], "b b"], "a"]],
+        "(a,(b,c));": ["a", ["b", "c"]],
+    }
+    for text, want in cases.items():
+        p = tmp_path / "t.nwk"
+        p.write_text(text + "\n")
+        got, members = T.read_newick(str(p))
+        assert got == want, text
+        assert sorted(members) == sorted(T.tips_of(got))
