@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libscoary_hip.so")
+# SCOARY_HIP_LIB: an alternative build of the same sources (kernel A/B experiments, tools/ab_lib.sh)
+LIB_PATH = os.environ.get("SCOARY_HIP_LIB") or os.path.join(_HERE, "csrc", "libscoary_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "scoary_hip.h")
 
 ABI_VERSION = 4

@@ -527,11 +527,14 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const int n4 = (int)(list_tile_dwords(N, TW) / 4);   // HBM tiles are padded to 16 bytes
     const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds;
     for (int i = wave * kWave; i < n4; i += nwaves * kWave)
-      if (i + lane < n4)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :
+      if (i + lane < n4) {
+        uint32_t m0_saved;     // M0 is handed back as it was: nothing else may be assumed about it
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_saved)
                      : "s"(lds0 + (uint32_t)i * 16u), "v"(lane_off), "s"(src4 + i)
-                     : "memory", "m0");
+                     : "memory");
+      }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
@@ -590,9 +593,18 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const int64_t gbytes = lidx_bytes - (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 128;
     const __amdgpu_buffer_rsrc_t lists_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<Ent*>(gbase), 0, (int)min(gbytes, (int64_t)0x7fffffff), 0x00020000);
+    // cache policy of the index loads (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1).  "nt"
+    // (non-temporal, evict first) was tried so that the streaming lists stop pushing the XCD's
+    // 25 label tiles out of its 4 MB L2: FETCH_SIZE 2.35 -> 1.93 GB per launch, but the kernel
+    // got 5 % SLOWER (4.46 -> 4.70 ms, profiles/r02_ab_list_load_policy.txt) -- HBM is at 7 %
+    // of its peak here, issue slots are what is scarce.  Default policy stays.
+#ifndef SCOARY_LIST_LOAD_POLICY
+#define SCOARY_LIST_LOAD_POLICY 0
+#endif
+    constexpr int kListLoadPolicy = SCOARY_LIST_LOAD_POLICY;
     auto load_piece = [&](int p) -> Ent {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(lists_rsrc, lane_off,
-                                                            min(p, last) * (kWave * (int)sizeof(Ent)), 0);
+                                                            min(p, last) * (kWave * (int)sizeof(Ent)), kListLoadPolicy);
       return Ent{{v.x, v.y, v.z, v.w}};
     };
     Ent ring[4] = {load_piece(0), load_piece(1), load_piece(2), load_piece(3)};
