@@ -188,7 +188,7 @@ int scoary_permute_lists(scoary_handle h, const uint32_t *d_tiles, const uint32_
  * From the tiled gene matrix already in HBM (no host pass, no PCIe copy of the
  * lists): for every gene the positions of its MINORITY value (ones if popcount <=
  * N/2, else zeros: d_flipped[g] = 1), genes ordered by descending list length
- * (stable), lists padded to 32 entries and to the longest list of their wavefront
+ * (stable), lists padded to 16 entries (half a kernel step) and to the longest list of their wavefront
  * group, the lists of a group interleaved in pieces of `piece` entries, entries in
  * the bank-rotation order of spec S6 (the same layout
  * scoary_lists_build of include/scoary_io.h -- the checker -- produces on the host).

@@ -61,8 +61,9 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
  * (scoary_permute_lists, include/scoary_hip.h).  For every gene row of a
  * rows64 matrix [G][W64] over N isolates: the positions of its MINORITY value
  * (ones if popcount <= N/2, else zeros; flipped[g] = 1 in the latter case),
- * padded with the value N (an all-zero row on the device) to a multiple of 32
- * entries and to the longest list of its wavefront group.  Lists are laid out
+ * padded with the value N (an all-zero row on the device) to a multiple of 16
+ * entries (half a 32-entry step of the kernel) and to the longest list of its
+ * wavefront group.  Lists are laid out
  * back to back in `order`: genes sorted by descending list length, so that the
  * `genes_per_wave` genes a wavefront processes together (slots w*gpw ..) have
  * similar lengths and, after padding, the same number of 32-entry groups.
@@ -85,8 +86,9 @@ void scoary_gpa_meta_copy(scoary_gpa_t g, int32_t *lengths, char *bytes);
  *   second call : scoary_lists_build fills
  *       idx     uint32 [total]   entry = position * row_stride (the LDS byte offset of
  *                                that isolate's label row in the list-driven kernel)
- *       start   int32  [G]       first entry of gene order[k], in groups of 32
- *       ngroups int32  [G]       groups of 32 of gene order[k] (equal within a wave group)
+ *       start   int32  [G]       first entry of gene order[k]: in units of 32 entries
+ *                                (piece > 0, the group base) or of 16 (piece = 0)
+ *       ngroups int32  [G]       half-steps of 16 entries of gene order[k] (equal within a wave group)
  *       order   int32  [G]       gene id of slot k
  *       flipped uint8  [G]       per gene id */
 int64_t scoary_lists_count(const uint64_t *rows64, int64_t G, int64_t N, int64_t genes_per_wave,

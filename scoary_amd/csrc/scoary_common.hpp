@@ -69,7 +69,8 @@ __host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int TW) {
   return ((N + 1) * TW + 3) / 4 * 4;
 }
 
-constexpr int kListPad = 32;        // list lengths are padded to a multiple of this many entries
+constexpr int kListPad = 16;        // list lengths are padded to a multiple of this many entries (half a 32-entry step)
+constexpr int kListStartUnit = 32;  // d_lstart counts in units of this many entries (128 bytes)
 constexpr int kListSlack = 256;     // zero entries after the last list (one wavefront index load)
 
 int fail(scoary_handle h, int code, const std::string& msg) {

@@ -400,7 +400,8 @@ static inline int64_t row_popcount(const uint64_t* r, int64_t W) {
 // Padded length of every list: a multiple of kListPad entries, and equal for the
 // `gpw` genes that share a wavefront (slots w*gpw .. w*gpw+gpw-1 of the
 // length-sorted order), so that the kernel's loop count is wave-uniform.
-static const int64_t kListPad = 32;
+static const int64_t kListPad = 16;         // half a 32-entry step of the kernel
+static const int64_t kListStartUnit = 32;   // start[] of the interleaved layout counts in 32-entry units
 
 static void list_plan(const uint64_t* rows64, int64_t G, int64_t N, int64_t gpw,
                       std::vector<int32_t>& len, std::vector<int32_t>& order,
@@ -472,7 +473,7 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
         const int64_t g = order[k];
         order_out[k] = (int32_t)g;
         ngroups[k] = (int32_t)(padded[k] / kListPad);
-        start[k] = (int32_t)((piece > 0 ? base[q] : base[k]) / kListPad);
+        start[k] = (int32_t)(piece > 0 ? base[q] / kListStartUnit : base[k] / kListPad);
         const uint64_t* r = rows64 + g * W;
         const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
         // Spec S6: the genes of one LDS lane group read the label tile in

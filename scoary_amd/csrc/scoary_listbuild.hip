@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void k_lists_slots(const int32_t* __restrict__
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= G) return;
   const int q = k / gpw;
-  start[k] = (int32_t)(base[q] / kListPad);
-  ngroups[k] = padded[q] / kListPad;
+  start[k] = (int32_t)(base[q] / kListStartUnit);      // gpw * padded is a multiple of 16 * 16
+  ngroups[k] = padded[q] / kListPad;                   // half-steps of 16 entries
 }
 
 // Spec S6, entry order: the listed positions of slot k are ordered by

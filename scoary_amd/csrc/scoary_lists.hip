@@ -543,7 +543,10 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   // LDS object and sits at LDS address 0 (checked on the host: no static LDS in this kernel)
   {
   for (int q = q_lo + wave; q < q_hi; q += nwaves) {
-    const int nsuper = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);   // 32-entry steps
+    // list length of the group in half-steps of 16 entries (lists are padded to 16: a last
+    // half step costs half a step, where padding to 32 made the average list 3 % longer)
+    const int nhalf = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);
+    const int nsuper = (nhalf + 1) >> 1;                               // 32-entry steps, the last maybe half
     // interleaved lists (piece = TW entries): the wavefront's 64 lanes read 64
     // consecutive 16-byte index vectors per piece
     struct alignas(16) Ent { uint32_t e[4]; };
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     // four vectors (a region of four steps is a multiple of four pieces, so the ring
     // slot of every piece is a compile-time constant).  Reads past the end of the
     // list re-read its last piece (valid rows, never summed).
-    const int last = max(nsuper * (8 / LPG) - 1, 0);
+    const int last = max(nhalf * (4 / LPG) - 1, 0);
     int piece = 0;                                   // piece whose vector is ring[piece % 4]
     // buffer load: group base in the resource descriptor (SGPRs), piece offset in the scalar
     // offset, lane offset in one VGPR -- no per-load 64-bit VALU address arithmetic
@@ -635,7 +638,8 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     for (int sg = 0; sg < nsuper; sg += kRegion) {
 #define STEP(K)                                   /* 32 listed isolates */ \
   [&]() -> Carry4 {                                                         \
-    if (sg + (K) >= nsuper) return zero;                                    \
+    const int left = nhalf - 2 * (sg + (K));     /* half-steps left, wave-uniform */ \
+    if (left <= 0) return zero;                                             \
     const Carry4 b0 = SUBSTEP(K, 0, xa, xb);                                \
     const Carry4 b1 = SUBSTEP(K, 1, xb, xa);                                \
     const Carry4 d0 = FA4(2, b0, b1);                                       \
@@ -643,13 +647,16 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     const Carry4 b3 = SUBSTEP(K, 3, xb, xa);                                \
     const Carry4 d1 = FA4(2, b2, b3);                                       \
     const Carry4 e0 = FA4(3, d0, d1);                                       \
-    const Carry4 b4 = SUBSTEP(K, 4, xa, xb);                                \
-    const Carry4 b5 = SUBSTEP(K, 5, xb, xa);                                \
-    const Carry4 d2 = FA4(2, b4, b5);                                       \
-    const Carry4 b6 = SUBSTEP(K, 6, xa, xb);                                \
-    const Carry4 b7 = SUBSTEP(K, 7, xb, xa);                                \
-    const Carry4 d3 = FA4(2, b6, b7);                                       \
-    const Carry4 e1 = FA4(3, d2, d3);                                       \
+    Carry4 e1 = zero;                                                       \
+    if (left > 1) {                              /* the second 16 entries exist */ \
+      const Carry4 b4 = SUBSTEP(K, 4, xa, xb);                              \
+      const Carry4 b5 = SUBSTEP(K, 5, xb, xa);                              \
+      const Carry4 d2 = FA4(2, b4, b5);                                     \
+      const Carry4 b6 = SUBSTEP(K, 6, xa, xb);                              \
+      const Carry4 b7 = SUBSTEP(K, 7, xb, xa);                              \
+      const Carry4 d3 = FA4(2, b6, b7);                                     \
+      e1 = FA4(3, d2, d3);                                                  \
+    }                                                                       \
     return FA4(4, e0, e1);                       /* weight 32 */            \
   }()
 #define QUAD(K0)                                  /* four steps -> carry of weight 128 */ \

@@ -477,7 +477,8 @@ def test_io_library_exports_every_declared_symbol():
                                                        (64, 16, 16, 4), (64, 32, 8, 4), (64, 64, 4, 4)])
 def test_minority_lists_builder(gpw, classes, stride, piece):
     """scoary_lists_build (host native): per gene the positions of its minority
-    value, padded with N to a multiple of 32 and to the wave group's longest list,
+    value, padded with N to a multiple of 16 (half a kernel step; ngroups counts 16s, start of
+    the interleaved layout 32s) and to the wave group's longest list,
     genes ordered by descending length, entries in the bank-rotation order of spec S6
     (entry e of slot k from residue class (k + e) mod classes while every class has
     positions left), entries premultiplied by the row stride;
@@ -500,20 +501,20 @@ def test_minority_lists_builder(gpw, classes, stride, piece):
     for k in range(G):
         g = order[k]
         if piece == 0:
-            ent = L["idx"][start[k] * 32:(start[k] + ng[k]) * 32]
-            assert start[k] * 32 == total
-            total += ng[k] * 32
+            ent = L["idx"][start[k] * 16:(start[k] + ng[k]) * 16]    # contiguous mode: start in 16s
+            assert start[k] * 16 == total
+            total += ng[k] * 16
         else:
             j, base = k % gpw, start[k] * 32
             assert start[k] == start[(k // gpw) * gpw]
             if j == 0:
                 assert base == total
-                total += gpw * ng[k] * 32                           # full groups, also the last
-            e = np.arange(ng[k] * 32)
+                total += gpw * ng[k] * 16                           # full groups, also the last
+            e = np.arange(ng[k] * 16)
             ent = L["idx"][base + ((e // piece) * gpw + j) * piece + e % piece]
         assert ng[k] == ng[(k // gpw) * gpw]                        # equal within a wave group
-        assert ng[k] * 32 >= length[g] and \
-            (ng[(k // gpw) * gpw] * 32 - length[order[(k // gpw) * gpw]]) < 32
+        assert ng[k] * 16 >= length[g] and \
+            (ng[(k // gpw) * gpw] * 16 - length[order[(k // gpw) * gpw]]) < 16
         assert np.all(ent % stride == 0)
         pos = (ent // stride).astype(np.int64)
         real = pos[:length[g]]
@@ -536,7 +537,7 @@ def test_minority_lists_builder(gpw, classes, stride, piece):
         assert np.array_equal(real, want[np.argsort(key)])
     if piece:                                                       # missing genes of the last group
         k0 = (G - 1) // gpw * gpw
-        e = np.arange(ng[k0] * 32)
+        e = np.arange(ng[k0] * 16)
         for j in range(G - k0, gpw):
             ent = L["idx"][start[k0] * 32 + ((e // piece) * gpw + j) * piece + e % piece]
             assert np.all(ent == N * stride)
