@@ -597,3 +597,70 @@ def test_read_newick_resolves_polytomies_like_ete3(tmp_path):
         got, members = T.read_newick(str(p))
         assert got == want, text
         assert sorted(members) == sorted(T.tips_of(got))
+
+
+# ------------------------------------------- build-time kernel checks, counters ----
+_REMARKS = """\
+x.hip:1:1: remark: Function Name: _ZN1A15k_permute_listsILi4ELi4ELi11EEEvPKj [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     TotalSGPRs: 66 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs: %(vgprs)d [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     ScratchSize [bytes/lane]: %(scratch)d [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     Occupancy [waves/SIMD]: 4 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     SGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     VGPRs Spill: %(spill)d [-Rpass-analysis=kernel-resource-usage]
+x.hip:1:1: remark:     LDS Size [bytes/block]: %(lds)d [-Rpass-analysis=kernel-resource-usage]
+"""
+
+
+def test_build_refuses_a_list_kernel_that_spills_or_grew_static_lds():
+    """the register-pinned kernel must fail the BUILD, not the GPU run, when
+    the compiler did not produce what the source assumes (no scratch, <= 128 VGPRs, the label
+    tile as the only LDS object).  The parser reads hipcc's own resource-usage remarks."""
+    import __graft_entry__ as ge
+
+    def report(**kw):
+        vals = dict(vgprs=127, scratch=0, spill=0, lds=0)
+        vals.update(kw)
+        one = _REMARKS % vals
+        return ge.parse_resource_usage("".join(one.replace("Li11E", "Li%dE" % (11 + i)) for i in range(5)))
+
+    ok = report()
+    assert len(ok) == 5 and all(v["VGPRs"] == 127 and v["ScratchSize"] == 0 for v in ok.values())
+    ge.check_kernel_resources(ok)
+    for bad in (dict(scratch=16), dict(spill=3), dict(vgprs=130), dict(lds=64)):
+        with pytest.raises(RuntimeError):
+            ge.check_kernel_resources(report(**bad))
+    with pytest.raises(RuntimeError):                     # an instance went missing
+        ge.check_kernel_resources({k: v for k, v in list(ok.items())[:4]})
+    ge.check_ctr_banks()                                  # the committed register table is consistent
+    # the library that is actually in the tree passed the same check when it was built
+    res_path = ge.HIP_RESOURCES
+    if os.path.exists(res_path):
+        with open(res_path) as f:
+            ge.check_kernel_resources(json.load(f))
+
+
+def test_bench_refuses_counters_of_other_kernel_sources(tmp_path, monkeypatch):
+    """roofline counters come from a profiles/ file that records the hash
+    of the kernel sources it was collected from; a summary of other sources is refused
+    (null + reason), never reported."""
+    import bench
+    sha = bench.kernel_source_sha()
+    assert len(sha) == 64 and sha == bench.kernel_source_sha()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: sha)
+    body = {"k_permute_lists<4, 4, 11>": {"SQ_INSTS_VALU": 3.0e9, "hbm_traffic_bytes_per_launch": 2.4e9},
+            "k_permute_reg<16, 1>": {"SQ_INSTS_VALU": 1.0e10}}
+    (prof / "r09_pmc.json").write_text(json.dumps(dict(body, _meta={"workload": "cfg3", "kernel_source_sha256": "0" * 64})))
+    ctr, why = bench.load_counters("cfg3", True, "k_permute_lists")
+    assert ctr is None and "sha256 mismatch" in why
+    (prof / "r10_pmc.json").write_text(json.dumps(dict(body, _meta={"workload": "cfg3", "kernel_source_sha256": sha})))
+    ctr, why = bench.load_counters("cfg3", True, "k_permute_lists")
+    assert why is None and ctr["SQ_INSTS_VALU"] == 3.0e9 and ctr["source"].endswith("r10_pmc.json")
+    ctr, _ = bench.load_counters("cfg3", True, "k_permute")            # the dense kernel's entry, not the list one
+    assert ctr["SQ_INSTS_VALU"] == 1.0e10
+    assert bench.load_counters("cfg4", True, "k_permute_lists")[0] is None        # other workload
+    ctr, why = bench.load_counters("cfg3", False, "k_permute_lists")              # shape overridden
+    assert ctr is None and "overridden" in why
