@@ -76,6 +76,13 @@ def parse(argv=None):
                          "per-kernel times then come from extra eager steps after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=6.0,
                     help="target wall time of each cpu_baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of a multi-rank run: nccl (= RCCL over xGMI, the real "
+                         "thing) or gloo (host-staged; lets several ranks share ONE GPU with --share-gpu, "
+                         "a functional check of the multi-rank path on a single-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="map rank r to device r %% visible devices instead of requiring one GPU per "
+                         "rank (functional check only: the ranks time-share the device)")
     ap.add_argument("--dry-exchange", action="store_true",
                     help="CPU-only check of the launcher + exchange path (gloo, fabricated "
                          "records, no kernels): what tests/test_dist_gloo.py drives")
@@ -98,7 +105,7 @@ def maybe_relaunch(args):
     if not args.dry_exchange:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
+        if have < (1 if args.share_gpu else args.gpus):
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -422,11 +429,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
+    if args.share_gpu:
+        local_rank %= torch.cuda.device_count()
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if sharded:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from scoary_amd import synth
     from scoary_amd import dist as sdist
@@ -526,7 +538,8 @@ def main():
     eng.set_timing(False)
 
     if sharded:                                      # MAX over ranks
-        tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        tmax = torch.tensor([dt], dtype=torch.float64,
+                            device=eng.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     nval = (traits != 2).sum(1)
@@ -557,7 +570,9 @@ def main():
                        "genes_per_gpu": G, "genes_total": G_total, "isolates": N, "traits": T,
                        "permutations": P, "parallelism": "gene-shard x%d" % world,
                        "hip_graph": bool(graph),
-                       "exchange": ("rccl %s of per-gene records" % exchange.kind) if exchange
+                       "exchange": ("%s %s of per-gene records" % (
+                           "rccl" if args.backend == "nccl" else "gloo (shared-GPU functional check)",
+                           exchange.kind)) if exchange
                        else "none (single GPU)"},
             "rccl_ranks": rccl_ranks,
             # once per data set, outside the timed region: H2D of the packed bits + device tiling +
