@@ -948,14 +948,19 @@ def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Pruned
         # sort key of the filtered set (methods.py:1124-1135); ``keep`` is already
         # in ascending-p order, and every sort is stable
         pos = np.arange(len(keep))
+        if num_threads is not None and int(num_threads) > 1 and len(keep):
+            # --threads n: the reference hands worker k the ranks k, k+n, k+2n, ... and weaves the
+            # workers' results back thread by thread (scoary/methods.py:1076-1078, 1115-1122), so
+            # rows with EQUAL sort keys come out in (rank mod n, rank) order
+            pos = np.lexsort((pos, pos % int(num_threads)))
         if any(m in cutoffs for m in ("I", "B", "BH")):
-            pos = pos[np.argsort(colget["p_v"][keep], kind="stable")]
+            pos = pos[np.argsort(colget["p_v"][keep][pos], kind="stable")]
         elif "EPW" in cutoffs:
-            pos = pos[np.argsort(extra["Pboth"], kind="stable")]
+            pos = pos[np.argsort(np.asarray(extra["Pboth"])[pos], kind="stable")]
         elif "PW" in cutoffs:
-            pos = pos[np.argsort(extra["Plowest"], kind="stable")]
+            pos = pos[np.argsort(np.asarray(extra["Plowest"])[pos], kind="stable")]
         elif "P" in cutoffs:
-            pos = pos[np.argsort(extra["Empirical_p"], kind="stable")]
+            pos = pos[np.argsort(np.asarray(extra["Empirical_p"])[pos], kind="stable")]
         else:
             log.info("No filtration applied")
         pos = pos[:min(num_results, len(keep))]

@@ -253,7 +253,9 @@ def tree_goldens(gd, td, prune, res, manifest):
     # -- default (pairwise) mode CSVs + tree file -----------------------------
     for sub, extra in (("csv_pairwise_default", ["-u"]),
                        ("csv_pairwise_epw", ["-c", "I", "EPW", "-p", "0.05", "0.05"]),
-                       ("csv_pairwise_bh_pw", ["-c", "BH", "PW", "-p", "0.9", "0.05", "-m", "300"])):
+                       ("csv_pairwise_bh_pw", ["-c", "BH", "PW", "-p", "0.9", "0.05", "-m", "300"]),
+                       # the order of equal-p rows depends on --threads (result weave, :1115-1122)
+                       ("csv_pairwise_threads3", ["--threads", "3"])):
         od = tempfile.mkdtemp()
         files = run_cli(["-g", gpa, "-t", tr] + extra, od)
         for fn, text in files.items():

@@ -239,6 +239,20 @@ def test_cli_default_pairwise_mode_vs_reference(exampledir, tmp_path, sub, extra
         want = list(csv.reader(io.StringIO(golden_text("%s/%s.results.csv.gz" % (sub, trait)))))
         assert got[0] == want[0]
         assert len(got) == len(want), (trait, len(got), len(want))
+        # same ORDER of the rows that are exactly tied -- identical 2x2 tables, hence identical p in
+        # either implementation (with --threads the reference's thread weave decides their order,
+        # scoary/methods.py:1115-1122).  Rows of DIFFERENT tables whose p is mathematically equal
+        # (a gene and its complement) sit one ulp apart in SciPy in an arbitrary direction; their
+        # mutual order is rounding noise and is not compared.
+        def by_table(rows):
+            out = {}
+            for r in rows[1:]:
+                out.setdefault(tuple(r[3:7]), []).append(r[0])
+            return out
+        assert by_table(got) == by_table(want), trait
+        gp = [float(r[10]) for r in got[1:]]
+        if "EPW" not in extra and "PW" not in extra:
+            assert all(gp[i] <= gp[i + 1] * (1 + 1e-9) for i in range(len(gp) - 1))
         wi = {r[0]: r for r in want[1:]}
         for r in got[1:]:
             w = wi[r[0]]
@@ -317,3 +331,40 @@ def test_tree_tip_limit_and_large_caterpillar(eng, orc):
     p = ctypes.c_void_p(gb.data_ptr())
     rc = eng.lib.scoary_tree_pairs(eng.h, p, 3, 1, p, p, 1, 1, 32768, p, None)
     assert rc == -3 and b"32767" in eng.lib.scoary_last_error(eng.h)
+
+
+def test_thread_weave_tie_order_given_the_references_p_values(exampledir, tmp_path):
+    """with --threads n the reference hands worker k the ranks k, k+n, ... and
+    weaves the results back thread by thread (scoary/methods.py:1076-1078, 1115-1122), so the
+    order of equal-p rows depends on n.  WHICH rank a gene has among mathematically tied rows
+    is last-ulp noise of SciPy's pmf (a gene and its complement differ by one ulp in an
+    arbitrary direction), so the comparison feeds the REFERENCE'S own p-values (golden
+    --no_pairwise -p 1.0 CSVs) into StoreTraitResult: the whole row order must then equal the
+    reference's `--threads 3` run, and differ from its single-threaded order."""
+    from scoary_amd import methods as m, tree as T
+    with open(os.path.join(exampledir, "Gene_presence_absence.csv"), "r", newline=None) as g, \
+            open(os.path.join(exampledir, "Tetracycline_resistance.csv"), "r", newline=None) as t:
+        gd = m.Csv_to_dic_Roary(g, ",", [], startcol=14)
+        td, prune = m.Csv_to_dic(t, ",", None, gd["Strains"])
+    res = m.Setup_results(gd["Roarydic"], td, False)
+    upgma = T.upgma(m.get_engine(), gd["Zero_ones_matrix"].file_rows(), gd["Strains"])
+    for trait in ("Tetracycline_resistance", "Bogus_trait"):
+        ref = list(csv.reader(io.StringIO(golden_text("csv_no_pairwise/%s.results.csv.gz" % trait))))
+        byname = {r[0]: r for r in ref[1:]}
+        R = res["Results"][trait]
+        assert set(R.genes) == set(byname)
+        for col, k in (("p_v", 10), ("B_p", 11), ("BH_p", 12)):
+            R.cols[col] = np.array([float(byname[gname][k]) for gname in R.genes])
+    out = tmp_path / "w"
+    os.makedirs(out)
+    m.StoreResults(res["Results"], None, {"I": 0.05}, upgma, res["Gene_trait_combinations"], prune,
+                   str(out) + "/", 0, 3, False, gd["Roarydic"], [], gd["Firstcolnames"])
+    for trait in ("Tetracycline_resistance", "Bogus_trait"):
+        with open(out / (trait + ".results.csv"), newline="") as f:
+            got = [r[0] for r in csv.reader(f)][1:]
+        want3 = [r[0] for r in csv.reader(io.StringIO(golden_text(
+            "csv_pairwise_threads3/%s.results.csv.gz" % trait)))][1:]
+        want1 = [r[0] for r in csv.reader(io.StringIO(golden_text(
+            "csv_pairwise_default/%s.results.csv.gz" % trait)))][1:]
+        assert got == want3, trait
+        assert sorted(want1) == sorted(want3) and want1 != want3      # the weave does reorder ties
