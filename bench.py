@@ -531,7 +531,7 @@ def main():
         torch.cuda.synchronize()
     k3_name = "k_permute_lists" if use_lists else "k_permute"
     k3_ms = eng.kernel_ms(k3_name)
-    names = ("k_margins", "k_counts", "k_fisher") + (
+    names = ("k_counts", "k_fisher") + (
         ("k_perm_generate_tiles", "k_lists_crit", "k_permute_lists", "k_lists_reduce") if use_lists else
         ("k_perm_generate", "k_permute"))
     kernel_ms = {k: eng.kernel_ms(k) for k in names}
@@ -580,6 +580,8 @@ def main():
             "setup_ms": setup_ms,
             "value_incl_setup": tests_per_step * args.steps / (dt + setup_ms * 1e-3),
             "value_single_step_incl_setup": tests_per_step / (dt / args.steps + setup_ms * 1e-3),
+            # SURVEY 8d's end-to-end figure: the observed tables count as tests too, G*T*(P+1)
+            "value_incl_observed_tables": G_total * T * (P + 1) * args.steps / dt,
             "roofline": roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms),
             "kernel_ms": kernel_ms,
         }

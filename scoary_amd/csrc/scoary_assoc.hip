@@ -58,48 +58,37 @@ __global__ __launch_bounds__(256) void k_tile_rows(const uint32_t* __restrict__ 
 // ----------------------------------------------------------------------------
 // a3: contingency counts
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_margins(const uint32_t* __restrict__ traits,
-                                                const uint32_t* __restrict__ masks, int Wp,
-                                                int32_t* __restrict__ margins) {
-  const int t = blockIdx.x;
-  int npos = 0, nval = 0;
-  for (int k = threadIdx.x; k < Wp; k += kWave) {
-    npos += __popc(traits[(int64_t)t * Wp + k]);
-    nval += __popc(masks[(int64_t)t * Wp + k]);
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    npos += __shfl_down(npos, off);
-    nval += __shfl_down(nval, off);
-  }
-  if (threadIdx.x == 0) {
-    margins[2 * t] = npos;
-    margins[2 * t + 1] = nval;
-  }
-}
-
 __device__ __forceinline__ int popc4(const uint4 a, const uint4 b) {
   return __popc(a.x & b.x) + __popc(a.y & b.y) + __popc(a.z & b.z) + __popc(a.w & b.w);
 }
 
+__device__ __forceinline__ int popc4(const uint4 a) {
+  return __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w);
+}
+
 // Lane = gene; blockIdx.y = group of TB traits.  Gene quads stream once per
 // trait group (coalesced 16 B / lane); trait and mask quads are wave-uniform
-// (scalar loads).
+// (scalar loads).  The trait margins (positives, valid isolates) are popcounts of the
+// same wave-uniform words, so every block counts them on the scalar unit as it goes
+// and block x = 0 publishes them (a separate k_margins launch before round 2: one
+// launch less on the critical path of launch-bound workloads).
 template <int TB>
 __global__ __launch_bounds__(256) void k_counts(const uint4* __restrict__ tiled,
                                                 const uint32_t* __restrict__ traits,
                                                 const uint32_t* __restrict__ masks,
-                                                const int32_t* __restrict__ margins, int G,
+                                                int32_t* __restrict__ margins, int G,
                                                 int Gp, int Qp, int T, int4* __restrict__ counts) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   const int t0 = blockIdx.y * TB;
   const int Wp = Qp * 4;
-  int a[TB], m[TB];
+  int a[TB], m[TB], npos_[TB], nval_[TB];
   const uint4* trow[TB];
   const uint4* mrow[TB];
 #pragma unroll
   for (int j = 0; j < TB; ++j) {
     a[j] = 0;
     m[j] = 0;
+    npos_[j] = nval_[j] = 0;
     const int t = min(t0 + j, T - 1);
     trow[j] = reinterpret_cast<const uint4*>(traits + (int64_t)t * Wp);
     mrow[j] = reinterpret_cast<const uint4*>(masks + (int64_t)t * Wp);
@@ -108,16 +97,27 @@ __global__ __launch_bounds__(256) void k_counts(const uint4* __restrict__ tiled,
     const uint4 gw = tiled[(int64_t)q * Gp + g];
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
-      a[j] += popc4(gw, trow[j][q]);
-      m[j] += popc4(gw, mrow[j][q]);
+      const uint4 tw = trow[j][q], mw = mrow[j][q];       // wave-uniform
+      a[j] += popc4(gw, tw);
+      m[j] += popc4(gw, mw);
+      npos_[j] += popc4(tw);
+      nval_[j] += popc4(mw);
     }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+      if (t0 + j < T) {
+        margins[2 * (t0 + j)] = npos_[j];
+        margins[2 * (t0 + j) + 1] = nval_[j];
+      }
   }
   if (g >= G) return;
 #pragma unroll
   for (int j = 0; j < TB; ++j) {
     const int t = t0 + j;
     if (t < T) {
-      const int npos = margins[2 * t], nval = margins[2 * t + 1];
+      const int npos = npos_[j], nval = nval_[j];
       counts[(int64_t)t * G + g] =
           make_int4(a[j], npos - a[j], m[j] - a[j], nval - npos - m[j] + a[j]);
     }
@@ -470,11 +470,6 @@ int scoary_counts(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_tr
   DeviceGuard guard(h->device);
   const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  {
-    KernelTimer kt(h, s, "k_margins");
-    hipLaunchKernelGGL(k_margins, dim3((unsigned)T), dim3(kWave), 0, s, d_traits, d_masks,
-                       (int)(Qp * 4), d_margins);
-  }
   constexpr int TB = 4;
   {
     KernelTimer kt(h, s, "k_counts");
