@@ -455,7 +455,8 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
   const int64_t cmask = classes - 1;                 // classes is a power of two
 #pragma omp parallel
   {
-    std::vector<uint32_t> tmp(N + 1), sorted(N + 1), one;   // positions: ascending / by class / as emitted
+    std::vector<uint32_t> tmp(N + 1), sorted(N + 1), one, grid;   // positions: ascending / by class / as emitted / on the grid
+    const uint32_t kNoEntry = 0xffffffffu;
     std::vector<int64_t> first(classes + 1), taken(classes);
 #pragma omp for schedule(dynamic, 8)
     for (int64_t q = 0; q < nwg; ++q) {
@@ -476,15 +477,14 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
         start[k] = (int32_t)(piece > 0 ? base[q] / kListStartUnit : base[k] / kListPad);
         const uint64_t* r = rows64 + g * W;
         const uint64_t inv = flipped[g] ? ~(uint64_t)0 : 0;
-        // Spec S6: the genes of one LDS lane group read the label tile in
-        // lockstep, and a row's bank range is fixed by (isolate index mod classes).  The
-        // listed positions are ordered by rank-within-class * classes + ((class - k) mod
-        // classes), ascending position within a class, and written without gaps: while
-        // every class still has positions, entry e of slot k comes from class (k + e) mod
-        // classes, so the genes of a group sit on distinct bank slots; the tails of the
-        // longer classes keep the rotation order.  Closed form (what the device builder
-        // k_lists_fill evaluates per position):
-        //   entry(c, rho) = sum over c' of min(cnt[c'], rho + [(c'-k) mod C < (c-k) mod C]).
+        // Spec S6: the genes of one LDS lane group read the label tile in lockstep,
+        // and a row's bank range is fixed by (isolate index mod classes).  Position (class c,
+        // rank rho within the class, ascending) belongs on grid slot rho * classes + ((c - k) mod
+        // classes): entry e of slot k then comes from class (k + e) mod classes and the genes of a
+        // group sit on distinct bank slots.  The list has no gaps: positions whose grid slot lies
+        // at or beyond the list length fill, in grid order, the holes below it (slots of classes
+        // that ran dry), in hole order.  (The device builder k_lists_fill finds the same places
+        // in closed form; here the grid is simply built and compacted.)
         std::fill(first.begin(), first.end(), 0);     // counting sort by class
         int64_t nt = 0;
         for (int64_t w = 0; w < W; ++w) {
@@ -504,15 +504,22 @@ void scoary_lists_build(const uint64_t* rows64, int64_t G, int64_t N, int64_t ro
           sorted[taken[tmp[i] & cmask]++] = (uint32_t)(tmp[i] * row_stride);
         const int64_t L = padded[k];
         one.assign(L, zero_row);                      // padding -> the zero row
+        int64_t maxcnt = 0;
+        for (int64_t c = 0; c < classes; ++c) maxcnt = std::max<int64_t>(maxcnt, first[c + 1] - first[c]);
+        grid.assign((size_t)(maxcnt * classes), kNoEntry);
         for (int64_t c = 0; c < classes; ++c) {
           const int64_t dc = (c - k) & cmask;
-          for (int64_t rho = 0; rho < first[c + 1] - first[c]; ++rho) {
-            int64_t e = 0;
-            for (int64_t x = 0; x < classes; ++x) {
-              const int64_t dx = (x - k) & cmask;
-              e += std::min<int64_t>(first[x + 1] - first[x], rho + (dx < dc ? 1 : 0));
-            }
-            one[e] = sorted[first[c] + rho];
+          for (int64_t rho = 0; rho < first[c + 1] - first[c]; ++rho)
+            grid[(size_t)(rho * classes + dc)] = sorted[first[c] + rho];
+        }
+        int64_t hole = 0;                             // next hole below nt
+        for (int64_t e = 0; e < (int64_t)grid.size(); ++e) {
+          if (grid[(size_t)e] == kNoEntry) continue;
+          if (e < nt) {
+            one[e] = grid[(size_t)e];
+          } else {                                    // overflow -> next hole
+            while (grid[(size_t)hole] != kNoEntry) ++hole;
+            one[hole++] = grid[(size_t)e];
           }
         }
         if (piece <= 0) {                             // gene-contiguous

@@ -181,13 +181,18 @@ __global__ __launch_bounds__(256) void k_lists_slots(const int32_t* __restrict__
   ngroups[k] = padded[q] / kListPad;                   // half-steps of 16 entries
 }
 
-// Spec S6, entry order: the listed positions of slot k are ordered by
-//   rank-within-class * C + ((class - k) mod C),     class = position mod C
-// (ascending position within a class) and written without gaps: while every class still
-// has positions, entry e comes from class (k + e) mod C -- the genes of an LDS lane group
-// sit on distinct bank slots -- and the tail of the longer classes keeps the rotation
-// order.  Closed form, so every position finds its entry independently:
-//   entry(class c, rank p) = sum over c' of min(cnt[c'], p + [(c'-k) mod C < (c-k) mod C]).
+// Spec S6, entry order.  Class of a position = position mod C; within a class positions are
+// ranked ascending (rho = 0, 1, ...).  The position (class c, rank rho) belongs on grid slot
+//   e = rho * C + ((c - k) mod C)
+// of list slot k -- entry e then comes from class (k + e) mod C, and the genes of an LDS lane
+// group, whose slots k are consecutive, sit on distinct bank slots at every step.  The list
+// has total = sum of the class counts entries and no gaps: positions whose grid slot is
+// >= total ("overflow": the classes with more positions than average) fill, in grid order,
+// the holes below total (grid slots of classes that have run dry), in hole order.  Everything
+// is closed form -- filled(x) = sum over c' of min(cnt[c'], ceil((x - d(c')) / C)) grid slots
+// below x are occupied -- so every position finds its entry independently: an overflow
+// position of rank ov among the overflow goes to the smallest x with x + 1 - filled(x + 1)
+// = ov + 1 (binary search).  All but the hole entries are aligned.
 // C lanes per slot (lane = class), 64 / C slots per wavefront.
 template <int C>
 __global__ __launch_bounds__(256) void k_lists_fill(const uint4* __restrict__ tiled, int64_t Gp,
@@ -242,6 +247,17 @@ __global__ __launch_bounds__(256) void k_lists_fill(const uint4* __restrict__ ti
   int m = cnt[0];
   for (int x = 1; x < C; ++x) m = min(m, cnt[x]);
   const int dk = (int)((c - k) & (C - 1));
+  (void)m;
+  // grid slots below x that hold a position: class x' owns the slots rho * C + d(x'), rho < cnt[x']
+  auto filled = [&](int x) -> int {
+    int f = 0;
+    for (int xc = 0; xc < C; ++xc) {
+      const int dx = (int)((xc - k) & (C - 1));
+      f += min(cnt[xc], max(0, (x - dx + C - 1) / C));
+    }
+    return f;
+  };
+  const int filled_total = filled(total);
   if (live) {
     int rho = 0;
     for (int qd = 0; qd < Qn; ++qd) {
@@ -253,15 +269,15 @@ __global__ __launch_bounds__(256) void k_lists_fill(const uint4* __restrict__ ti
         while (bits) {
           const int b = __builtin_ctz(bits);
           bits &= bits - 1;
-          int pos;
-          if (rho < m) {
-            pos = rho * C + dk;
-          } else {
-            pos = 0;
-            for (int x = 0; x < C; ++x) {
-              const int dx = (int)((x - k) & (C - 1));
-              pos += min(cnt[x], rho + (dx < dk ? 1 : 0));
+          int pos = rho * C + dk;                    // the position's aligned grid slot
+          if (pos >= total) {                          // overflow: goes to the ov-th hole
+            const int ov = filled(pos) - filled_total;
+            int lo = 0, hi = total - 1;                // smallest x with holes(x + 1) >= ov + 1
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (mid + 1 - filled(mid + 1) >= ov + 1) hi = mid; else lo = mid + 1;
             }
+            pos = lo;
           }
           idx[at(pos)] = (uint32_t)(32 * (4 * qd + w4) + b) * row_stride;
           ++rho;

@@ -373,6 +373,9 @@ class AssociationEngine:
         T = traits.shape[0]
         if use_lists is None:
             use_lists = genes.lists is not None and self.lists_supported(genes.N)
+        if use_lists and permutations > 0 and genes.lists is None:
+            raise ValueError("use_lists=True but the gene matrix has no index lists: call "
+                             "build_lists(genes) once per data set first")
         ws = workspace
         if ws is None:
             ws = Workspace(self, genes, T, permutations, use_lists, perm_buffer)
