@@ -37,7 +37,13 @@
 #include <omp.h>
 #endif
 
-#define ORC_TIE 1e-10 /* relative tie window on recurrence weights (spec S3) */
+/* Spec S3 tie rule = SciPy's: a support point x is "as extreme as observed" iff
+ * w(x) <= w(a_obs) * (1 + 1e-14) -- scipy/stats/_stats_py.py, fisher_exact: epsilon = 1e-14,
+ * gamma = 1 + epsilon.  The fp64 recurrence carries ~2e-16 per step, so a comparison that
+ * comes out within ORC_AMBIG of equality is settled EXACTLY, on big integers (hg_leq_exact):
+ * exact ties (symmetric margins) are ties, and the closest non-equal weights that exist
+ * (1.7e-12 apart at N = 1972, tests/golden/near_ties.json) are told apart. */
+#define ORC_AMBIG 1e-9
 
 /* ------------------------------------------------------------------ S1 -- */
 /* Row-major bit packing: bit i of word w of a row = isolate 64*w + i.      */
@@ -137,6 +143,80 @@ static int64_t hg_weights(int64_t n1, int64_t n2, int64_t n, double *w,
     return lo;
 }
 
+/* ---- exact comparison of two hypergeometric weights -------------------------
+ * Little-endian arrays of 32-bit limbs, multiplied in place by small factors. */
+typedef struct { uint32_t *v; int64_t n, cap; } orc_big;
+static void big_init(orc_big *b, int64_t cap)
+{
+    b->v = (uint32_t *)calloc((size_t)cap, sizeof(uint32_t));
+    b->cap = cap;
+    b->n = 1;
+    b->v[0] = 1;
+}
+static void big_mul(orc_big *b, uint32_t f)
+{
+    uint64_t carry = 0;
+    for (int64_t i = 0; i < b->n; ++i) {
+        uint64_t t = (uint64_t)b->v[i] * f + carry;
+        b->v[i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    if (carry) {
+        if (b->n >= b->cap) abort();             /* sized by the caller: cannot happen */
+        b->v[b->n++] = (uint32_t)carry;
+    }
+}
+static int big_cmp(const orc_big *a, const orc_big *b)
+{
+    int64_t na = a->n, nb = b->n;
+    while (na > 1 && a->v[na - 1] == 0) --na;
+    while (nb > 1 && b->v[nb - 1] == 0) --nb;
+    if (na != nb) return na < nb ? -1 : 1;
+    for (int64_t i = na - 1; i >= 0; --i)
+        if (a->v[i] != b->v[i]) return a->v[i] < b->v[i] ? -1 : 1;
+    return 0;
+}
+/* w(x) <= w(a) * (1 + 1e-14), exactly.  For x > a:  w(x)/w(a) = NUM/DEN with
+ * NUM = prod_{j=a}^{x-1} (n1-j)(n-j),  DEN = prod (j+1)(n2-n+j+1)  (the recurrence of
+ * hg_weights); for x < a the roles of NUM and DEN swap. */
+static int hg_leq_exact(int64_t n1, int64_t n2, int64_t n, int64_t x, int64_t a)
+{
+    if (x == a) return 1;
+    int64_t from = x < a ? x : a, to = x < a ? a : x, k = to - from;
+    orc_big num, den;
+    big_init(&num, 2 * k + 16);                  /* two factors < 2^32 per step, + the constant */
+    big_init(&den, 2 * k + 16);
+    for (int64_t j = from; j < to; ++j) {        /* every factor < 2^32 (N < 2^32) */
+        big_mul(&num, (uint32_t)(n1 - j));
+        big_mul(&num, (uint32_t)(n - j));
+        big_mul(&den, (uint32_t)(j + 1));
+        big_mul(&den, (uint32_t)(n2 - n + j + 1));
+    }
+    /* x > a:  NUM/DEN <= (1e14+1)/1e14  <=>  NUM * 1e14 <= DEN * (1e14+1)
+     * x < a:  DEN/NUM <= (1e14+1)/1e14  <=>  DEN * 1e14 <= NUM * (1e14+1) */
+    orc_big *left = x > a ? &num : &den, *right = x > a ? &den : &num;
+    big_mul(left, 10000000u);                    /* 1e14 = 1e7 * 1e7 */
+    big_mul(left, 10000000u);
+    big_mul(right, 29u);                         /* 1e14 + 1 = 29 * 101 * 281 * 121499449 */
+    big_mul(right, 101u);
+    big_mul(right, 281u);
+    big_mul(right, 121499449u);
+    int r = big_cmp(left, right) <= 0;
+    free(num.v);
+    free(den.v);
+    return r;
+}
+/* w(x) <= w(a) (1 + 1e-14) given the fp64 weights: decided in fp64 when it is clear, exactly
+ * when the two weights agree to ORC_AMBIG. */
+static int hg_leq(const double *w, int64_t lo, int64_t n1, int64_t n2, int64_t n, int64_t x,
+                  int64_t a)
+{
+    double wx = w[x - lo], wa = w[a - lo];
+    if (wx <= wa * (1.0 - ORC_AMBIG)) return 1;
+    if (wx > wa * (1.0 + ORC_AMBIG)) return 0;
+    return hg_leq_exact(n1, n2, n, x, a);
+}
+
 /* Two-sided Fisher exact p and sample odds ratio of [[a, b], [c, d]]
  * (= [[tpgp, tpgn], [tngp, tngn]], methods.py:842-845). */
 void orc_fisher(int64_t a, int64_t b, int64_t c, int64_t d, double *p_out,
@@ -153,11 +233,11 @@ void orc_fisher(int64_t a, int64_t b, int64_t c, int64_t d, double *p_out,
     int64_t cap = (n < n1 ? n : n1) + 2;
     double *w = (double *)malloc((size_t)cap * sizeof(double));
     int64_t len, lo = hg_weights(n1, n2, n, w, &len);
-    double thr = w[a - lo] * (1.0 + ORC_TIE), tot = 0.0, inc = 0.0;
+    double tot = 0.0, inc = 0.0;
     int all = 1;
     for (int64_t i = 0; i < len; ++i) {
         tot += w[i];
-        if (w[i] <= thr)
+        if (hg_leq(w, lo, n1, n2, n, lo + i, a))
             inc += w[i];
         else
             all = 0;
@@ -285,6 +365,29 @@ void orc_permute_r(const uint64_t *genes, const uint64_t *traits,
                 wlo[m] = hg_weights(npos, nneg, m, wtab[m], &len);
             }
         }
+        /* rejection region per gene: first point at or above the mode / last point at or
+         * below it whose weight is <= w(a_obs) (1 + 1e-14) (hg_leq) */
+        int32_t *regL = (int32_t *)malloc((size_t)G * sizeof(int32_t));
+        int32_t *regH = (int32_t *)malloc((size_t)G * sizeof(int32_t));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64)
+#endif
+        for (int64_t g = 0; g < G; ++g) {
+            int32_t m = gm[g];
+            regL[g] = regH[g] = 0;
+            if (!wtab[m]) continue;
+            const double *w = wtab[m];
+            int64_t lo = wlo[m], hi = m < npos ? m : npos, mode = lo;
+            for (int64_t x = lo; x <= hi; ++x)
+                if (w[x - lo] == 1.0) { mode = x; break; }
+            int64_t H = hi + 1, L = lo - 1;
+            for (int64_t x = mode; x <= hi; ++x)
+                if (hg_leq(w, lo, npos, nneg, m, x, aobs[g])) { H = x; break; }
+            for (int64_t x = mode; x >= lo; --x)
+                if (hg_leq(w, lo, npos, nneg, m, x, aobs[g])) { L = x; break; }
+            regL[g] = (int32_t)L;
+            regH[g] = (int32_t)H;
+        }
         for (int64_t p0 = 0; p0 < P; p0 += PB) {
             int64_t nb = P - p0 < PB ? P - p0 : PB;
 #ifdef _OPENMP
@@ -303,15 +406,14 @@ void orc_permute_r(const uint64_t *genes, const uint64_t *traits,
                 if (!wtab[m]) {
                     cnt = (uint32_t)nb;
                 } else {
-                    const double *w = wtab[m];
-                    int64_t lo = wlo[m];
-                    double thr = w[aobs[g] - lo] * (1.0 + ORC_TIE);
+                    /* the acceptance interval (Lb, Hb) of a under spec S3, then: in the
+                     * region <=> a <= Lb or a >= Hb (weights are unimodal) */
                     for (int64_t j = 0; j < nb; ++j) {
                         const uint64_t *lr = labs + j * W;
                         int32_t a = 0;
                         for (int64_t k = 0; k < W; ++k)
                             a += __builtin_popcountll(gr[k] & lr[k]);
-                        cnt += w[a - lo] <= thr;
+                        cnt += (a <= regL[g] || a >= regH[g]);
                     }
                 }
                 r_out[g * T + t] += cnt;
@@ -323,6 +425,8 @@ void orc_permute_r(const uint64_t *genes, const uint64_t *traits,
         free(wlo);
         free(gm);
         free(aobs);
+        free(regL);
+        free(regH);
     }
     free(labs);
 }

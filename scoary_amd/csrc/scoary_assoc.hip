@@ -137,6 +137,55 @@ __device__ __forceinline__ double w_down(double w, int x, int n1, int n2, int n)
   return w * ((double)x * (double)(n2 - n + x)) / ((double)(n1 - x + 1) * (double)(n - x + 1));
 }
 
+// ---- spec S3 tie rule: w(x) <= w(a) * (1 + 1e-14), SciPy's gamma ------------------------
+// The fp64 recurrence carries ~2e-16 of error per step, so a comparison that comes out within
+// kAmbig of equality is redone in double-double arithmetic (~1e-31 per step): the ratio
+// w(x)/w(a) is the product of the recurrence's step ratios between the two points; they sit on
+// opposite sides of the mode, so the product is taken from both ends -- the next factor > 1
+// while the running value is <= 1, the next factor < 1 otherwise -- and never leaves the
+// range of the factors.  Exact ties (symmetric margins) come out as 1 to ~1e-28 and are ties;
+// the closest non-equal weights there are (1.7e-12 apart at N = 1972; 6.1e-12 at N = 10 000,
+// tests/golden/near_ties.json) are told apart.  The oracle settles the same comparisons on
+// big integers.
+struct DD { double hi, lo; };
+__device__ __forceinline__ DD dd_mul_d(DD a, double b) {
+  const double p = a.hi * b;
+  double e = fma(a.hi, b, -p);          // a.hi * b = p + e exactly
+  e += a.lo * b;
+  const double s = p + e;
+  return {s, e - (s - p)};
+}
+__device__ __forceinline__ DD dd_div_d(DD a, double b) {
+  const double q1 = a.hi / b;
+  const double p = q1 * b;
+  const double e = fma(q1, b, -p);      // q1 * b = p + e exactly
+  const double r = ((a.hi - p) - e) + a.lo;
+  const double q2 = r / b;
+  const double s = q1 + q2;
+  return {s, q2 - (s - q1)};
+}
+constexpr double kAmbig = 1e-9;
+constexpr double kGamma = 1.0 + 1e-14;  // scipy/stats/_stats_py.py fisher_exact: gamma = 1 + epsilon
+__device__ __noinline__ bool hg_leq_dd(int n1, int n2, int n, int x, int a) {
+  if (x == a) return true;
+  int i = min(x, a), j = max(x, a) - 1;  // step ratios i .. j still to be multiplied in
+  DD R = {1.0, 0.0};                     // -> w(max) / w(min)
+  while (i <= j) {
+    const int t = R.hi <= 1.0 ? i++ : j--;
+    R = dd_mul_d(R, (double)(n1 - t) * (double)(n - t));            // both products are exact
+    R = dd_div_d(R, (double)(t + 1) * (double)(n2 - n + t + 1));
+  }
+  if (x > a) return R.hi < kGamma || (R.hi == kGamma && R.lo <= 0.0);   // w(x)/w(a) = R <= gamma
+  const DD G = dd_mul_d(R, kGamma);                                      // w(x)/w(a) = 1/R <= gamma
+  return G.hi > 1.0 || (G.hi == 1.0 && G.lo >= 0.0);                     //   <=>  gamma * R >= 1
+}
+// w(x) <= w(a) (1 + 1e-14), given the fp64 weights w = w(x), wobs = w(a)
+__device__ __forceinline__ bool hg_leq(double w, double wobs, int n1, int n2, int n, int x, int a) {
+  if (w <= wobs * (1.0 - kAmbig)) return true;
+  if (w > wobs * (1.0 + kAmbig)) return false;
+  return hg_leq_dd(n1, n2, n, x, a);
+}
+
 __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, int64_t M,
                                                double* __restrict__ p_out,
                                                double* __restrict__ or_out,
@@ -163,7 +212,8 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
     for (int x = mode; x < a; ++x) w = w_up(w, x, n1, n2, n);
   else
     for (int x = mode; x > a; --x) w = w_down(w, x, n1, n2, n);
-  const double thr = w * (1.0 + kTie);
+  const double wobs = w;
+  const double thr = w;                  // (only the 2^-90 tail cut below still uses it)
 
   // Both walks stop once a term is inside the rejection region AND below
   // 2^-90 of the observed table's weight: what is left of the
@@ -176,7 +226,7 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
   w = 1.0;
   for (int x = mode; x <= hi; ++x) {
     tot += w;
-    if (w <= thr) {
+    if (hg_leq(w, wobs, n1, n2, n, x, a)) {
       inc += w;
       if (H > hi) H = x;
       if (w < tiny) break;
@@ -187,7 +237,7 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
   for (int x = mode; x > lo; --x) {
     w = w_down(w, x, n1, n2, n);  // weight of x-1
     tot += w;
-    if (w <= thr) {
+    if (hg_leq(w, wobs, n1, n2, n, x - 1, a)) {
       inc += w;
       if (L < lo) L = x - 1;
       if (w < tiny) break;

@@ -32,7 +32,6 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kGeneAlign = 256;
-constexpr double kTie = 1e-10;             // spec S3: relative tie window
 constexpr uint32_t kPermDomain = 0x53434F41u;  // "SCOA", spec S4
 
 // Row sizes (in quads of four 32-bit words) for which a gene row is held

@@ -50,13 +50,60 @@ def exact_p(n1, n2, n, a, tie):
     return Fraction(sum(w for w in ws if w <= thr), sum(ws))
 
 
+def tables_for(case):
+    """Exact two-sided p of the two tables of a pair (observed = x, observed = y) under the
+    strict rule and under the tie windows 1e-14 (SciPy, = spec S3) and 1e-10 (spec S3 of
+    round 1)."""
+    n1, n2, n = case["n1"], case["n2"], case["n"]
+    out = []
+    for a in (case["x"], case["y"]):
+        p_strict = exact_p(n1, n2, n, a, Fraction(0))
+        p_10 = exact_p(n1, n2, n, a, Fraction(1, 10 ** 10))
+        p_14 = exact_p(n1, n2, n, a, Fraction(1, 10 ** 14))
+        out.append({"a": a, "b": n1 - a, "c": n - a, "d": n2 - n + a,
+                    "p_strict": float(p_strict), "p_tie_1e-10": float(p_10),
+                    "p_tie_1e-14": float(p_14), "rules_agree": p_10 == p_14})
+    return out
+
+
+def add_tables(out, explicit):
+    """Tables for the closest pairs of the explicitly listed sizes (N <= 2100: the big-integer
+    sums are cheap) and for EVERY pair inside the (1e-14, 1e-10) band, whatever its N."""
+    for case in out["cases"]:
+        inside = 1e-14 < abs(case["rel_gap"]) < 1e-10
+        if inside or (case["N"] in explicit and case["N"] <= 2100):
+            if not case["tables"]:
+                case["tables"] = tables_for(case)
+    out["pairs_inside_band"] = sum(1 for c in out["cases"] if 1e-14 < abs(c["rel_gap"]) < 1e-10)
+    # keep the fixture small: the closest gap per population size for the record, the pairs
+    # themselves only where they carry tables
+    per_n = dict(out.get("closest_per_N", {}))
+    for c in out["cases"]:
+        k = str(c["N"])
+        if k not in per_n or abs(c["rel_gap"]) < per_n[k]:
+            per_n[k] = abs(c["rel_gap"])
+    out["closest_per_N"] = per_n
+    out["cases"] = [c for c in out["cases"] if c["tables"]]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--tables-only", action="store_true",
+                    help="keep the census of an existing near_ties.json, (re)compute the exact tables")
     ap.add_argument("--sizes", default=",".join(str(s) for s in SIZES))
     ap.add_argument("--all-up-to", type=int, default=0,
                     help="additionally walk EVERY N from 4 to this value (minutes to hours)")
     args = ap.parse_args()
     explicit = set(int(s) for s in args.sizes.split(",") if s)
+    if args.tables_only:
+        with open(os.path.join(HERE, "near_ties.json")) as f:
+            out = json.load(f)
+        add_tables(out, explicit)
+        with open(os.path.join(HERE, "near_ties.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        print("tables:", sum(len(c["tables"]) for c in out["cases"]), "pairs inside the band:",
+              out["pairs_inside_band"])
+        return 0
     sizes = sorted(set(list(explicit) +
                        list(range(4, args.all_up_to + 1))))
     exe = build()
@@ -85,18 +132,10 @@ def main():
                 continue
             kept += 1
             case = {"N": N, "n1": n1, "n2": n2, "n": n, "x": x, "y": y, "rel_gap": g, "tables": []}
-            if N in explicit and N <= 2100:     # exact p-values: the big-integer sums are cheap up to here
-                for a in (x, y):
-                    p_strict = exact_p(n1, n2, n, a, Fraction(0))
-                    p_s3 = exact_p(n1, n2, n, a, Fraction(1, 10 ** 10))
-                    p_scipy = exact_p(n1, n2, n, a, Fraction(1, 10 ** 14))
-                    case["tables"].append({"a": a, "b": n1 - a, "c": n - a, "d": n2 - n + a,
-                                           "p_strict": float(p_strict), "p_tie_1e-10": float(p_s3),
-                                           "p_tie_1e-14": float(p_scipy),
-                                           "rules_agree": p_s3 == p_scipy})
             out["cases"].append(case)
         print("N=%d: %d candidate pairs below %s, closest %s" % (
             N, len(rows), BAND, ("%.3e" % rows[0][0]) if rows else "none"), flush=True)
+    add_tables(out, explicit)
     if overall:
         out["closest_overall"] = dict(zip(("rel_gap", "N", "n1", "n2", "n", "x", "y"), overall))
     with open(os.path.join(HERE, "near_ties.json"), "w") as f:

@@ -595,3 +595,32 @@ def test_permute_sequential_early_abort_vs_oracle(eng, orc, G, N, T, P):
         eng.perm_batch = small
     assert np.array_equal(r2.cpu().numpy().view(np.uint32), r)
     assert np.array_equal(n2.cpu().numpy().view(np.uint32), nstop)
+
+
+def test_fisher_on_the_near_tie_census_tables(eng):
+    """k_fisher on the closest non-equal weight pairs there are (tests/golden/near_ties.json,
+    exhaustive census with exact-rational p-values; 34 of the pairs are closer than 1e-10
+    without being equal): p equals the exact p under spec S3's rule -- SciPy's 1 + 1e-14,
+    decided in double-double arithmetic when the fp64 weights agree to 1e-9 -- to 1e-12, and
+    the rejection regions separate the two points of every pair the way the exact rule does."""
+    import torch
+    with open(os.path.join(GOLDEN, "near_ties.json")) as f:
+        d = json.load(f)
+    tabs, want = [], []
+    for c in d["cases"]:
+        for t in c["tables"]:
+            tabs.append([t["a"], t["b"], t["c"], t["d"]])
+            want.append(t["p_tie_1e-14"])
+    assert len(tabs) == 104
+    p, _, crit = eng.fisher(torch.tensor(tabs, dtype=torch.int32, device="cuda"), want_crit=True)
+    assert np.max(np.abs(p.cpu().numpy() - np.array(want))) < P_TOL
+    crit = crit.cpu().numpy().view(np.uint32)
+    k = 0
+    for c in d["cases"]:
+        for t in c["tables"]:
+            base, span = int(crit[k, 0]), int(crit[k, 1])
+            other = c["y"] if t["a"] == c["x"] else c["x"]
+            bigger_other = (c["rel_gap"] > 0) == (other == c["y"])     # is the partner's weight the larger one?
+            in_region = not (base <= other < base + span)
+            assert in_region == (not bigger_other), (c, t, base, span)
+            k += 1
