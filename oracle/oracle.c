@@ -22,7 +22,7 @@
  *
  * Third-party arithmetic: scipy.stats.fisher_exact is not part of the
  * reference tree.  Its published two-sided rule is restated here in "set"
- * form:   p = sum{ pmf(x) : pmf(x) <= pmf(a_obs) * (1 + TIE) } over the
+ * form:   p = sum{ pmf(x) : pmf(x) <= pmf(a_obs) * (1 + 1e-14) } over the
  * hypergeometric support, min(p, 1); (nan, 1.0) when a margin is zero; sample
  * odds ratio a*d/(b*c), inf when b*c == 0.  pmf ratios come from the exact
  * recurrence  w(x+1)/w(x) = (n1-x)(n-x) / ((x+1)(n2-n+x+1))  normalised at the
@@ -323,7 +323,7 @@ void orc_perm_labels(uint64_t seed, uint32_t t, uint32_t pi,
 
 /* ------------------------------------------------------------------ S5 -- */
 /* r[g][t] = #{ pi < P : the permuted table is as or less probable than the
- * observed one }, i.e. w(a_pi) <= w(a_obs) * (1 + TIE) under the (gene, trait)
+ * observed one }, i.e. w(a_pi) <= w(a_obs) * (1 + 1e-14) under the (gene, trait)
  * margins -- the rejection region of the two-sided Fisher test, so
  * "p_pi <= p_obs".  Empirical p = (r+1)/(P+1) (methods.py:1365).  Genes the
  * reference skips (all-absent / all-present among valid isolates,

@@ -153,7 +153,7 @@ def test_fisher_golden_grid(eng):
 
 def test_fisher_vs_oracle_and_rejection_region(eng, orc):
     """p within 1e-12 of the oracle; the (base, span) rejection region equals
-    the set {x : w(x) <= w(a_obs)(1+TIE)} computed from the oracle's p-values."""
+    the set {x : w(x) <= w(a_obs)(1 + 1e-14)} computed from the oracle's p-values."""
     import torch
     rng = np.random.default_rng(12)
     tabs = []
