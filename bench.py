@@ -173,9 +173,9 @@ def cpu_baseline_port(genes, traits, N, seed, target_s):
     mb = pack_bits_rows((traits != 2).astype(np.uint8))
     orc.permute_r(gb, tb, mb, N, 64, seed)             # warm the thread pool / caches
     t0 = time.perf_counter()
-    orc.permute_r(gb, tb, mb, N, 1024, seed)
+    orc.permute_r(gb, tb, mb, N, 4096, seed)
     probe = time.perf_counter() - t0
-    rate = Gs * T * 1024 / probe
+    rate = Gs * T * 4096 / probe
     Ps = int(max(64, min(400000, target_s * rate / (Gs * T))))
     t0 = time.perf_counter()
     orc.permute_r(gb, tb, mb, N, Ps, seed)
@@ -586,12 +586,13 @@ def main():
             "kernel_ms": kernel_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
+            port = cpu_baseline_port(genes, traits, N, seed, args.cpu_seconds)
             try:
                 out["cpu_baseline"] = cpu_baseline_scipy(eng, genes, traits, N, seed, args.cpu_seconds)
             except Exception as e:                        # the GPU line must not die with the CPU leg
                 out["cpu_baseline"] = {"value": None, "kind": "scipy-restatement",
                                        "error": "%s: %s" % (type(e).__name__, e)}
-            out["cpu_baseline_port"] = cpu_baseline_port(genes, traits, N, seed, args.cpu_seconds)
+            out["cpu_baseline_port"] = port
         print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()
