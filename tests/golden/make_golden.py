@@ -406,6 +406,54 @@ def synth2(manifest):
         gz_write(text, os.path.join(HERE, "synth2", "semicolon", fn + ".gz"))
 
 
+def neartie(manifest):
+    """Third data set: the closest near-tie the census found (tests/golden/near_ties.json): 1972
+    isolates, trait A with 750 positives, trait B with 756.  Under trait A the genes nt_x / nt_y
+    (756 carriers, 282 / 293 of them positive) sit on two support points whose hypergeometric
+    weights differ by 1.7e-12 without being equal; under trait B the genes nt_u / nt_v (750
+    carriers) are the row/column-swapped pair.  SciPy -- hence the reference -- tells the points
+    apart; a tie window wider than 1.7e-12 does not (p 0.6334 instead of 0.6002).  Plus a few
+    ordinary genes.  The reference's --no_pairwise CSVs are the golden output."""
+    N = 1972
+    iso = ["s%04d" % i for i in range(N)]
+    tA = np.zeros(N, dtype=int); tA[:750] = 1
+    tB = np.zeros(N, dtype=int); tB[:756] = 1
+
+    def gene(pos_in, neg_in, trait):
+        g = np.zeros(N, dtype=int)
+        pos, neg = np.nonzero(trait == 1)[0], np.nonzero(trait == 0)[0]
+        g[pos[:pos_in]] = 1
+        g[neg[:neg_in]] = 1
+        return g
+    genes = {"nt_x": gene(282, 474, tA), "nt_y": gene(293, 463, tA),
+             "nt_u": gene(282, 468, tB), "nt_v": gene(293, 457, tB)}
+    rng = np.random.default_rng(1972)
+    for k in range(6):
+        genes["bg_%d" % k] = (rng.random(N) < rng.uniform(0.1, 0.9)).astype(int)
+    meta = ["Gene", "Non-unique Gene name", "Annotation", "No. isolates", "No. sequences",
+            "Avg sequences per isolate", "Genome Fragment", "Order within Fragment",
+            "Accessory Fragment", "Accessory Order with Fragment", "QC", "Min group size nuc",
+            "Max group size nuc", "Avg group size nuc"]
+    lines = [",".join(meta + iso)]
+    for name, g in genes.items():
+        lines.append(",".join([name, "", "near-tie census"] + ["1"] * 11 + ["x" if v else "" for v in g]))
+    gpa_text = "\n".join(lines) + "\n"
+    tr_text = ",A,B\n" + "".join("%s,%d,%d\n" % (iso[i], tA[i], tB[i]) for i in range(N))
+    tmp = tempfile.mkdtemp()
+    gpa, tr = os.path.join(tmp, "gpa.csv"), os.path.join(tmp, "traits.csv")
+    with open(gpa, "w") as f:
+        f.write(gpa_text)
+    with open(tr, "w") as f:
+        f.write(tr_text)
+    gz_write(gpa_text, os.path.join(HERE, "neartie", "gpa.csv.gz"))
+    gz_write(tr_text, os.path.join(HERE, "neartie", "traits.csv.gz"))
+    od = tempfile.mkdtemp()
+    files = run_cli(["-g", gpa, "-t", tr, "--no_pairwise", "-p", "1.0"], od)
+    for fn, text in files.items():
+        gz_write(text, os.path.join(HERE, "neartie", fn + ".gz"))
+    manifest["neartie_files"] = sorted(files)
+
+
 def vcf_cli(manifest):
     """The non-Roary path through the command line: vcf2scoary output + `-s`."""
     tmp = tempfile.mkdtemp()
@@ -527,6 +575,7 @@ def main():
 
     tree_goldens(gd, td, prune, res, manifest)
     vcf_cli(manifest)
+    neartie(manifest)
 
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -395,3 +395,24 @@ def test_cli_vcf_table_with_start_col(exampledir, tmp_path, manifest):
         assert g[0] == w[0] and len(g) == len(w)
         # all rows tie at p = 1 / 0.5 here; compare as sets of rows
         assert sorted(g[1:]) == sorted(w[1:])
+
+
+def test_cli_near_tie_dataset_vs_reference(tmp_path):
+    """tests/golden/neartie: the closest near-tie of the census as a data set, run through the
+    REFERENCE (SciPy 1.15.3) by make_golden.py.  Under trait A the genes nt_x / nt_y sit on two
+    support points whose weights differ by 1.7e-12: SciPy -- the reference -- gives them
+    different p-values (0.6002 / 0.6334); a tie window wider than that gap would give both
+    0.6334.  Every cell of both CSVs within the usual tolerance."""
+    d = tmp_path / "in"
+    os.makedirs(d)
+    for fn in ("gpa.csv", "traits.csv"):
+        with open(d / fn, "w", newline="") as f:
+            f.write(golden_text("neartie/%s.gz" % fn))
+    files = run_cli(["-g", str(d / "gpa.csv"), "-t", str(d / "traits.csv"), "--no_pairwise",
+                     "-p", "1.0"], tmp_path / "out")
+    for trait, pair in (("A", ("nt_x", "nt_y")), ("B", ("nt_u", "nt_v"))):
+        got, want = files[trait + ".results.csv"], golden_text("neartie/%s.results.csv.gz" % trait)
+        _assert_csv_equal(got, want)
+        rows = {r[0]: r for r in csv.reader(io.StringIO(got))}
+        px, py = float(rows[pair[0]][10]), float(rows[pair[1]][10])
+        assert abs(px - 0.6002069089625) < 1e-12 and abs(py - 0.6333635751133) < 1e-12
