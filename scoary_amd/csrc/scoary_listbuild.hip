@@ -244,10 +244,7 @@ __global__ __launch_bounds__(256) void k_lists_fill(const uint4* __restrict__ ti
   s_cnt[tid] = my_cnt;
   __syncthreads();
   const int32_t* cnt = s_cnt + (tid - c);    // the C class counts of this slot
-  int m = cnt[0];
-  for (int x = 1; x < C; ++x) m = min(m, cnt[x]);
   const int dk = (int)((c - k) & (C - 1));
-  (void)m;
   // grid slots below x that hold a position: class x' owns the slots rho * C + d(x'), rho < cnt[x']
   auto filled = [&](int x) -> int {
     int f = 0;
