@@ -251,6 +251,7 @@ class Exchange:
     def __init__(self, torch, eng, world, rank, T, G, bounds=None):
         from scoary_amd import dist as sdist
         self.sdist, self.world, self.rank, self.G = sdist, world, rank, G
+        self.eng = eng if hasattr(eng, "lib") else None
         # weak scaling: every rank sends G genes (G*world in all); strong: shard_bounds(G)
         self.total = G * world if bounds is None else bounds[-1][1]
         self.pending, self.step_no, self.kind = [], 0, "gather"
@@ -267,7 +268,10 @@ class Exchange:
     def submit(self, res):
         sdist = self.sdist
         self.drain(keep=1)
-        rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
+        if self.eng is not None and hasattr(self.eng, "pack_records"):
+            rec = self.eng.pack_records(res)              # one kernel (scoary_pack_records)
+        else:                                             # CPU tensors (gloo tests)
+            rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
         if self.kind == "gather":
             try:
                 _, finish = sdist.gather_genes(rec, self.total, dst=0, async_op=True,

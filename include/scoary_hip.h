@@ -286,6 +286,17 @@ int scoary_tree_permute(scoary_handle h, const int32_t *d_ops, int64_t nops,
 int scoary_row_hash(scoary_handle h, const uint32_t *d_tiled, const uint32_t *d_masks,
                     int64_t G, int64_t T, int64_t N, uint64_t *d_out, scoary_stream_t stream);
 
+/* ---- result records for the one exchange step of the path --------------
+ * The reference weaves per-gene result dicts back from its worker processes
+ * (scoary/methods.py:1115-1122); here every rank packs its shard into fixed records and
+ * one RCCL gather / all-gather moves them (scoary_amd/dist.py):
+ *   d_rec[i] = { tpgp, tpgn, tngp, tngn, p lo, p hi, odds lo, odds hi, r, nstop }
+ * (uint32 [M][10], bit patterns preserved) for the M = T * G_shard (trait, gene) pairs of
+ * d_counts [M][4] / d_p / d_odds / d_r / d_nstop; d_r and d_nstop may be NULL (zeros). */
+int scoary_pack_records(scoary_handle h, const int32_t *d_counts, const double *d_p,
+                        const double *d_odds, const uint32_t *d_r, const uint32_t *d_nstop,
+                        int64_t M, uint32_t *d_rec, scoary_stream_t stream);
+
 /* ---- hipGraph capture ----------------------------------------------------------
  * Small workloads are launch-bound (BASELINE configs[1]: six kernels, 0.14 ms).
  * scoary_graph_begin puts `stream` into capture mode; every scoary_* call made on

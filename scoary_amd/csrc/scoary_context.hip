@@ -71,6 +71,48 @@ int scoary_last_kernel_ms(scoary_handle h, const char* kernel, double* ms_out) {
   return SCOARY_OK;
 }
 
+// ---- per-gene result records for the exchange step --------------------
+// rec[t][g] = { tpgp, tpgn, tngp, tngn, p (2 words), odds (2 words), r, nstop }: the ten
+// int32 words every rank sends to rank 0 (RCCL gather) -- one fused pass instead of a chain
+// of tensor reshapes / copies / a concatenation on the host side.
+extern "C++" {
+namespace {
+__global__ __launch_bounds__(256) void k_pack_records(const int4* __restrict__ counts,
+                                                      const double* __restrict__ p,
+                                                      const double* __restrict__ odds,
+                                                      const uint32_t* __restrict__ r,
+                                                      const uint32_t* __restrict__ nstop,
+                                                      int64_t M, uint32_t* __restrict__ rec) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const int4 c = counts[i];
+  const uint64_t pb = (uint64_t)__double_as_longlong(p[i]), ob = (uint64_t)__double_as_longlong(odds[i]);
+  uint32_t* o = rec + i * 10;
+  o[0] = (uint32_t)c.x; o[1] = (uint32_t)c.y; o[2] = (uint32_t)c.z; o[3] = (uint32_t)c.w;
+  o[4] = (uint32_t)pb; o[5] = (uint32_t)(pb >> 32);
+  o[6] = (uint32_t)ob; o[7] = (uint32_t)(ob >> 32);
+  o[8] = r ? r[i] : 0u;
+  o[9] = nstop ? nstop[i] : 0u;
+}
+}  // namespace
+}  // extern "C++"
+
+int scoary_pack_records(scoary_handle h, const int32_t* d_counts, const double* d_p,
+                        const double* d_odds, const uint32_t* d_r, const uint32_t* d_nstop,
+                        int64_t M, uint32_t* d_rec, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_counts || !d_p || !d_odds || !d_rec || M < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_pack_records: bad argument");
+  if ((M + 255) / 256 > 0x7fffffffLL) return fail(h, SCOARY_ERR_SIZE, "scoary_pack_records: M too large");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_pack_records");
+  hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const int4*>(d_counts), d_p, d_odds, d_r, d_nstop, M, d_rec);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
 // ---- hipGraph capture of a launch sequence (small, launch-bound workloads) ----
 struct scoary_graph {
   hipGraph_t graph = nullptr;

@@ -439,6 +439,22 @@ class AssociationEngine:
             self._check(rc, "scoary_graph_end")
         return StepGraph(self, g, stream), res
 
+    def pack_records(self, res, nstop=None, out=None):
+        """The exchange records of one associate() result (scoary_pack_records): int32
+        device tensor [T, G, 10] = counts, p, odds, r, nstop -- the layout of
+        scoary_amd.dist.pack_records, produced by one kernel."""
+        torch = _torch()
+        T, G = res["p"].shape
+        if out is None:
+            out = self._empty((T, G, 10), torch.int32)
+        r = res.get("r")
+        self._check(self.lib.scoary_pack_records(
+            self.h, self._ptr(res["counts"]), self._ptr(res["p"]), self._ptr(res["odds"]),
+            self._ptr(r) if r is not None else None,
+            self._ptr(nstop) if nstop is not None else None, T * G, self._ptr(out),
+            self._stream()), "scoary_pack_records")
+        return out
+
     # -- --collapse support (SURVEY 8f-4) -----------------------------------------
     def row_hash(self, genes, masks):
         """(T, G, 2) uint64 numpy: 128-bit hash of every gene row AND each

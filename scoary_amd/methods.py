@@ -615,9 +615,10 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
             crit = eng.fisher(res["counts"], want_crit=True)[2]
             r, nstop = eng.permute_sequential(gm, mkv, res["margins"], crit, permutations, seed,
                                               T_._abort_thresholds(permutations))
-            return dist.pack_records(res["counts"], res["p"], res["odds"], r, nstop)
+            res["r"] = r
+            return eng.pack_records(res, nstop=nstop)
         res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed)
-        return dist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
+        return eng.pack_records(res)
 
     out = dist.numpy_records(dist.associate_sharded(local, G))
     if permutations <= 0:

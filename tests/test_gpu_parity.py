@@ -624,3 +624,25 @@ def test_fisher_on_the_near_tie_census_tables(eng):
             in_region = not (base <= other < base + span)
             assert in_region == (not bigger_other), (c, t, base, span)
             k += 1
+
+
+def test_pack_records_kernel_equals_the_host_side_packing(eng):
+    """scoary_pack_records (one kernel) writes the same [T, G, 10] int32 records as
+    scoary_amd.dist.pack_records (tensor ops; what the gloo tests use) -- bit patterns of p /
+    odds preserved, r / nstop optional -- and unpack_records inverts it."""
+    import torch
+    from scoary_amd import dist as sd
+    rng = np.random.default_rng(3)
+    genes, traits = _random_case(rng, 700, 300, 3)
+    tb, mb = _bits(eng, traits)
+    gm = eng.pack_dense(genes)
+    res = eng.associate(gm, eng.vecrows(tb, 300), eng.vecrows(mb, 300), permutations=100, seed=1)
+    nstop = torch.arange(3 * 700, dtype=torch.int32, device="cuda").view(3, 700)
+    got = eng.pack_records(res, nstop=nstop)
+    want = sd.pack_records(res["counts"], res["p"], res["odds"], res["r"], nstop)
+    assert torch.equal(got, want)
+    d = sd.unpack_records(got)
+    assert torch.equal(d["p"], res["p"]) or torch.equal(d["p"].isnan(), res["p"].isnan())
+    assert torch.equal(d["r"], res["r"]) and torch.equal(d["nstop"], nstop)
+    none = eng.pack_records({"counts": res["counts"], "p": res["p"], "odds": res["odds"], "r": None})
+    assert torch.equal(none, sd.pack_records(res["counts"], res["p"], res["odds"], None))
