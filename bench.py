@@ -334,8 +334,8 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
     construction); the measured v_bitop3 ceiling, the SURVEY 8d operand-bandwidth figure
     and the measured HBM traffic ride along."""
     W64 = (N + 63) // 64
-    tests_per_launch = G * T * (P if use_lists else min(P, pbatch))
-    launches_per_step = 1 if use_lists else -(-P // pbatch)
+    launches_per_step = -(-P // pbatch)                # label tiles / label rows come in batches
+    tests_per_launch = G * T * P / launches_per_step   # average over the launches of a step
     operand_bytes = 16.0 * W64 * tests_per_launch        # SURVEY 8d: 16*W bytes / test
     default_sizes = (args.genes is None and args.permutations is None
                      and args.isolates is None and args.traits is None)
@@ -586,7 +586,8 @@ def main():
             "value_single_step_incl_setup": tests_per_step / (dt / args.steps + setup_ms * 1e-3),
             # SURVEY 8d's end-to-end figure: the observed tables count as tests too, G*T*(P+1)
             "value_incl_observed_tables": G_total * T * (P + 1) * args.steps / dt,
-            "roofline": roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms),
+            "roofline": roofline_report(args, eng, use_lists, G, N, T, P,
+                                        ws.batch if use_lists else pbatch, k3_name, k3_ms),
             "kernel_ms": kernel_ms,
         }
         if world == 1 and not args.no_cpu_baseline:

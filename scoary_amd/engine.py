@@ -64,7 +64,7 @@ class Workspace:
         self.tiles = self.scratch = self.perms = None
         self.batch = 0
         if permutations > 0 and use_lists:
-            self.batch = eng.list_batch(T, N, permutations)
+            self.batch = eng.list_batch(T, N, permutations, G)
             nb0 = min(self.batch, permutations)
             self.tiles = eng._empty((int(eng.lib.scoary_list_tiles_words(N, nb0, T)),), torch.int32)
             self.scratch = eng.permute_lists_scratch(G, T, N, nb0)
@@ -350,11 +350,18 @@ class AssociationEngine:
         return int(max(1, min(P, budget_bytes // max(per, 1))))
 
     # -- the whole hot path ----------------------------------------------------
-    def list_batch(self, T, N, permutations, budget_bytes=8 << 30):
-        """Permutations per label-tile batch of the list-driven path (multiple of
-        512, tiles under budget_bytes)."""
-        per = max(int(self.lib.scoary_list_tiles_words(N, 512, T)) * 4, 1)    # bytes / 512 perms
-        return int(max(512, min(-(-permutations // 512) * 512, (budget_bytes // per) * 512)))
+    def list_batch(self, T, N, permutations, G=0, budget_bytes=8 << 30, scratch_bytes=4 << 30):
+        """Permutations per label-tile batch of the list-driven path (multiple of 512): the
+        label tiles stay under budget_bytes and the per-(trait, tile, gene) 16-bit counts of
+        scoary_permute_lists under scratch_bytes (one count per 512 / 256 / 128 ... permutations,
+        trait and gene: 9.8 GB for a cfg5 shard in one batch)."""
+        per = max(int(self.lib.scoary_list_tiles_words(N, 512, T)) * 4, 1)    # tile bytes / 512 perms
+        batch = (budget_bytes // per) * 512
+        if G > 0:
+            tile_perms = 32 * self.list_params(N)[0]
+            per_tile = 2 * int(T) * (int(G) + 64)                              # count bytes / tile column
+            batch = min(batch, max(1, scratch_bytes // per_tile) * tile_perms // 512 * 512)
+        return int(max(512, min(-(-permutations // 512) * 512, batch)))
 
     def workspace(self, genes, T, permutations=0, use_lists=None, perm_buffer=None):
         """Every device buffer one associate() step needs, allocated once: steps that

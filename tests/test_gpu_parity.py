@@ -646,3 +646,26 @@ def test_pack_records_kernel_equals_the_host_side_packing(eng):
     assert torch.equal(d["r"], res["r"]) and torch.equal(d["nstop"], nstop)
     none = eng.pack_records({"counts": res["counts"], "p": res["p"], "odds": res["odds"], "r": None})
     assert torch.equal(none, sd.pack_records(res["counts"], res["p"], res["odds"], None))
+
+
+def test_list_path_in_batches_equals_one_shot_and_oracle(eng, orc, monkeypatch):
+    """The list-driven path with the permutations split into batches of label tiles (what a
+    cfg5-size run does to bound the tile and per-tile-count buffers): r accumulates over the
+    batches, permutation indices stay global -- identical to the one-batch run and the oracle;
+    list_batch keeps the 16-bit count scratch of a cfg5 shard under 4 GB."""
+    rng = np.random.default_rng(41)
+    G, N, T, P = 500, 600, 2, 1700
+    genes, traits = _random_case(rng, G, N, T)
+    tb, mb = _bits(eng, traits)
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    eng.build_lists(gm)
+    one = eng.associate(gm, trv, mkv, permutations=P, seed=9, use_lists=True)["r"].cpu().numpy()
+    monkeypatch.setattr(eng, "list_batch", lambda *a, **k: 512)
+    many = eng.associate(gm, trv, mkv, permutations=P, seed=9, use_lists=True)["r"].cpu().numpy()
+    monkeypatch.undo()
+    assert np.array_equal(one, many)
+    assert np.array_equal(one.view(np.uint32), orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, 9).T)
+    b = eng.list_batch(50, 10000, 100000, 125000)
+    assert b % 512 == 0 and 2 * 50 * 125064 * (b // 128) <= 4 << 30 and b >= 32768
+    assert eng.list_batch(10, 2000, 10000, 50000) == 10240          # the headline config: one batch
