@@ -93,7 +93,12 @@ int scoary_counts(scoary_handle h, const uint32_t *d_tiled,
 /* ---- a5: scipy.stats.fisher_exact(obs_table) at scoary/methods.py:854 ---
  * Two-sided Fisher exact p and sample odds ratio for M 2x2 tables
  * [[tpgp, tpgn], [tngp, tngn]] (d_tables int32 [M][4]); SciPy >= 1.7
- * semantics: (nan, 1.0) when a margin is zero, inf odds when tpgn*tngp == 0.
+ * semantics: (nan, 1.0) when a margin is zero, inf odds when tpgn*tngp == 0;
+ * a support point counts as "as extreme as observed" iff its weight is
+ * <= the observed weight * (1 + 1e-14) -- SciPy's own factor -- and that
+ * comparison is decided exactly (double-double) whenever the fp64 weights agree
+ * to 1e-9: tables whose two closest support points are 1e-12 apart (they
+ * exist: tests/golden/near_ties.json) get SciPy's p, exact ties are ties.
  *   d_p, d_or : double [M]
  *   d_crit    : uint32 [M][2] or NULL -- the rejection region of table m as
  *               (base, span): a permuted table with overlap count a' is "as
