@@ -61,9 +61,38 @@ static void run(const char* name, uint32_t* d, int waves_per_simd) {
          waves_per_simd, ops / (best * 1e-3), 1024.0 * 2.4e9 * 64 / (ops / (best * 1e-3)));
 }
 
-int main() {
+#include <chrono>
+#include <cstdlib>
+// sustained mode: valu_banks <waves per SIMD> <seconds> -- the conflict-free v_bitop3 stream back to
+// back for that long (tools/clock_valu.sh samples the shader clock and socket power meanwhile)
+static int sustained(uint32_t* d, int waves, double seconds) {
+  const int blocks = 256 * 4 * waves, iters = 100000;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  const auto t0 = std::chrono::steady_clock::now();
+  double ms_total = 0.0;
+  long launches = 0;
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((k<0>), dim3(blocks), dim3(64), 0, 0, d, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    ms_total += ms;
+    launches += 10;
+  }
+  const double ops = (double)blocks * 64 * iters * 16 * launches;
+  printf("sustained v_bitop3_b32 (banks 1,2,3), %d waves/SIMD, %.1f s: %.3e lane-ops/s\n", waves,
+         ms_total * 1e-3, ops / (ms_total * 1e-3));
+  return 0;
+}
+
+int main(int argc, char** argv) {
   uint32_t* d;
   (void)hipMalloc(&d, 256 * 4 * 8 * 64 * 4);
+  if (argc > 2) return sustained(d, atoi(argv[1]), atof(argv[2]));
   for (int w : {4, 8}) {
     run<0>("bitop3 d, v1, v2, v3  (banks 1,2,3)", d, w);
     run<1>("bitop3 d, v1, v5, v3  (src0,src1 share a bank)", d, w);
