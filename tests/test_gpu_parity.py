@@ -539,7 +539,8 @@ def test_workspace_and_graph_replay_equal_eager(eng, orc, use_lists):
 
 
 # ------------------------------ opt-in early abort on the Fisher statistic -----
-@pytest.mark.parametrize("G,N,T,P", [(120, 90, 2, 200), (70, 700, 1, 333), (40, 2100, 2, 130)])
+@pytest.mark.parametrize("G,N,T,P", [(120, 90, 2, 200), (70, 700, 1, 333), (40, 2100, 2, 130), (64, 1000, 1, 120),
+                                     (30, 7000, 1, 70)])
 def test_permute_sequential_early_abort_vs_oracle(eng, orc, G, N, T, P):
     """--permute-early-abort (scoary_permute_seq): the reference's sequential estimator
     (scoary/methods.py:1348-1365) applied to the Fisher statistic.  The oracle leg states
