@@ -517,6 +517,41 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   // 32-byte memory-side write each: 316 MB for a 2 MB result at the headline config)
   uint16_t* out = partial + (int64_t)blockIdx.x * ((int64_t)ngroups * GPW);
 
+  // interleaved lists (piece = TW entries): the wavefront's 64 lanes read 64 consecutive
+  // 16-byte index vectors per piece; lane l reads vector piece*64 + l of its group
+  struct alignas(16) Ent { uint32_t e[4]; };
+#ifndef SCOARY_LIST_LOAD_POLICY
+#define SCOARY_LIST_LOAD_POLICY 0
+#endif
+  constexpr int kListLoadPolicy = SCOARY_LIST_LOAD_POLICY;
+  // A wave group's list: its length in half-steps of 16 entries (lists are padded to 16: a last
+  // half step costs half a step, where padding to 32 made the average list 3 % longer), its last
+  // piece, and a buffer resource on it -- group base in the descriptor (SGPRs), piece offset in
+  // the scalar offset, lane offset in one VGPR: no per-load 64-bit VALU address arithmetic.
+  // num_records = the bytes from the group's base to the end of the index array: a read past
+  // the end (groups without entries still issue their prologue loads) returns 0.
+  struct Group { int nhalf, last; __amdgpu_buffer_rsrc_t rsrc; };
+  auto open_group = [&](int qq) -> Group {
+    const int64_t start = (int64_t)__builtin_amdgcn_readfirstlane(lstart[qq * GPW]);
+    const int nh = __builtin_amdgcn_readfirstlane(lngroups[qq * GPW]);
+    const int64_t gbytes = lidx_bytes - start * 128;
+    return Group{nh, max(nh * (4 / LPG) - 1, 0),
+                 __builtin_amdgcn_make_buffer_rsrc(
+                     const_cast<Ent*>(reinterpret_cast<const Ent*>(lidx) + start * 8), 0,
+                     (int)min(gbytes, (int64_t)0x7fffffff), 0x00020000)};
+  };
+  auto load_from = [&](const Group& gr, int p) -> Ent {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+        gr.rsrc, lane_off, min(p, gr.last) * (kWave * (int)sizeof(Ent)), kListLoadPolicy);
+    return Ent{{v.x, v.y, v.z, v.w}};
+  };
+  // The first four index vectors of a group are requested one group AHEAD: at the start of the
+  // previous group's epilogue (region test, ~0.3 us of VALU work in which the ring registers
+  // are dead) -- and for the wavefront's first group here, before the label tile is waited
+  // for -- so a group does not open with an exposed L2 round trip.
+  int q = q_lo + wave;
+  Group cur = open_group(min(q, ngroups - 1));
+  Ent ring[4] = {load_from(cur, 0), load_from(cur, 1), load_from(cur, 2), load_from(cur, 3)};
   const uint32_t* src = tiles + (int64_t)blockIdx.x * list_tile_dwords(N, TW);
   {
     // tile -> LDS by LDS-DMA (global_load_lds_dwordx4): a wavefront moves 64 x 16 B
@@ -542,17 +577,9 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   // LPG == 1: an entry is used as the LDS address as it is -- the tile is the kernel's only
   // LDS object and sits at LDS address 0 (checked on the host: no static LDS in this kernel)
   {
-  for (int q = q_lo + wave; q < q_hi; q += nwaves) {
-    // list length of the group in half-steps of 16 entries (lists are padded to 16: a last
-    // half step costs half a step, where padding to 32 made the average list 3 % longer)
-    const int nhalf = __builtin_amdgcn_readfirstlane(lngroups[q * GPW]);
+  for (; q < q_hi; q += nwaves) {
+    const int nhalf = cur.nhalf, last = cur.last;
     const int nsuper = (nhalf + 1) >> 1;                               // 32-entry steps, the last maybe half
-    // interleaved lists (piece = TW entries): the wavefront's 64 lanes read 64
-    // consecutive 16-byte index vectors per piece
-    struct alignas(16) Ent { uint32_t e[4]; };
-    // wave-uniform base of the group's lists; lane l reads vector piece*64 + l
-    const Ent* gbase = reinterpret_cast<const Ent*>(lidx) +
-                       (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 8;
     // this lane's column of a tile row, as an absolute LDS address (entries are row byte offsets)
     const uint32_t colb = (uint32_t)col * (NW * 4u) +
                           (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds;
@@ -586,31 +613,8 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     // four vectors (a region of four steps is a multiple of four pieces, so the ring
     // slot of every piece is a compile-time constant).  Reads past the end of the
     // list re-read its last piece (valid rows, never summed).
-    const int last = max(nhalf * (4 / LPG) - 1, 0);
     int piece = 0;                                   // piece whose vector is ring[piece % 4]
-    // buffer load: group base in the resource descriptor (SGPRs), piece offset in the scalar
-    // offset, lane offset in one VGPR -- no per-load 64-bit VALU address arithmetic
-    // (v_lshl_add_u64 per load otherwise, ~10 cycles each beside the v_bitop3 stream)
-    // num_records = the bytes from the group's base to the end of the index array: a
-    // read past the end (groups without entries still issue their prologue loads) returns 0
-    const int64_t gbytes = lidx_bytes - (int64_t)__builtin_amdgcn_readfirstlane(lstart[q * GPW]) * 128;
-    const __amdgpu_buffer_rsrc_t lists_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<Ent*>(gbase), 0, (int)min(gbytes, (int64_t)0x7fffffff), 0x00020000);
-    // cache policy of the index loads (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1).  "nt"
-    // (non-temporal, evict first) was tried so that the streaming lists stop pushing the XCD's
-    // 25 label tiles out of its 4 MB L2: FETCH_SIZE 2.35 -> 1.93 GB per launch, but the kernel
-    // got 5 % SLOWER (4.46 -> 4.70 ms, profiles/r02_ab_list_load_policy.txt) -- HBM is at 7 %
-    // of its peak here, issue slots are what is scarce.  Default policy stays.
-#ifndef SCOARY_LIST_LOAD_POLICY
-#define SCOARY_LIST_LOAD_POLICY 0
-#endif
-    constexpr int kListLoadPolicy = SCOARY_LIST_LOAD_POLICY;
-    auto load_piece = [&](int p) -> Ent {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(lists_rsrc, lane_off,
-                                                            min(p, last) * (kWave * (int)sizeof(Ent)), kListLoadPolicy);
-      return Ent{{v.x, v.y, v.z, v.w}};
-    };
-    Ent ring[4] = {load_piece(0), load_piece(1), load_piece(2), load_piece(3)};
+    auto load_piece = [&](int p) -> Ent { return load_from(cur, p); };
     read4x4<LPG, 0, NW>(xa, ring[0].e, colb);
     // sub-step S of step K (both literals): issue the reads of the next sub-step into
     // `other`, sum `mine`
@@ -690,6 +694,14 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
 #undef STEP
 #undef SUBSTEP
 #undef FA4
+    // next group of this wavefront: open it and request its first index vectors now
+    if (q + nwaves < q_hi) {
+      cur = open_group(q + nwaves);
+      ring[0] = load_from(cur, 0);
+      ring[1] = load_from(cur, 1);
+      ring[2] = load_from(cur, 2);
+      ring[3] = load_from(cur, 3);
+    }
     // the lane's gene within the group, recomputed here (volatile asm: not hoisted) rather
     // than held in a register across the list walk -- the walk uses every VGPR there is
     const int lg = fresh_lane() / LPG;
