@@ -123,7 +123,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
     const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-    const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    // three-input xor = one v_bitop3_b32 (LUT 0x96); two v_xor_b32 otherwise
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32(h1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(h0, c3, k1, 0x96);
     c0 = n0;
     c1 = l1;
     c2 = n2;

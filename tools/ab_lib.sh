@@ -3,7 +3,7 @@
 # separate passes).   tools/ab_lib.sh <alt.so> [bench args]
 cd "$(dirname "$0")/.."
 REPO=$(pwd); ALT=$REPO/$1; shift
-pick='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%-8s step %.3f ms  k_permute_lists %.3f ms  value %.3e" % (sys.argv[1], d["ms_per_step"], d["kernel_ms"]["k_permute_lists"], d["value"]))'
+pick='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%-8s step %.3f ms  k_permute_lists %.3f ms  tiles %.4f ms  value %.3e" % (sys.argv[1], d["ms_per_step"], d["kernel_ms"]["k_permute_lists"], d["kernel_ms"].get("k_perm_generate_tiles", 0), d["value"]))'
 for i in 1 2 3; do
   python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "$pick" default
   SCOARY_HIP_LIB=$ALT python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "$pick" alt
