@@ -416,3 +416,71 @@ def test_cli_near_tie_dataset_vs_reference(tmp_path):
         rows = {r[0]: r for r in csv.reader(io.StringIO(got))}
         px, py = float(rows[pair[0]][10]), float(rows[pair[1]][10])
         assert abs(px - 0.6002069089625) < 1e-12 and abs(py - 0.6333635751133) < 1e-12
+
+
+def test_cli_cfg2_sized_table_every_row_vs_oracle(tmp_path):
+    """The command line on a table of BASELINE configs[1]'s shape (10 000 genes x 500
+    isolates, 1000 permutations, here with 3 traits and missing values): every
+    output row -- counts, sensitivity / specificity, Naive_p, corrected p and
+    Empirical_p -- against the oracle fed by the independent reader, and the row
+    order against the reference's sort keys.  Exercises the native reader, the
+    list-driven permutation path and the results writer at a size the example data
+    does not reach."""
+    from oracle import oracle as orc
+    from scoary_amd.engine import pack_bits_rows
+    rng = np.random.default_rng(20)
+    G, N, T, P, seed = 10_000, 500, 3, 1000, 77
+    dense = rng.random((G, N)) < rng.beta(0.5, 0.5, (G, 1))
+    dense[11] = rng.random(N) < 0.4
+    lab = np.where(rng.random((T, N)) < 0.45, "1", "0").astype(object)
+    lab[0] = np.where(dense[11] ^ (rng.random(N) < 0.04), "1", "0")
+    lab[1, rng.random(N) < 0.1] = "NA"
+    iso = ["s%03d" % i for i in range(N)]
+    meta = ["Gene", "Non-unique Gene name", "Annotation", "No. isolates", "No. sequences",
+            "Avg sequences per isolate", "Genome Fragment", "Order within Fragment",
+            "Accessory Fragment", "Accessory Order with Fragment", "QC", "Min group size nuc",
+            "Max group size nuc", "Avg group size nuc"]
+    cells = np.where(dense, "x", "")
+    gtxt = ",".join(meta + iso) + "\n" + "".join(
+        "g%05d,,\"syn, thetic\",%s,%s\n" % (g, ",".join(["1"] * 11), ",".join(cells[g]))
+        for g in range(G))
+    ttxt = "," + ",".join("tr%d" % t for t in range(T)) + "\n" + "".join(
+        iso[i] + "," + ",".join(lab[:, i]) + "\n" for i in range(N))
+    (tmp_path / "g.csv").write_text(gtxt)
+    (tmp_path / "t.csv").write_text(ttxt)
+    files = run_cli(["-g", str(tmp_path / "g.csv"), "-t", str(tmp_path / "t.csv"),
+                     "--no_pairwise", "-e", str(P), "--seed", str(seed), "-p", "1.0"],
+                    tmp_path / "out")
+    ids, strains, genes, names, traits = read_dense(gtxt, ttxt)
+    assert strains == iso and len(ids) == G
+    gb = orc.pack_rows(genes)
+    tb = pack_bits_rows((traits == 1).astype(np.uint8))
+    mb = pack_bits_rows((traits != 2).astype(np.uint8))
+    r = orc.permute_r(gb, tb, mb, N, P, seed)
+    cnt_all = orc.counts_packed(gb, tb, mb)
+    for t, trait in enumerate(names):
+        rows = list(csv.reader(io.StringIO(files[trait + ".results.csv"])))
+        col = {c: k for k, c in enumerate(rows[0])}
+        cnt = cnt_all[:, t]                            # tpgp, tpgn, tngp, tngn
+        odds, p = orc.fisher_many(cnt)
+        keep = [g for g in range(G) if cnt[g, 0] + cnt[g, 2] and cnt[g, 1] + cnt[g, 3]]
+        assert len(rows) - 1 == len(keep)             # all-present / all-absent genes drop out
+        seen = set()
+        for d in rows[1:]:
+            g = int(d[0][1:])
+            seen.add(g)
+            assert d[2] == "syn, thetic"
+            assert [int(d[col[c]]) for c in
+                    ("Number_pos_present_in", "Number_neg_present_in",
+                     "Number_pos_not_present_in", "Number_neg_not_present_in")] == \
+                [cnt[g, 0], cnt[g, 2], cnt[g, 1], cnt[g, 3]]
+            assert abs(float(d[col["Naive_p"]]) - p[g]) <= 1e-12 + 1e-11 * p[g]
+            assert d[col["Empirical_p"]] == repr((float(r[g, t]) + 1.0) / (P + 1.0))
+        assert seen == set(keep)
+        naive = [float(d[col["Naive_p"]]) for d in rows[1:]]
+        assert all(a <= b * (1 + 1e-9) for a, b in zip(naive, naive[1:]))
+        bonf = [float(d[col["Bonferroni_p"]]) for d in rows[1:]]
+        assert all(abs(b - min(1.0, q * len(keep))) <= 1e-9 * max(b, 1e-300)
+                   for b, q in zip(bonf, naive))
+    top = list(csv.reader(io.StringIO(files["tr0.results.csv"])))[1]
+    assert top[0] == "g00011"                          # the planted gene wins its trait
