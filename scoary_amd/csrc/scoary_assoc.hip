@@ -133,9 +133,6 @@ __global__ __launch_bounds__(256) void k_counts(const uint4* __restrict__ tiled,
 __device__ __forceinline__ double w_up(double w, int x, int n1, int n2, int n) {
   return w * ((double)(n1 - x) * (double)(n - x)) / ((double)(x + 1) * (double)(n2 - n + x + 1));
 }
-__device__ __forceinline__ double w_down(double w, int x, int n1, int n2, int n) {
-  return w * ((double)x * (double)(n2 - n + x)) / ((double)(n1 - x + 1) * (double)(n - x + 1));
-}
 
 // ---- spec S3 tie rule: w(x) <= w(a) * (1 + 1e-14), SciPy's gamma ------------------------
 // The fp64 recurrence carries ~2e-16 of error per step, so a comparison that comes out within
@@ -186,63 +183,85 @@ __device__ __forceinline__ bool hg_leq(double w, double wobs, int n1, int n2, in
   return hg_leq_dd(n1, n2, n, x, a);
 }
 
+// A lane PAIR per table: the even lane sums the weights from the mode upwards, the odd lane
+// those below the mode.  A downward walk is an upward walk in the mirrored coordinates
+// x' = n - x with the two margins swapped -- the oracle's downward step
+// w(x-1) = w(x) * (x * (n2-n+x)) / ((n1-x+1) * (n-x+1)) and w_up(w, n - x, n2, n1, n) multiply
+// and divide by the same two exact integer products, so the weights are bit-identical --
+// which lets every lane run the same loop whatever its
+// direction (no divergence between the lanes of a pair or between tables on either side of
+// their mode) and halves the serial length of the kernel.
 __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, int64_t M,
                                                double* __restrict__ p_out,
                                                double* __restrict__ or_out,
                                                uint2* __restrict__ crit) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t idx = tid >> 1;
+  const bool down = tid & 1;
   if (idx >= M) return;
   const int4 c = tables[idx];
   const int a = c.x, b = c.y, cc = c.z, d = c.w;
   const int n1 = a + b, n2 = cc + d, n = a + cc;
   if (n1 == 0 || n2 == 0 || n == 0 || b + d == 0) {
-    p_out[idx] = 1.0;
-    or_out[idx] = __longlong_as_double(0x7ff8000000000000LL);
-    if (crit) crit[idx] = make_uint2(0u, 0u);
+    if (down) {
+      or_out[idx] = __longlong_as_double(0x7ff8000000000000LL);
+    } else {
+      p_out[idx] = 1.0;
+      if (crit) crit[idx] = make_uint2(0u, 0u);
+    }
     return;
   }
-  or_out[idx] = (cc > 0 && b > 0) ? ((double)a * (double)d) / ((double)cc * (double)b)
-                                  : __longlong_as_double(0x7ff0000000000000LL);
   const int lo = max(0, n - n2), hi = min(n, n1);
   int mode = (int)(((double)(n + 1) * (double)(n1 + 1)) / (double)(n1 + n2 + 2));
   mode = min(max(mode, lo), hi);
 
+  // weight of the observed table, walking from the mode towards a
   double w = 1.0;
-  if (a > mode)
-    for (int x = mode; x < a; ++x) w = w_up(w, x, n1, n2, n);
-  else
-    for (int x = mode; x > a; --x) w = w_down(w, x, n1, n2, n);
+  {
+    const bool below = a < mode;
+    const int m1 = below ? n2 : n1, m2 = below ? n1 : n2;
+    const int xe = below ? n - a : a;
+    for (int x = below ? n - mode : mode; x < xe; ++x) w = w_up(w, x, m1, m2, n);
+  }
   const double wobs = w;
-  const double thr = w;                  // (only the 2^-90 tail cut below still uses it)
 
-  // Both walks stop once a term is inside the rejection region AND below
+  // The walk stops once a term is inside the rejection region AND below
   // 2^-90 of the observed table's weight: what is left of the
   // (super-geometrically decaying) tail is < 1e-26 of the included sum, so p
   // keeps its RELATIVE accuracy even when it is 1e-200, and the region
   // boundary has already been passed, so (L, H) are exact.
-  const double tiny = 8.077935669463161e-28 * (thr < 1.0 ? thr : 1.0);   // 2^-90 * w_obs
+  const double tiny = 8.077935669463161e-28 * (wobs < 1.0 ? wobs : 1.0);   // 2^-90 * w_obs
+  const int m1 = down ? n2 : n1, m2 = down ? n1 : n2;
+  const int xend = down ? n - lo : hi;
+  int x = down ? n - mode : mode;          // own (mirrored, for the odd lane) coordinate
+  int first = -1;                          // first term inside the region, own coordinate
+  bool take = !down;                       // the mode's term belongs to the upward lane
   double tot = 0.0, inc = 0.0;
-  int H = hi + 1, L = lo - 1;
   w = 1.0;
-  for (int x = mode; x <= hi; ++x) {
-    tot += w;
-    if (hg_leq(w, wobs, n1, n2, n, x, a)) {
-      inc += w;
-      if (H > hi) H = x;
-      if (w < tiny) break;
+  for (;;) {
+    if (take) {
+      tot += w;
+      if (hg_leq(w, wobs, n1, n2, n, down ? n - x : x, a)) {
+        inc += w;
+        if (first < 0) first = x;
+        if (w < tiny) break;
+      }
     }
-    w = w_up(w, x, n1, n2, n);
+    take = true;
+    if (x >= xend) break;
+    w = w_up(w, x, m1, m2, n);
+    ++x;
   }
-  w = 1.0;
-  for (int x = mode; x > lo; --x) {
-    w = w_down(w, x, n1, n2, n);  // weight of x-1
-    tot += w;
-    if (hg_leq(w, wobs, n1, n2, n, x - 1, a)) {
-      inc += w;
-      if (L < lo) L = x - 1;
-      if (w < tiny) break;
-    }
+  tot += __shfl_xor(tot, 1);
+  inc += __shfl_xor(inc, 1);
+  const int other = __shfl_xor(first, 1);
+  if (down) {
+    or_out[idx] = (cc > 0 && b > 0) ? ((double)a * (double)d) / ((double)cc * (double)b)
+                                    : __longlong_as_double(0x7ff0000000000000LL);
+    return;
   }
+  const int H = first >= 0 ? first : hi + 1;
+  const int L = other >= 0 ? n - other : lo - 1;
   const bool all = (H == mode);
   const double p = all ? 1.0 : inc / tot;
   p_out[idx] = p < 1.0 ? p : 1.0;
@@ -539,7 +558,7 @@ int scoary_fisher(scoary_handle h, const int32_t* d_tables, int64_t M, double* d
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   KernelTimer kt(h, s, "k_fisher");
-  hipLaunchKernelGGL(k_fisher, dim3((unsigned)((M + kWave - 1) / kWave)), dim3(kWave), 0, s,
+  hipLaunchKernelGGL(k_fisher, dim3((unsigned)((2 * M + kWave - 1) / kWave)), dim3(kWave), 0, s,
                      reinterpret_cast<const int4*>(d_tables), M, d_p, d_or,
                      reinterpret_cast<uint2*>(d_crit));
   HIP_TRY(h, hipGetLastError());

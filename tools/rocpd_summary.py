@@ -30,8 +30,10 @@ def main():
         rows = c.execute("select name, total_calls, total_duration, average, percentage "
                          "from top_kernels").fetchall()
         with open(prefix + "_kernel_stats.txt", "w") as f:
-            cmd = "python tools/bench_tree.py" if "tree" in (sys.argv[3] if len(sys.argv) > 3 else "") \
-                else "python bench.py --no-cpu-baseline   (defaults: 5 warm-up + 20 timed steps)"
+            wl = sys.argv[3] if len(sys.argv) > 3 else "cfg3"
+            cmd = "python tools/bench_tree.py" if "tree" in wl else (
+                "python bench.py --no-cpu-baseline%s   (defaults: 5 warm-up + 20 timed steps)"
+                % ("" if wl == "cfg3" else " --config " + wl))
             f.write("# rocprofv3 --kernel-trace --stats -- %s   (durations in us)\n" % cmd)
             f.write("%-34s %6s %14s %12s %8s\n" % ("kernel", "calls", "total_us", "avg_us", "pct"))
             for name, calls, tot, avg, pct in rows:
