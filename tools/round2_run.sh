@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out
 python bench.py > $O/bench_r02g.json 2> $O/bench_r02g.err
-tools/profile.sh r02e > $O/profile_r02e.log 2>&1
+tools/profile.sh r02g_cfg3 > $O/profile_r02g_cfg3.log 2>&1
 python bench.py --config cfg2 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_r02g_cfg2.json 2>/dev/null
 python bench.py --config cfg2 --steps 200 --warmup 20 --no-cpu-baseline --graph > $O/bench_r02g_cfg2_graph.json 2>/dev/null
 python bench.py --config cfg4 --no-cpu-baseline > $O/bench_r02g_cfg4.json 2>/dev/null
