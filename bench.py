@@ -536,7 +536,7 @@ def main():
     k3_name = "k_permute_lists" if use_lists else "k_permute"
     k3_ms = eng.kernel_ms(k3_name)
     names = ("k_counts", "k_fisher") + (
-        ("k_perm_generate_tiles", "k_lists_crit", "k_permute_lists", "k_lists_reduce") if use_lists else
+        ("k_perm_generate_tiles", "k_permute_lists", "k_lists_reduce") if use_lists else
         ("k_perm_generate", "k_permute"))
     kernel_ms = {k: eng.kernel_ms(k) for k in names}
     eng.set_timing(False)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SCOARY_ABI_VERSION 4
+#define SCOARY_ABI_VERSION 5
 
 /* error codes */
 #define SCOARY_OK 0
@@ -109,6 +109,19 @@ int scoary_counts(scoary_handle h, const uint32_t *d_tiled,
 int scoary_fisher(scoary_handle h, const int32_t *d_tables, int64_t M,
                   double *d_p, double *d_or, uint32_t *d_crit,
                   scoary_stream_t stream);
+/* The same test for the list-driven permutation path, one launch fewer per step:
+ * tables [T][G][4] are visited in LIST-SLOT order (slot k of trait t = gene
+ * d_lorder[k]; slots are sorted by minority count, so the lanes of a wavefront walk
+ * supports of similar length), results land at the gene's own index as in
+ * scoary_fisher (d_crit may be NULL), and the rejection region is also written in
+ * the form scoary_permute_lists consumes: d_lcrit uint32 [T][G][2] = (lo, hi1) of the
+ * LIST count in slot order (ones-list: [base, base + span); zeros-list:
+ * [npos - base - span + 1, npos - base + 1); span 0 -> (0, 0)).
+ *   d_lorder / d_lflipped : from scoary_lists_plan */
+int scoary_fisher_lists(scoary_handle h, const int32_t *d_tables, int64_t T, int64_t G,
+                        const int32_t *d_lorder, const uint8_t *d_lflipped,
+                        double *d_p, double *d_or, uint32_t *d_crit, uint32_t *d_lcrit,
+                        scoary_stream_t stream);
 
 /* ---- a8: PermuteGTC (scoary/methods.py:1371-1384) ----------------------
  * Label permutations pi = perm_base .. perm_base+P-1 of the T traits whose
@@ -168,7 +181,11 @@ int scoary_permute_seq(scoary_handle h, const uint32_t *d_tiled, const uint32_t 
  *             tile, list slot) -- the kernel writes them with plain stores and a
  *             small second kernel (k_lists_reduce) sums the tiles into d_r; no
  *             atomics (a device-scope atomic is a 32-byte memory-side write)
- *   d_r     : uint32 [T][G], += like scoary_permute */
+ *   d_crit  : regions in gene order from scoary_fisher (converted by a small kernel,
+ *             needs d_margins), or NULL when
+ *   d_lcrit : regions in slot order from scoary_fisher_lists is given (d_margins unused)
+ *   d_r     : uint32 [T][G]; accumulate != 0: += like scoary_permute (further batches of
+ *             permutations); accumulate == 0: overwritten (no zero fill needed) */
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T);
 int64_t scoary_list_tile_words(int64_t N);   /* dwords per (trait, tile) */
 int64_t scoary_list_max_isolates(void);
@@ -185,9 +202,10 @@ int64_t scoary_permute_lists_scratch_bytes(int64_t G, int64_t T, int64_t N, int6
 int scoary_permute_lists(scoary_handle h, const uint32_t *d_tiles, const uint32_t *d_lidx,
                          int64_t entries, const int32_t *d_lstart, const int32_t *d_lngroups,
                          const int32_t *d_lorder, const uint8_t *d_lflipped,
-                         const uint32_t *d_crit, const int32_t *d_margins, void *d_scratch,
+                         const uint32_t *d_crit, const uint32_t *d_lcrit,
+                         const int32_t *d_margins, void *d_scratch,
                          int64_t G, int64_t T, int64_t N, int64_t P, uint32_t *d_r,
-                         scoary_stream_t stream);
+                         int accumulate, scoary_stream_t stream);
 
 /* ---- index lists of the list-driven kernel, built on the device -----------------
  * From the tiled gene matrix already in HBM (no host pass, no PCIe copy of the

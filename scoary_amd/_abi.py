@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCOARY_HIP_LIB") or os.path.join(_HERE, "csrc", "libscoary_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "scoary_hip.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _i64, _u64, _i32, _vp, _cp = (ctypes.c_int64, ctypes.c_uint64, ctypes.c_int,
                               ctypes.c_void_p, ctypes.c_char_p)
@@ -30,6 +30,7 @@ SIGNATURES = {
     "scoary_tile_rows": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "scoary_counts": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "scoary_fisher": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "scoary_fisher_lists": (_i32, [_vp, _vp, _i64, _i64] + [_vp] * 7),
     "scoary_perm_generate": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp, _vp]),
     "scoary_permute": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "scoary_permute_seq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp,
@@ -41,8 +42,8 @@ SIGNATURES = {
     "scoary_perm_generate_tiles": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp,
                                           _vp]),
     "scoary_permute_lists_scratch_bytes": (_i64, [_i64, _i64, _i64, _i64]),
-    "scoary_permute_lists": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 7 + [_i64, _i64, _i64, _i64, _vp,
-                                                                       _vp]),
+    "scoary_permute_lists": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 8 + [_i64, _i64, _i64, _i64, _vp,
+                                                                       _i32, _vp]),
     "scoary_lists_scratch_bytes": (_i64, [_i64, _i64]),
     "scoary_lists_slack_entries": (_i64, []),
     "scoary_lists_plan": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp,

@@ -130,9 +130,18 @@ __global__ __launch_bounds__(256) void k_counts(const uint4* __restrict__ tiled,
 // Hypergeometric weights by the exact ratio recurrence, normalised at the
 // mode; same operation order as the oracle's hg_weights so the weights (and
 // hence the rejection regions) are bit-identical on both sides.
-__device__ __forceinline__ double w_up(double w, int x, int n1, int n2, int n) {
-  return w * ((double)(n1 - x) * (double)(n - x)) / ((double)(x + 1) * (double)(n2 - n + x + 1));
-}
+// One step: w(x + 1) = w(x) * ((n1 - x)(n - x)) / ((x + 1)(n2 - n + x + 1)), the four factors
+// kept as doubles that move by +-1 (exact; no int -> double conversions in the loop).
+struct HgWalk {
+  double fa, fb, fc, fd;
+  __device__ __forceinline__ HgWalk(int x, int n1, int n2, int n)
+      : fa((double)(n1 - x)), fb((double)(n - x)), fc((double)(x + 1)), fd((double)(n2 - n + x + 1)) {}
+  __device__ __forceinline__ double step(double w) {
+    const double r = w * (fa * fb) / (fc * fd);
+    fa -= 1.0; fb -= 1.0; fc += 1.0; fd += 1.0;
+    return r;
+  }
+};
 
 // ---- spec S3 tie rule: w(x) <= w(a) * (1 + 1e-14), SciPy's gamma ------------------------
 // The fp64 recurrence carries ~2e-16 of error per step, so a comparison that comes out within
@@ -176,29 +185,54 @@ __device__ __noinline__ bool hg_leq_dd(int n1, int n2, int n, int x, int a) {
   const DD G = dd_mul_d(R, kGamma);                                      // w(x)/w(a) = 1/R <= gamma
   return G.hi > 1.0 || (G.hi == 1.0 && G.lo >= 0.0);                     //   <=>  gamma * R >= 1
 }
-// w(x) <= w(a) (1 + 1e-14), given the fp64 weights w = w(x), wobs = w(a)
-__device__ __forceinline__ bool hg_leq(double w, double wobs, int n1, int n2, int n, int x, int a) {
-  if (w <= wobs * (1.0 - kAmbig)) return true;
-  if (w > wobs * (1.0 + kAmbig)) return false;
+// w(x) <= w(a) (1 + 1e-14) for fp64 weights that agree to kAmbig
+__device__ __forceinline__ bool hg_tie(int n1, int n2, int n, int x, int a) {
+  // Exact ties that need no arithmetic: the observed table itself, and its mirror image when
+  // a margin pair is symmetric (n1 == n2: w(x) = w(n - x); n == N - n: w(x) = w(n1 - x)).
+  // These are nearly all the comparisons that get here; sending them through the
+  // double-double product (|x - a| steps, run by the whole wavefront for one lane) made a
+  // wavefront of balanced genes -- which list-slot order puts side by side -- the long pole.
+  if (x == a || (n1 == n2 && x == n - a) || (2 * n == n1 + n2 && x == n1 - a)) return true;
   return hg_leq_dd(n1, n2, n, x, a);
 }
 
 // A lane PAIR per table: the even lane sums the weights from the mode upwards, the odd lane
 // those below the mode.  A downward walk is an upward walk in the mirrored coordinates
 // x' = n - x with the two margins swapped -- the oracle's downward step
-// w(x-1) = w(x) * (x * (n2-n+x)) / ((n1-x+1) * (n-x+1)) and w_up(w, n - x, n2, n1, n) multiply
+// w(x-1) = w(x) * (x * (n2-n+x)) / ((n1-x+1) * (n-x+1)) and the upward step at n - x on (n2, n1, n) multiply
 // and divide by the same two exact integer products, so the weights are bit-identical --
 // which lets every lane run the same loop whatever its
 // direction (no divergence between the lanes of a pair or between tables on either side of
 // their mode) and halves the serial length of the kernel.
+//
+// SLOTS = false: tables in the caller's order, pair id = table.  SLOTS = true (the list-driven
+// path, scoary_fisher_lists): grid.y = trait, pair id = list slot k, the table is that of gene
+// order[k].  Slots are sorted by list length, i.e. by the gene's minority count, so the lanes
+// of a wavefront walk supports of similar length (the trip count of a wavefront is that of
+// its longest lane), and the rejection region can be written a second time in the form the
+// list kernel wants -- (lo, hi1) of the LIST count u, in slot order -- which saves the
+// separate conversion launch (k_lists_crit):
+//   ones-list : u in [base, base + span);  zeros-list: u in [npos - base - span + 1, npos - base + 1)
+template <bool SLOTS>
 __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, int64_t M,
                                                double* __restrict__ p_out,
                                                double* __restrict__ or_out,
-                                               uint2* __restrict__ crit) {
+                                               uint2* __restrict__ crit,
+                                               const int32_t* __restrict__ order,
+                                               const uint8_t* __restrict__ flipped,
+                                               uint2* __restrict__ lcrit) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t idx = tid >> 1;
+  const int64_t pid = tid >> 1;
   const bool down = tid & 1;
-  if (idx >= M) return;
+  if (pid >= M) return;            // M = tables (SLOTS = false) or genes per trait (true)
+  int64_t idx = pid, lidx = 0;
+  bool zeros_list = false;
+  if constexpr (SLOTS) {
+    const int g = order[pid];
+    idx = (int64_t)blockIdx.y * M + g;
+    lidx = (int64_t)blockIdx.y * M + pid;
+    zeros_list = flipped[g] != 0;
+  }
   const int4 c = tables[idx];
   const int a = c.x, b = c.y, cc = c.z, d = c.w;
   const int n1 = a + b, n2 = cc + d, n = a + cc;
@@ -208,6 +242,7 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
     } else {
       p_out[idx] = 1.0;
       if (crit) crit[idx] = make_uint2(0u, 0u);
+      if constexpr (SLOTS) lcrit[lidx] = make_uint2(0u, 0u);
     }
     return;
   }
@@ -219,9 +254,9 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
   double w = 1.0;
   {
     const bool below = a < mode;
-    const int m1 = below ? n2 : n1, m2 = below ? n1 : n2;
-    const int xe = below ? n - a : a;
-    for (int x = below ? n - mode : mode; x < xe; ++x) w = w_up(w, x, m1, m2, n);
+    const int xs = below ? n - mode : mode, xe = below ? n - a : a;
+    HgWalk wk(xs, below ? n2 : n1, below ? n1 : n2, n);
+    for (int x = xs; x < xe; ++x) w = wk.step(w);
   }
   const double wobs = w;
 
@@ -230,26 +265,28 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
   // (super-geometrically decaying) tail is < 1e-26 of the included sum, so p
   // keeps its RELATIVE accuracy even when it is 1e-200, and the region
   // boundary has already been passed, so (L, H) are exact.
+  // The body is predicated rather than branched (a lone wavefront issues an instruction
+  // every ~6 cycles, so the instruction count is the latency of a small problem): only the
+  // comparisons inside the 1e-9 band around a tie -- rare -- leave the straight line.
   const double tiny = 8.077935669463161e-28 * (wobs < 1.0 ? wobs : 1.0);   // 2^-90 * w_obs
-  const int m1 = down ? n2 : n1, m2 = down ? n1 : n2;
+  const double sure_in = wobs * (1.0 - kAmbig), sure_out = wobs * (1.0 + kAmbig);
   const int xend = down ? n - lo : hi;
   int x = down ? n - mode : mode;          // own (mirrored, for the odd lane) coordinate
   int first = -1;                          // first term inside the region, own coordinate
   bool take = !down;                       // the mode's term belongs to the upward lane
   double tot = 0.0, inc = 0.0;
+  HgWalk wk(x, down ? n2 : n1, down ? n1 : n2, n);
   w = 1.0;
   for (;;) {
-    if (take) {
-      tot += w;
-      if (hg_leq(w, wobs, n1, n2, n, down ? n - x : x, a)) {
-        inc += w;
-        if (first < 0) first = x;
-        if (w < tiny) break;
-      }
-    }
+    bool in = w <= sure_in;
+    if (!in && !(w > sure_out)) in = hg_tie(n1, n2, n, down ? n - x : x, a);
+    in = in && take;
+    tot += take ? w : 0.0;
+    inc += in ? w : 0.0;
+    first = (in && first < 0) ? x : first;
+    if ((in && w < tiny) || x >= xend) break;
     take = true;
-    if (x >= xend) break;
-    w = w_up(w, x, m1, m2, n);
+    w = wk.step(w);
     ++x;
   }
   tot += __shfl_xor(tot, 1);
@@ -265,7 +302,15 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
   const bool all = (H == mode);
   const double p = all ? 1.0 : inc / tot;
   p_out[idx] = p < 1.0 ? p : 1.0;
-  if (crit) crit[idx] = all ? make_uint2(0u, 0u) : make_uint2((uint32_t)(L + 1), (uint32_t)(H - L - 1));
+  const uint32_t base = (uint32_t)(L + 1), span = all ? 0u : (uint32_t)(H - L - 1);
+  if (crit) crit[idx] = all ? make_uint2(0u, 0u) : make_uint2(base, span);
+  if constexpr (SLOTS) {
+    uint2 o = make_uint2(0u, 0u);                      // span 0: every permutation is in the region
+    if (span != 0u)
+      o = zeros_list ? make_uint2((uint32_t)n1 - base - span + 1u, (uint32_t)n1 - base + 1u)
+                     : make_uint2(base, base + span);
+    lcrit[lidx] = o;
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -558,9 +603,29 @@ int scoary_fisher(scoary_handle h, const int32_t* d_tables, int64_t M, double* d
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   KernelTimer kt(h, s, "k_fisher");
-  hipLaunchKernelGGL(k_fisher, dim3((unsigned)((2 * M + kWave - 1) / kWave)), dim3(kWave), 0, s,
+  hipLaunchKernelGGL(k_fisher<false>, dim3((unsigned)((2 * M + kWave - 1) / kWave)), dim3(kWave), 0, s,
                      reinterpret_cast<const int4*>(d_tables), M, d_p, d_or,
-                     reinterpret_cast<uint2*>(d_crit));
+                     reinterpret_cast<uint2*>(d_crit), nullptr, nullptr, nullptr);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+
+int scoary_fisher_lists(scoary_handle h, const int32_t* d_tables, int64_t T, int64_t G,
+                        const int32_t* d_lorder, const uint8_t* d_lflipped, double* d_p,
+                        double* d_or, uint32_t* d_crit, uint32_t* d_lcrit,
+                        scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tables || !d_lorder || !d_lflipped || !d_p || !d_or || !d_lcrit || T < 1 || G < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_fisher_lists: bad argument");
+  if (T > 65535 || (2 * G + kWave - 1) / kWave > 0x7fffffffLL)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_fisher_lists: T > 65535 or G too large");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer kt(h, s, "k_fisher");
+  hipLaunchKernelGGL(k_fisher<true>, dim3((unsigned)((2 * G + kWave - 1) / kWave), (unsigned)T),
+                     dim3(kWave), 0, s, reinterpret_cast<const int4*>(d_tables), G, d_p, d_or,
+                     reinterpret_cast<uint2*>(d_crit), d_lorder, d_lflipped,
+                     reinterpret_cast<uint2*>(d_lcrit));
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }

@@ -730,18 +730,19 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   }
 }
 
-// r[t][gene of slot k] += sum over the tiles of partial[t][tile][k]
+// r[t][gene of slot k] (+)= sum over the tiles of partial[t][tile][k]
 __global__ __launch_bounds__(256) void k_lists_reduce(const uint16_t* __restrict__ partial,
                                                       int ntiles, int64_t gs, int G,
                                                       const int32_t* __restrict__ order,
-                                                      uint32_t* __restrict__ r) {
+                                                      int accumulate, uint32_t* __restrict__ r) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int t = blockIdx.y;
   if (k >= G) return;
   const uint16_t* in = partial + (int64_t)t * ntiles * gs + k;
   uint32_t sum = 0u;
   for (int tile = 0; tile < ntiles; ++tile) sum += in[(int64_t)tile * gs];
-  r[(int64_t)t * G + order[k]] += sum;
+  uint32_t* dst = r + (int64_t)t * G + order[k];
+  *dst = accumulate ? *dst + sum : sum;
 }
 
 }  // namespace
@@ -844,15 +845,17 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
                                 const uint32_t* d_lidx, int64_t entries, const int32_t* d_lstart,
                                 const int32_t* d_lngroups, const int32_t* d_lorder,
                                 const uint8_t* d_lflipped, const uint32_t* d_crit,
-                                const int32_t* d_margins, uint32_t* d_scratch, int64_t G, int64_t T,
-                                int64_t N, int64_t P, uint32_t* d_r) {
-  uint32_t* d_lcrit = d_scratch;                       // [T][G][2]
+                                const uint32_t* d_lcrit_in, const int32_t* d_margins,
+                                uint32_t* d_scratch, int64_t G, int64_t T, int64_t N, int64_t P,
+                                uint32_t* d_r, int accumulate) {
+  uint32_t* d_lcrit_sc = d_scratch;                    // [T][G][2]
   uint16_t* d_partial = reinterpret_cast<uint16_t*>(d_scratch + 2 * T * G);   // [T][ntiles][gs]
-  {
+  const uint32_t* d_lcrit = d_lcrit_in ? d_lcrit_in : d_lcrit_sc;
+  if (!d_lcrit_in) {               // regions in gene order (scoary_fisher): convert to slot order
     KernelTimer kt(h, s, "k_lists_crit");
     hipLaunchKernelGGL(k_lists_crit, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
                        reinterpret_cast<const uint2*>(d_crit), d_margins, d_lorder, d_lflipped,
-                       (int)G, reinterpret_cast<uint2*>(d_lcrit));
+                       (int)G, reinterpret_cast<uint2*>(d_lcrit_sc));
   }
   const ListGeom g = list_geom(h->num_cu, G, T, N, P, entries);
   if (T * g.ntiles > 0x7fffffffLL || g.chunks > 65535)
@@ -881,7 +884,7 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   {
     KernelTimer kt(h, s, "k_lists_reduce");
     hipLaunchKernelGGL(k_lists_reduce, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
-                       d_partial, (int)g.ntiles, g.gs, (int)G, d_lorder, d_r);
+                       d_partial, (int)g.ntiles, g.gs, (int)G, d_lorder, accumulate, d_r);
   }
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
@@ -897,12 +900,13 @@ int64_t scoary_permute_lists_scratch_bytes(int64_t G, int64_t T, int64_t N, int6
 int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_t* d_lidx,
                          int64_t entries, const int32_t* d_lstart, const int32_t* d_lngroups,
                          const int32_t* d_lorder, const uint8_t* d_lflipped,
-                         const uint32_t* d_crit, const int32_t* d_margins, void* d_scratch,
-                         int64_t G, int64_t T, int64_t N, int64_t P, uint32_t* d_r,
-                         scoary_stream_t stream) {
+                         const uint32_t* d_crit, const uint32_t* d_lcrit, const int32_t* d_margins,
+                         void* d_scratch, int64_t G, int64_t T, int64_t N, int64_t P,
+                         uint32_t* d_r, int accumulate, scoary_stream_t stream) {
   if (!h) return SCOARY_ERR_ARG;
-  if (!d_tiles || !d_lidx || !d_lstart || !d_lngroups || !d_lorder || !d_lflipped || !d_crit ||
-      !d_margins || !d_scratch || !d_r || G < 1 || T < 1 || N < 1 || P < 1 || entries < 0)
+  if (!d_tiles || !d_lidx || !d_lstart || !d_lngroups || !d_lorder || !d_lflipped ||
+      (!d_crit && !d_lcrit) || (!d_lcrit && !d_margins) || !d_scratch || !d_r || G < 1 || T < 1 ||
+      N < 1 || P < 1 || entries < 0)
     return fail(h, SCOARY_ERR_ARG, "scoary_permute_lists: bad argument");
   const int TW = list_tw(N);
   if (!TW)
@@ -914,8 +918,8 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   // counter planes KC: lists hold <= N/2 entries, N/2 < 2^KC (and N + 1 < 2^(KC+1))
 #define LAUNCH(TWV, KCV)                                                                        \
   return launch_permute_lists<TWV, KCV>(h, s, d_tiles, d_lidx, entries, d_lstart, d_lngroups,   \
-                                        d_lorder, d_lflipped, d_crit, d_margins, sc, G, T, N, P, \
-                                        d_r)
+                                        d_lorder, d_lflipped, d_crit, d_lcrit, d_margins, sc, G, \
+                                        T, N, P, d_r, accumulate)
   if (TW == 16) LAUNCH(16, 11);
   if (TW == 8) LAUNCH(8, 12);
   if (TW == 4) LAUNCH(4, 13);

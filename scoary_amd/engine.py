@@ -61,13 +61,14 @@ class Workspace:
         self.odds = eng._empty((T, G), torch.float64)
         self.crit = eng._empty((T, G, 2), torch.int32) if permutations > 0 else None
         self.r = eng._empty((T, G), torch.int32) if permutations > 0 else None
-        self.tiles = self.scratch = self.perms = None
+        self.tiles = self.scratch = self.perms = self.lcrit = None
         self.batch = 0
         if permutations > 0 and use_lists:
             self.batch = eng.list_batch(T, N, permutations, G)
             nb0 = min(self.batch, permutations)
             self.tiles = eng._empty((int(eng.lib.scoary_list_tiles_words(N, nb0, T)),), torch.int32)
             self.scratch = eng.permute_lists_scratch(G, T, N, nb0)
+            self.lcrit = eng._empty((T, G, 2), torch.int32)
         elif permutations > 0:
             if perm_buffer is not None:
                 self.perms = perm_buffer
@@ -253,16 +254,22 @@ class AssociationEngine:
         nbytes = int(self.lib.scoary_permute_lists_scratch_bytes(G, T, N, P))
         return self._empty(((nbytes + 3) // 4,), torch.int32)
 
-    def permute_lists(self, genes, tiles, crit, margins, P, r, scratch=None):
+    def permute_lists(self, genes, tiles, crit, margins, P, r, scratch=None, lcrit=None,
+                      accumulate=True):
+        """r (+)= exceedance counts of P permutations (label tiles ``tiles``).  The regions
+        come in gene order (``crit`` from fisher) or, one launch cheaper, in slot order
+        (``lcrit`` from fisher(..., lists=...)); accumulate=False overwrites r."""
         L = genes.lists
-        T = crit.shape[0]
+        T = (lcrit if lcrit is not None else crit).shape[0]
         if scratch is None:
             scratch = self.permute_lists_scratch(genes.G, T, genes.N, P)
         self._check(self.lib.scoary_permute_lists(
             self.h, self._ptr(tiles), self._ptr(L.idx), L.entries, self._ptr(L.start),
-            self._ptr(L.ngroups), self._ptr(L.order), self._ptr(L.flipped), self._ptr(crit),
+            self._ptr(L.ngroups), self._ptr(L.order), self._ptr(L.flipped),
+            self._ptr(crit) if lcrit is None else None,
+            self._ptr(lcrit) if lcrit is not None else None,
             self._ptr(margins), self._ptr(scratch), genes.G, T, genes.N, P, self._ptr(r),
-            self._stream()), "scoary_permute_lists")
+            1 if accumulate else 0, self._stream()), "scoary_permute_lists")
         return r
 
     # -- a3: counts -----------------------------------------------------------
@@ -278,8 +285,11 @@ class AssociationEngine:
         return counts, margins
 
     # -- a5: Fisher -----------------------------------------------------------
-    def fisher(self, tables, want_crit=True, out=None):
-        """tables: int32 device tensor [..., 4] -> (p, odds, crit) shaped [...]."""
+    def fisher(self, tables, want_crit=True, out=None, lists=None, lcrit=None):
+        """tables: int32 device tensor [..., 4] -> (p, odds, crit) shaped [...].
+        With ``lists`` (the GeneLists of the matrix the [T, G, 4] tables were counted on):
+        scoary_fisher_lists -- tables visited in list-slot order, and the regions also
+        written in the list kernel's form; returns (p, odds, crit, lcrit)."""
         torch = _torch()
         tables = tables.contiguous()
         shape = tables.shape[:-1]
@@ -290,6 +300,17 @@ class AssociationEngine:
             p = self._empty(shape, torch.float64)
             odds = self._empty(shape, torch.float64)
             crit = self._empty(tuple(shape) + (2,), torch.int32) if want_crit else None
+        if lists is not None:
+            if len(shape) != 2:
+                raise ValueError("fisher(lists=...) wants tables shaped [T, G, 4]")
+            if lcrit is None:
+                lcrit = self._empty(tuple(shape) + (2,), torch.int32)
+            self._check(self.lib.scoary_fisher_lists(
+                self.h, self._ptr(tables), shape[0], shape[1], self._ptr(lists.order),
+                self._ptr(lists.flipped), self._ptr(p), self._ptr(odds),
+                self._ptr(crit) if crit is not None else None, self._ptr(lcrit),
+                self._stream()), "scoary_fisher_lists")
+            return p, odds, crit, lcrit
         self._check(self.lib.scoary_fisher(self.h, self._ptr(tables), M, self._ptr(p),
                                            self._ptr(odds),
                                            self._ptr(crit) if crit is not None else None,
@@ -398,15 +419,16 @@ class AssociationEngine:
             nb0 = min(ws.batch, permutations)
             with torch.cuda.stream(side):
                 self.perm_generate_tiles(masks, margins, genes.N, nb0, 0, seed, out=ws.tiles)
-            p, odds, crit = self.fisher(counts, out=(ws.p, ws.odds, ws.crit))
-            ws.r.zero_()
+            p, odds, crit, lcrit = self.fisher(counts, out=(ws.p, ws.odds, ws.crit),
+                                               lists=genes.lists, lcrit=ws.lcrit)
             main.wait_stream(side)
             done = 0
             while done < permutations:
                 nb = min(ws.batch, permutations - done)
                 if done > 0:
                     self.perm_generate_tiles(masks, margins, genes.N, nb, done, seed, out=ws.tiles)
-                self.permute_lists(genes, ws.tiles, crit, margins, nb, ws.r, scratch=ws.scratch)
+                self.permute_lists(genes, ws.tiles, None, margins, nb, ws.r, scratch=ws.scratch,
+                                   lcrit=lcrit, accumulate=done > 0)
                 done += nb
             return {"counts": counts, "margins": margins, "p": p, "odds": odds, "crit": crit,
                     "r": ws.r}

@@ -50,4 +50,5 @@ def test_integration_md_ctypes_stub_runs_and_matches_the_oracle():
     want_r = orc.permute_r(gb, tb, mb, N, P, seed).T
     got = env["d_r"].cpu().numpy().view(np.uint32)
     assert np.array_equal(got, 2 * want_r)      # both flows accumulated the same counts into d_r
+    assert np.array_equal(env["d_r2"].cpu().numpy().view(np.uint32), want_r)   # fused regions, overwrite
     env["lib"].scoary_destroy(env["h"])

@@ -431,9 +431,11 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_counts(h, null, p, p, 1, 1, 1, p, p, null) == -1
     assert b"scoary_counts" in lib.scoary_last_error(h)
     assert lib.scoary_fisher(h, p, 0, p, p, null, null) == -1
+    assert lib.scoary_fisher_lists(h, p, 1, 1, p, p, p, p, null, null, null) == -1        # no d_lcrit
+    assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, null, null, p, p, 4, 1, 100, 10, p, 1, null) == -1
     assert lib.scoary_permute(h, p, p, p, 1, 70000, 10, 10, p, null) == -3          # T > 65535
     assert lib.scoary_perm_generate(h, p, p, 1, 10, 2**33, 0, 0, 1, p, null) == -3   # index >= 2^32
-    assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, p, p, p, 4, 1, 40960, 10, p, null) == -3
+    assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, p, null, p, p, 4, 1, 40960, 10, p, 1, null) == -3
     assert b"LDS" in lib.scoary_last_error(h)
     assert lib.scoary_tree_pairs(h, p, 3, 40, p, p, 1, 1, 2, p, null) == -3          # stack_depth > 32
     assert lib.scoary_counts(null, p, p, p, 1, 1, 1, p, p, null) == -1
@@ -670,3 +672,50 @@ def test_list_path_in_batches_equals_one_shot_and_oracle(eng, orc, monkeypatch):
     b = eng.list_batch(50, 10000, 100000, 125000)
     assert b % 512 == 0 and 2 * 50 * 125064 * (b // 128) <= 4 << 30 and b >= 32768
     assert eng.list_batch(10, 2000, 10000, 50000) == 10240          # the headline config: one batch
+
+
+@pytest.mark.parametrize("N,T", [(333, 3), (2600, 2), (5200, 1)])
+def test_fisher_in_slot_order_and_fused_regions(eng, N, T):
+    from scoary_amd.engine import pack_bits_rows
+    """scoary_fisher_lists: the tables visited in list-slot order give bit-identical p /
+    odds / regions to scoary_fisher (a table's result does not depend on its neighbours),
+    and the slot-order regions it emits drive scoary_permute_lists to the same r as the
+    gene-order regions converted by k_lists_crit; accumulate = 0 overwrites r."""
+    import torch
+    from scoary_amd import synth
+    rng = np.random.default_rng(N)
+    G, P, seed = 3000, 700, 5
+    genes = synth.make_genes(G, N, rng, core_frac=0.03)
+    traits = synth.make_traits(T, N, rng, missing_traits=(0,), missing_frac=0.05)
+    gm = eng.pack_dense(genes)
+    eng.build_lists(gm)
+    trv = eng.vecrows(pack_bits_rows((traits == 1).astype(np.uint8)), N)
+    mkv = eng.vecrows(pack_bits_rows((traits != 2).astype(np.uint8)), N)
+    counts, margins = eng.counts(gm, trv, mkv)
+    p0, o0, c0 = eng.fisher(counts)
+    p1, o1, c1, lc = eng.fisher(counts, lists=gm.lists)
+    assert torch.equal(p0.view(torch.int64), p1.view(torch.int64))
+    assert torch.equal(o0.view(torch.int64), o1.view(torch.int64))
+    assert torch.equal(c0, c1)
+    # the conversion rule, restated on the host
+    order = gm.lists.order.cpu().numpy()
+    fl = gm.lists.flipped.cpu().numpy().astype(bool)[order]
+    c = c0.cpu().numpy().view(np.uint32)[:, order, :].astype(np.int64)
+    npos = margins.cpu().numpy()[:, 0].astype(np.int64)[:, None]
+    lo = np.where(fl[None, :], npos - c[..., 0] - c[..., 1] + 1, c[..., 0])
+    hi = np.where(fl[None, :], npos - c[..., 0] + 1, c[..., 0] + c[..., 1])
+    lo, hi = np.where(c[..., 1] == 0, 0, lo), np.where(c[..., 1] == 0, 0, hi)
+    got = lc.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert np.array_equal(got[..., 0], lo) and np.array_equal(got[..., 1], hi)
+    tiles = eng.perm_generate_tiles(mkv, margins, N, P, 0, seed)
+    r0 = torch.zeros((T, G), dtype=torch.int32, device=eng.device)
+    eng.permute_lists(gm, tiles, c0, margins, P, r0)
+    r1 = torch.full((T, G), 12345, dtype=torch.int32, device=eng.device)
+    eng.permute_lists(gm, tiles, None, margins, P, r1, lcrit=lc, accumulate=False)
+    assert torch.equal(r0, r1)
+    eng.permute_lists(gm, tiles, None, margins, P, r1, lcrit=lc, accumulate=True)
+    assert torch.equal(2 * r0, r1)
+    # and the whole step, against the dense kernels
+    res = eng.associate(gm, trv, mkv, permutations=P, seed=seed)
+    ref = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=False)
+    assert torch.equal(res["r"], ref["r"]) and torch.equal(res["crit"], ref["crit"])
