@@ -5,7 +5,7 @@
 # tools/rocpd_summary.py on the merged gpurun_out/prof_<tag>_<cfg> to install them under profiles/.
 #   tools/profile_configs.sh <tag> cfg4 cfg2 ...
 set -u
-TAG=${1:-r02g}; shift
+TAG=${1:-r02h}; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$REPO"
 for CFG in "$@"; do
