@@ -719,3 +719,48 @@ def test_fisher_in_slot_order_and_fused_regions(eng, N, T):
     res = eng.associate(gm, trv, mkv, permutations=P, seed=seed)
     ref = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=False)
     assert torch.equal(res["r"], ref["r"]) and torch.equal(res["crit"], ref["crit"])
+
+
+def test_fisher_symmetric_margins_and_large_n(eng, orc):
+    """Tables with a symmetric margin pair (n1 == n2, or n == N - n) have an exact mirror
+    tie for every a: k_fisher settles those without arithmetic (x == a, x == n - a,
+    x == n1 - a).  p against the oracle (which compares big integers), the acceptance
+    interval symmetric about the centre, up to the largest N the list path takes; plus
+    unconstrained tables at large N."""
+    import torch
+    rng = np.random.default_rng(77)
+    tabs, kinds = [], []
+    for N in (10, 64, 500, 2000, 5000, 20000, 40958):
+        for _ in range(60):
+            kind = int(rng.integers(0, 3))
+            if kind == 0:                                   # n1 == n2
+                n1 = N // 2; Nn = 2 * n1
+                n = int(rng.integers(1, Nn))
+            elif kind == 1:                                 # n == N - n
+                n = N // 2; Nn = 2 * n
+                n1 = int(rng.integers(1, Nn))
+            else:
+                Nn = N; n1 = int(rng.integers(1, N)); n = int(rng.integers(1, N))
+            n2 = Nn - n1
+            lo, hi = max(0, n - n2), min(n, n1)
+            mode = (n + 1) * (n1 + 1) // (Nn + 2)
+            sd = max(1.0, (n * n1 / Nn * n2 / Nn * (Nn - n) / max(Nn - 1, 1)) ** 0.5)
+            a = int(np.clip(round(mode + rng.normal() * 2.5 * sd), lo, hi))
+            tabs.append((a, n1 - a, n - a, n2 - n + a)); kinds.append(kind)
+    tabs = np.array(tabs, dtype=np.int32)
+    assert tabs.min() >= 0
+    p, odds, crit = eng.fisher(torch.from_numpy(tabs).cuda())
+    p = p.cpu().numpy()
+    crit = crit.cpu().numpy().view(np.uint32).astype(np.int64)
+    _, o_p = orc.fisher_many(tabs)
+    assert np.max(np.abs(p - o_p)) < P_TOL
+    ok = o_p > 1e-280
+    assert np.max(np.abs(p[ok] - o_p[ok]) / o_p[ok]) < 1e-10
+    checked = 0
+    for (a, b, c, d), kind, (base, span) in zip(tabs.tolist(), kinds, crit.tolist()):
+        if kind == 2 or span == 0:
+            continue
+        centre2 = (a + c) if kind == 0 else (a + b)         # x -> n - x  or  x -> n1 - x
+        assert base + (base + span - 1) == centre2, (a, b, c, d, base, span)
+        checked += 1
+    assert checked > 150
