@@ -285,7 +285,9 @@ bool parse_span(const scoary_gpa* g, const std::vector<int32_t>& slot, size_t lo
   return true;
 }
 
-int finish_pieces(scoary_gpa* g, std::vector<Piece>& pieces) {
+// range_start > 0: the pieces are one rank's byte range of the body -- the rows before it were
+// parsed elsewhere, so the bad row is named by its position inside the range
+int finish_pieces(scoary_gpa* g, std::vector<Piece>& pieces, size_t range_start = 0) {
   const int64_t ncols = (int64_t)g->header.size();
   for (auto& pc : pieces) {
     g->bits.insert(g->bits.end(), pc.bits.begin(), pc.bits.end());
@@ -293,8 +295,10 @@ int finish_pieces(scoary_gpa* g, std::vector<Piece>& pieces) {
     g->meta.append(pc.meta);
     g->rows += pc.rows;
     if (pc.bad_cells >= 0) {
-      g->err = "row " + std::to_string(g->rows + 2) + " has " + std::to_string(pc.bad_cells) +
-               " cells, header has " + std::to_string(ncols);
+      g->err = (range_start ? "data row " + std::to_string(g->rows + 1) + " of the byte range starting at offset " +
+                                  std::to_string(range_start)
+                            : "row " + std::to_string(g->rows + 2)) +
+               " has " + std::to_string(pc.bad_cells) + " cells, header has " + std::to_string(ncols);
       return -5;
     }
   }
@@ -344,7 +348,7 @@ int scoary_gpa_parse_part(scoary_gpa_t g, const uint8_t* keep, int64_t part, int
     g->err = "a part boundary lies inside a quoted cell: parse the file in one piece";
     return -6;
   }
-  return finish_pieces(g, pieces);
+  return finish_pieces(g, pieces, part > 0 ? outer[part] : 0);
 }
 
 int scoary_gpa_parse(scoary_gpa_t g, const uint8_t* keep) {

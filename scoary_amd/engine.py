@@ -456,15 +456,24 @@ class AssociationEngine:
         self.associate(genes, traits, masks, permutations=permutations, seed=seed,
                        use_lists=use_lists, workspace=workspace)
         torch.cuda.synchronize(self.device)
-        stream = torch.cuda.Stream(device=self.device)
+        if torch.cuda.is_current_stream_capturing():
+            raise _abi.ScoaryHipError("capture(): the current stream is already capturing")
+        stream = torch.cuda.Stream(device=self.device)      # a fresh stream: never mid-capture
         with torch.cuda.stream(stream):
             self._check(self.lib.scoary_graph_begin(self.h, self._stream()), "scoary_graph_begin")
+            failed = True
             try:
                 res = self.associate(genes, traits, masks, permutations=permutations, seed=seed,
                                      use_lists=use_lists, workspace=workspace)
+                failed = False
             finally:
+                # the capture must be ended either way; a graph that came out of a failed step
+                # is destroyed here instead of leaking with the exception
                 g = ctypes.c_void_p()
                 rc = self.lib.scoary_graph_end(self.h, self._stream(), ctypes.byref(g))
+                if (failed or rc != 0) and g.value:
+                    self.lib.scoary_graph_destroy(g)
+                    g = ctypes.c_void_p()
             self._check(rc, "scoary_graph_end")
         return StepGraph(self, g, stream), res
 

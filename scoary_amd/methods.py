@@ -235,6 +235,10 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
         from . import dist as _dist
         world, rank = _dist.world_rank()
         name = _reduced_name(outdir, time)
+        if world > 1:
+            # every rank built `time` from its own clock: ranks that straddle a minute would
+            # look for a file rank 0 never wrote -- rank 0's name is the name
+            name = _dist.all_gather_objects(name)[0]
         if rank == 0:
             ReduceSet(genefile, delimiter, grabcols, startcol, allowed_isolates, time, outdir)
         if world > 1:
@@ -386,7 +390,8 @@ class _LazyZeroOnes:
     def file_rows(self):
         """(file rows, N) uint8 presence of every row of the gene file (what the
         reference's zero_ones_line loop sees, before the all-0 / all-1 filter)."""
-        by = np.ascontiguousarray(self._rows64).view(np.uint8).reshape(self._rows64.shape[0], -1)
+        rows, words = self._rows64.shape     # explicit width: a table without data rows has size 0
+        by = np.ascontiguousarray(self._rows64).view(np.uint8).reshape(rows, words * 8)
         return np.unpackbits(by, axis=1, bitorder="little")[:, :self._n]
 
     def _get(self):
@@ -394,7 +399,8 @@ class _LazyZeroOnes:
             d = self.file_rows()
             tot = d.sum(axis=1) if d.size else np.zeros(0)
             var = (tot > 0) & (tot < d.shape[1])
-            self._lists = d[var].T.tolist() if d.shape[1] else []
+            # no variable row: the reference transposes an empty list, zip(*[]) == [] (:499)
+            self._lists = d[var].T.tolist() if d.shape[1] and var.any() else []
         return self._lists
 
     def __iter__(self):
@@ -425,7 +431,12 @@ def _read_gpa_ranks(io_native, path, delimiter, startcol, allowed_isolates, want
             status = "boundary"
         except io_native.GpaError as e:
             status = "error:" + str(e)
+        except Exception as e:   # OSError, MemoryError, ctypes failure: still reach the gather,
+            status = "fatal:%s: %s" % (type(e).__name__, e)     # or the other ranks block in it
         statuses = _dist.all_gather_objects(status)
+        fatal = [x[6:] for x in statuses if x.startswith("fatal:")]
+        if fatal:
+            raise RuntimeError("reading %s failed on a rank: %s" % (path, fatal[0]))
         if "boundary" not in statuses:
             # (after a boundary inside a quoted cell the NEXT rank starts mid-cell and sees a
             # malformed row: its error means nothing, the whole-file read below decides)
@@ -837,28 +848,44 @@ def decideifbreak(cutoffs, currentgene):
     return False
 
 
+def _kept_ranks(order, cols, cutoffs, num_threads=None):
+    """Ranks (positions in ``order``) of the genes the reference's pairwise stage keeps.
+    Worker k of n walks the ranks k, k+n, k+2n, ... and stops at ITS OWN first gene that fails
+    an I/B/BH cutoff (scoary/methods.py:1076-1078, :1290-1294): the kept set is the union of the
+    workers' prefixes.  With one worker, or with cutoff columns that are monotone in the rank,
+    that is a prefix of ``order``; a non-monotone column (the stale-rank BH of --collapse) lets
+    a later worker keep ranks past another worker's stop.  The weave's modulo (StoreTraitResult)
+    is taken of these ranks."""
+    nworkers = max(1, int(num_threads or 1))
+    ranks = []
+    for k in range(nworkers):
+        for rank in range(k, len(order), nworkers):
+            i = order[rank]
+            if any(m in cutoffs and cols[CUT_FIELD[m]][i] > cutoffs[m] for m in ("I", "B", "BH")):
+                break
+            ranks.append(rank)
+    return np.array(sorted(ranks), dtype=np.int64)
+
+
 def _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC, Prunedic, permutations,
-                    genedic, seed):
+                    genedic, seed, num_threads=None):
     """PairWiseComparisons (methods.py:1208-1312) for the genes ``order`` (row
     indices, ascending naive p) of one trait, on the GPU: the prefix that passes
     the I/B/BH cutoffs gets max contrasting / supporting / opposing pairs, the
     two binomial p-values and, with permutations, the tree-statistic empirical p.
-    Returns (row indices kept, dict of extra columns over those rows)."""
+    Returns (row indices kept, their ranks in ``order``, dict of extra columns over those
+    rows)."""
     from . import tree as T
     cols = {k: np.asarray(Trait.column(k)) for k in ("p_v", "B_p", "BH_p")}
-    keep = []
-    for i in order:
-        if any(m in cutoffs and cols[CUT_FIELD[m]][i] > cutoffs[m] for m in ("I", "B", "BH")):
-            break
-        keep.append(int(i))
-    keep = np.array(keep, dtype=np.int64)
+    ranks = _kept_ranks(order, cols, cutoffs, num_threads)
+    keep = np.asarray(order, dtype=np.int64)[ranks] if len(ranks) else np.zeros(0, dtype=np.int64)
     extra = {k: np.zeros(len(keep)) for k in ("Pbest", "Pworst", "Plowest", "Pboth")}
     for k in ("max_total_pairs", "max_propairs", "max_antipairs"):
         extra[k] = np.zeros(len(keep), dtype=np.int64)
     if permutations >= 10:
         extra["Empirical_p"] = np.zeros(len(keep))
     if len(keep) == 0:
-        return keep, extra
+        return keep, ranks, extra
     gtc = GTC[Traitname]
     table = gtc.table
     tree = upgmatree
@@ -893,7 +920,7 @@ def _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC, Prunedic, 
         exceed = stage.permute(rows64, obs, permutations)
         for k in range(len(keep)):
             extra["Empirical_p"][k] = T.empirical_p_sequential(exceed[k])
-    return keep, extra
+    return keep, ranks, extra
 
 
 def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Prunedic, outdir,
@@ -943,8 +970,8 @@ def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Pruned
         log.info("Calculating max number of contrasting pairs for each %s gene%s"
                  % ("significant" if with_emp else "nominally significant",
                     " and performing %d permutations" % permutations if with_emp else ""))
-        keep, extra = _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC, Prunedic,
-                                      permutations, genedic, seed)
+        keep, ranks, extra = _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC,
+                                             Prunedic, permutations, genedic, seed, num_threads)
         colget = {k: np.asarray(Trait.column(k)) for k in fields}
         # sort key of the filtered set (methods.py:1124-1135); ``keep`` is already
         # in ascending-p order, and every sort is stable
@@ -953,7 +980,9 @@ def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Pruned
             # --threads n: the reference hands worker k the ranks k, k+n, k+2n, ... and weaves the
             # workers' results back thread by thread (scoary/methods.py:1076-1078, 1115-1122), so
             # rows with EQUAL sort keys come out in (rank mod n, rank) order
-            pos = np.lexsort((pos, pos % int(num_threads)))
+            # -- the modulo is of the gene's rank in the sorted results, not of its position in
+            # ``keep`` (the two differ once a worker stopped before another)
+            pos = np.lexsort((ranks, ranks % int(num_threads)))
         if any(m in cutoffs for m in ("I", "B", "BH")):
             pos = pos[np.argsort(colget["p_v"][keep][pos], kind="stable")]
         elif "EPW" in cutoffs:

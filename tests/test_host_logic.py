@@ -669,3 +669,31 @@ def test_bench_refuses_counters_of_other_kernel_sources(tmp_path, monkeypatch):
     assert bench.load_counters("cfg4", True, "k_permute_lists")[0] is None        # other workload
     ctr, why = bench.load_counters("cfg3", False, "k_permute_lists")              # shape overridden
     assert ctr is None and "overridden" in why
+
+
+def test_kept_ranks_are_the_union_of_the_workers_prefixes():
+    """the reference's worker k of n stops at its own first failing rank
+    (scoary/methods.py:1076-1078, :1290-1294); the weave's modulo is of the rank in the
+    sorted results.  Monotone cutoff columns: a plain prefix, whatever n.  A non-monotone
+    column (stale-rank BH under --collapse): worker 1 keeps rank 3 although rank 2 failed."""
+    from scoary_amd import methods as M
+    order = np.array([4, 2, 0, 3, 1])
+    mono = {"p_v": np.array([.03, .5, .02, .04, .01]), "B_p": np.ones(5), "BH_p": np.ones(5)}
+    for n in (None, 1, 2, 3, 7):
+        assert M._kept_ranks(order, mono, {"I": 0.035}, n).tolist() == [0, 1, 2]
+    bh = np.ones(5)
+    bh[order] = [.01, .01, .9, .02, .9]           # by rank: pass pass FAIL pass FAIL
+    cols = {"p_v": mono["p_v"], "B_p": np.ones(5), "BH_p": bh}
+    assert M._kept_ranks(order, cols, {"BH": 0.05}, 1).tolist() == [0, 1]
+    assert M._kept_ranks(order, cols, {"BH": 0.05}, 2).tolist() == [0, 1, 3]   # worker 1: ranks 1, 3
+    assert M._kept_ranks(order, cols, {"BH": 0.05}, 3).tolist() == [0, 1, 3]   # worker 0: ranks 0, 3
+    assert M._kept_ranks(order, cols, {"P": 0.05}, 2).tolist() == [0, 1, 2, 3, 4]   # no I/B/BH cutoff
+
+
+def test_zero_ones_matrix_of_a_table_without_data_rows():
+    """a header-only (or fully filtered) gene table has a (0, W) bit matrix; the
+    lazy Zero_ones_matrix must be empty, not a numpy reshape error."""
+    from scoary_amd import methods as M
+    z = M._LazyZeroOnes(np.zeros((0, 3), dtype=np.uint64), 130)
+    assert z.file_rows().shape == (0, 130)
+    assert len(z) == 0 and list(z) == []
