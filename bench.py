@@ -47,7 +47,11 @@ VALU_NOMINAL_LANE_OPS = 256 * 4 * 32 * 2.4e9
 # VGPR operands in distinct banks (tools/valu_banks.hip: 2.5 cycles per wave-instruction at 8 waves
 # per SIMD, 2.8 at the 4 the list kernel runs with)
 VALU_PEAK_AND_BCNT = 4.1e13
-VALU_PEAK_BITOP3 = 6.2e13
+# sustained v_bitop3_b32, conflict-free banks, no memory traffic (profiles/r02_clock_valu_both_occupancies.txt):
+# 5.61e13 at the 4 waves per SIMD the list kernel can have (127 VGPRs, one 1024-thread block per CU),
+# 6.06e13 at 8 waves per SIMD (out of its reach: <= 64 VGPRs)
+VALU_PEAK_BITOP3_4WAVES = 5.61e13
+VALU_PEAK_BITOP3_8WAVES = 6.06e13
 KERNEL_SOURCES = ("scoary_lists.hip", "scoary_assoc.hip", "scoary_common.hpp",
                   "scoary_ctr_regs.inc", "scoary_vgpr_banks.inc")
 
@@ -83,6 +87,9 @@ def parse(argv=None):
     ap.add_argument("--share-gpu", action="store_true",
                     help="map rank r to device r %% visible devices instead of requiring one GPU per "
                          "rank (functional check only: the ranks time-share the device)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="after the timed region rank 0 recomputes every rank's shard by itself and "
+                         "compares the gathered records with it bit for bit (gather_matches_single_rank)")
     ap.add_argument("--dry-exchange", action="store_true",
                     help="CPU-only check of the launcher + exchange path (gloo, fabricated "
                          "records, no kernels): what tests/test_dist_gloo.py drives")
@@ -181,7 +188,8 @@ def cpu_baseline_port(genes, traits, N, seed, target_s):
     orc.permute_r(gb, tb, mb, N, Ps, seed)
     dt = time.perf_counter() - t0
     return {"value": Gs * T * Ps / dt, "unit": "gene-permutation Fisher tests/s",
-            "cores": cores, "kind": "port",
+            "cores": cores, "cores_are": "OpenMP threads = logical CPUs (SMT siblings included)",
+            "kind": "port",
             "sample": "oracle/oracle.c orc_permute_r (bit-packed popcount counts + Fisher weights + "
                       "label permutations + exceedance), %d genes x %d isolates x %d traits x %d "
                       "permutations, %d OpenMP threads, %.1f s" % (Gs, N, T, Ps, cores, dt)}
@@ -230,6 +238,7 @@ def cpu_baseline_scipy(eng, genes, traits, N, seed, target_s):
               and np.max(np.abs(gp - p)) < 1e-12)
     tests = Gs * (Ps + 1)
     return {"value": tests / dt, "unit": "gene-permutation Fisher tests/s", "cores": n,
+            "cores_are": "Pool workers = os.cpu_count() logical CPUs (SMT siblings included)",
             "kind": "scipy-restatement", "matches_gpu": ok,
             "sample": "oracle/scipy_baseline.py: per-isolate Python counting + memoised "
                       "scipy.stats.fisher_exact, multiprocessing.Pool(%d) over stride domains "
@@ -326,13 +335,41 @@ def measured_copy_peak(device):
     return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
+def list_adder_work(eng, gm, genes, T, P, batch):
+    """Lane-ops of one k_permute_lists launch that are the algorithm itself: the bit-sliced
+    full adders.  A list entry adds one tile-row word into the counter planes of every
+    permutation word: 32 entries -> 31 full adders per word, a full adder = 2 v_bitop3_b32
+    (sum 0x96, carry 0xE8).  A wave group of GPW genes walks its lists padded to the group's
+    common length (nhalf half-steps of 16 entries, scoary_lists_plan), 64 lanes x NW words:
+        adder_lane_ops = sum_groups nhalf*16 * 64*NW * (31/32)*2  x  T * tiles per launch
+    `unpadded` takes the genes' true minority counts instead (padding is not useful either).
+    Everything else the kernel issues -- address adds, ripple, region test, epilogue, index and
+    tile loads -- is overhead."""
+    tw, _stride, gpw, _classes, _piece = eng.list_params(gm.N)
+    nw = tw // (64 // gpw)
+    nhalf = gm.lists.ngroups.cpu().numpy().astype(np.int64)[::gpw]        # one per wave group
+    tile_perms = 32 * tw
+    launches = -(-P // batch)
+    tiles_per_launch = sum(-(-min(batch, P - b) // tile_perms) for b in range(0, P, batch)) / launches
+    per_tile_padded = float(nhalf.sum()) * 16 * 64 * nw * (31.0 / 32.0) * 2.0
+    ones = genes.sum(axis=1, dtype=np.int64)
+    minority = np.minimum(ones, gm.N - ones)
+    per_tile_true = float(minority.sum()) * tw * (31.0 / 32.0) * 2.0
+    return {"padded": per_tile_padded * T * tiles_per_launch,
+            "unpadded": per_tile_true * T * tiles_per_launch,
+            "padded_entries_per_gene": float(nhalf.sum()) * 16 * gpw / max(gm.G, 1),
+            "minority_entries_per_gene": float(minority.mean())}
+
+
+def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms, adders=None):
     """The `roofline` object.  What binds the permutation kernel is integer-VALU issue,
     not HBM, so: bound = "valu", achieved = lane-ops/s from the
     SQ_INSTS_VALU count of the committed PMC pass of THIS kernel version (sha-checked)
     and the live hipEvent duration, peak = the nominal SIMD peak (frac <= 1 by
-    construction); the measured v_bitop3 ceiling, the SURVEY 8d operand-bandwidth figure
-    and the measured HBM traffic ride along."""
+    construction).  `frac` is a UTILISATION (every overhead instruction raises it);
+    `useful_frac` counts only the full-adder lane-ops the algorithm needs (list_adder_work)
+    against the same peak.  The measured v_bitop3 ceilings, the SURVEY 8d
+    operand-bandwidth figure and the measured HBM traffic ride along."""
     W64 = (N + 63) // 64
     launches_per_step = -(-P // pbatch)                # label tiles / label rows come in batches
     tests_per_launch = G * T * P / launches_per_step   # average over the launches of a step
@@ -346,18 +383,30 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
         valu = ctr["SQ_INSTS_VALU"] * 64.0                # lane-ops per launch
         traffic = ctr.get("hbm_traffic_bytes_per_launch")
     copy_gbs = measured_copy_peak(eng.device)
-    measured_peak = VALU_PEAK_BITOP3 if use_lists else VALU_PEAK_AND_BCNT
-    return {
+    measured_peak = VALU_PEAK_BITOP3_4WAVES if use_lists else VALU_PEAK_AND_BCNT
+    useful = adders["padded"] if adders else None
+    out = {
         "bound": "valu",
         "kernel": k3_name,
         "achieved": None if valu is None else valu / sec / 1e12,
         "peak": VALU_NOMINAL_LANE_OPS / 1e12,
         "unit": "T lane-ops/s (SQ_INSTS_VALU x 64 / kernel time; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz)",
         "frac": None if valu is None else valu / sec / VALU_NOMINAL_LANE_OPS,
+        # how much of the issue is the algorithm: full-adder lane-ops only (list_adder_work)
+        "useful_lane_ops": useful,
+        "useful_frac": None if useful is None else useful / sec / VALU_NOMINAL_LANE_OPS,
+        "useful_frac_unpadded": None if not adders else adders["unpadded"] / sec / VALU_NOMINAL_LANE_OPS,
+        "adder_ops_per_test": None if useful is None else useful / tests_per_launch,
+        "overhead_ops_per_test": None if (useful is None or valu is None)
+                                 else (valu - useful) / tests_per_launch,
+        "padded_entries_per_gene": None if not adders else adders["padded_entries_per_gene"],
+        "minority_entries_per_gene": None if not adders else adders["minority_entries_per_gene"],
         "frac_of_measured_op_peak": None if valu is None else valu / sec / measured_peak,
         "measured_op_peak": measured_peak / 1e12,
-        "measured_op_peak_source": "tools/valu_banks.hip (v_bitop3_b32, 8 waves/SIMD)" if use_lists
+        "measured_op_peak_source": ("profiles/r02_clock_valu_both_occupancies.txt (sustained v_bitop3_b32 at "
+                                    "the 4 waves/SIMD this kernel can have)") if use_lists
                                    else "tools/valu_peak.hip (v_and_b32 + v_bcnt_u32_b32)",
+        "measured_op_peak_8waves": VALU_PEAK_BITOP3_8WAVES / 1e12 if use_lists else None,
         "ops_per_test": None if valu is None else valu / tests_per_launch,
         "counters_source": ctr["source"] if ctr else None,
         "counters_refused": why,
@@ -376,9 +425,10 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms):
         "operand_bw_gbs": operand_bytes / sec / 1e9,
         "operand_bw_frac": operand_bytes / sec / 1e9 / HBM_PEAK_GBS,
         "operand_bytes_per_launch": operand_bytes,
-        "clock_note": "the list kernel runs at the socket power cap: ~1.37 kW, shader clock ~2.15 of "
-                      "2.4 GHz (profiles/r01_clock_power.txt)" if use_lists else None,
+        "clock_note": "the list kernel runs at the socket power cap: 1.31-1.38 kW, shader clock 2.14-2.22 "
+                      "of 2.4 GHz (profiles/r02_clock_power.txt)" if use_lists else None,
     }
+    return out
 
 
 def dry_exchange(args, world, rank):
@@ -450,19 +500,23 @@ def main():
 
     c = synth.CONFIGS[args.config]
     G_cfg = args.genes or (c["G"] // 8 if args.config == "cfg5" else c["G"])   # cfg5: the per-GPU shard
-    bounds = None
-    genes, traits, P, seed = synth.make_config(args.config, G=G_cfg, N=args.isolates, T=args.traits)
-    if args.scaling == "strong" and world > 1:
-        # the config's genes, split: every rank generates the same matrix and keeps its rows
-        bounds = sdist.shard_bounds(G_cfg, world)
-        a, b = bounds[rank]
-        genes = np.ascontiguousarray(genes[a:b])
-    elif rank > 0:
-        # weak: every rank its own G-gene shard (different seed offset), same traits
-        rng = np.random.default_rng(seed + 1000 * rank)
-        genes = synth.make_genes(genes.shape[0], genes.shape[1], rng,
-                                 kind="rare" if args.config == "cfg4" else "uniform",
-                                 core_frac=0.05 if args.config in ("cfg3", "cfg5") else 0.0)
+    bounds = sdist.shard_bounds(G_cfg, world) if (args.scaling == "strong" and world > 1) else None
+    base_genes, traits, P, seed = synth.make_config(args.config, G=G_cfg, N=args.isolates, T=args.traits)
+
+    def shard_of(rk):
+        """The gene rows rank rk works on.  strong: the config's genes, split -- every rank
+        generates the same matrix and keeps its rows; weak: every rank its own G-gene shard
+        (different seed offset), same traits."""
+        if bounds is not None:
+            a, b = bounds[rk]
+            return np.ascontiguousarray(base_genes[a:b])
+        if rk == 0:
+            return base_genes
+        rng = np.random.default_rng(seed + 1000 * rk)
+        return synth.make_genes(base_genes.shape[0], base_genes.shape[1], rng,
+                                kind="rare" if args.config == "cfg4" else "uniform",
+                                core_frac=0.05 if args.config in ("cfg3", "cfg5") else 0.0)
+    genes = shard_of(rank)
     if args.permutations:
         P = args.permutations
     G, N = genes.shape
@@ -524,8 +578,17 @@ def main():
     for i in range(args.steps):
         step()
         ev[i + 1].record()
+    exposed_ms = None
+    if exchange:
+        # what the exchange step costs beyond the kernels: wall clock from the moment this
+        # rank's last kernel (the record packing of the last step) has finished to the end of
+        # the timed region -- draining the gathers still in flight + the closing barrier
+        ev[args.steps].synchronize()
+        t_kernels = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    if exchange:
+        exposed_ms = (time.perf_counter() - t_kernels) * 1e3
     step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if step_ms else None
     if graph is not None:                           # per-kernel times: a few eager steps afterwards
@@ -541,15 +604,42 @@ def main():
     kernel_ms = {k: eng.kernel_ms(k) for k in names}
     eng.set_timing(False)
 
+    dt_own = dt
+    per_rank = None
     if sharded:                                      # MAX over ranks
         tmax = torch.tensor([dt], dtype=torch.float64,
                             device=eng.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # one line per rank, so that a sub-linear point of the scaling curve explains itself:
+        # its own wall clock, its kernels, the bytes it sends per step and how long the
+        # exchange kept it waiting after its last kernel
+        mine = {"rank": rank, "device": local_rank, "genes": G, "ms_per_step": dt_own / args.steps * 1e3,
+                "ms_per_step_median": median_ms, "kernel_ms": kernel_ms,
+                "exchange_exposed_ms": exposed_ms,
+                "exchange_bytes": T * G * sdist.REC_WORDS * 4}
+        per_rank = sdist.all_gather_objects(mine)
     nval = (traits != 2).sum(1)
     rccl_ranks = exchange.check(T, nval) if exchange else None
     if exchange and rank == 0 and exchange.kind == "gather" and rccl_ranks != world:
         raise SystemExit("bench.py: rank 0 received valid records from %s of %d ranks" % (rccl_ranks, world))
+    gather_ok = None
+    if args.verify_gather and exchange and rank == 0 and exchange.kind == "gather":
+        # rank 0 alone recomputes every rank's shard and compares the block it received from
+        # that rank in the last step, record for record (counts, p, odds, r: 40 bytes each)
+        last = exchange.recv[(exchange.step_no - 1) % 2]
+        gather_ok = True
+        for rk, (a, b) in enumerate(sdist.shard_bounds(exchange.total, world)):
+            g_rk = eng.tile_rows(pack_bits_rows(shard_of(rk)), N)
+            if use_lists:
+                eng.build_lists(g_rk)
+            alone = eng.pack_records(eng.associate(g_rk, trv, mkv, permutations=P, seed=seed,
+                                                   use_lists=use_lists))
+            gather_ok = gather_ok and bool(torch.equal(last[rk, :, :b - a], alone))
+        if not gather_ok:
+            raise SystemExit("bench.py: the gathered records differ from a single-rank run")
+    if sharded:
+        dist.barrier()                               # the other ranks wait for rank 0's checks
 
     if rank == 0:
         tests_per_step = G_total * T * P
@@ -579,6 +669,8 @@ def main():
                            exchange.kind)) if exchange
                        else "none (single GPU)"},
             "rccl_ranks": rccl_ranks,
+            "gather_matches_single_rank": gather_ok,
+            "per_rank": per_rank,
             # once per data set, outside the timed region: H2D of the packed bits + device tiling +
             # device list build + trait vectors (host bit-packing and parsing excluded)
             "setup_ms": setup_ms,
@@ -586,8 +678,9 @@ def main():
             "value_single_step_incl_setup": tests_per_step / (dt / args.steps + setup_ms * 1e-3),
             # SURVEY 8d's end-to-end figure: the observed tables count as tests too, G*T*(P+1)
             "value_incl_observed_tables": G_total * T * (P + 1) * args.steps / dt,
-            "roofline": roofline_report(args, eng, use_lists, G, N, T, P,
-                                        ws.batch if use_lists else pbatch, k3_name, k3_ms),
+            "roofline": roofline_report(
+                args, eng, use_lists, G, N, T, P, ws.batch if use_lists else pbatch, k3_name, k3_ms,
+                adders=list_adder_work(eng, gm, genes, T, P, ws.batch) if use_lists else None),
             "kernel_ms": kernel_ms,
         }
         if world == 1 and not args.no_cpu_baseline:

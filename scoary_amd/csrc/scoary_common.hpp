@@ -70,6 +70,7 @@ __host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int TW) {
 
 constexpr int kListPad = 16;        // list lengths are padded to a multiple of this many entries (half a 32-entry step)
 constexpr int kListStartUnit = 32;  // d_lstart counts in units of this many entries (128 bytes)
+constexpr int kListChunkMB = 2;     // MB of index lists per k_permute_lists block (an XCD's L2 is 4 MB)
 constexpr int kListSlack = 256;     // zero entries after the last list (one wavefront index load)
 
 int fail(scoary_handle h, int code, const std::string& msg) {

@@ -815,6 +815,16 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
 }
 
 extern "C++" {
+// Bytes of index lists one k_permute_lists block walks against its LDS tile.  SCOARY_LIST_CHUNK_MB
+// (1..64) overrides it for same-box A/B runs (tools/ab_chunk.sh); read once per process.
+static int64_t list_chunk_bytes() {
+  static const int64_t bytes = [] {
+    const char* e = std::getenv("SCOARY_LIST_CHUNK_MB");
+    const long mb = e ? std::strtol(e, nullptr, 10) : 0;
+    return (int64_t)((mb >= 1 && mb <= 64) ? mb : kListChunkMB) << 20;
+  }();
+  return bytes;
+}
 // Launch geometry of k_permute_lists (also sizes the scratch)
 struct ListGeom {
   int64_t ntiles, ngroups, gs, gpb, chunks;
@@ -830,7 +840,8 @@ static ListGeom list_geom(int num_cu, int64_t G, int64_t T, int64_t N, int64_t P
   // (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the chunk run;
   // each chunk a multiple of 16 wave groups (one per wavefront)
   int64_t chunks = ((int64_t)num_cu * 16 + g.ntiles * T - 1) / (g.ntiles * T);
-  const int64_t by_l2 = (entries * 4 + (2 << 20) - 1) / (2 << 20);
+  const int64_t chunk_bytes = list_chunk_bytes();
+  const int64_t by_l2 = (entries * 4 + chunk_bytes - 1) / chunk_bytes;
   if (chunks < by_l2) chunks = by_l2;
   if (chunks > 65535) chunks = 65535;
   if (chunks < 1) chunks = 1;

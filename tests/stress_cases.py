@@ -1,0 +1,137 @@
+"""Randomised cross-checks of the list path's three device stages, one case per call (fixed
+seeds): what tools/stress_{tiles,lists,listbuild}.py and tools/bigcheck.py used to run by
+hand.  tests/test_gpu_stress.py runs them under `pytest -m gpu`; the tools are thin loops
+over the same functions for longer soaks on a GPU box.
+
+Every function returns (ok, description).
+"""
+import numpy as np
+
+TILE_N = [1, 5, 63, 64, 65, 127, 128, 129, 500, 1000, 2559, 2560, 4000, 5120, 9000, 10240, 15000,
+          20480, 31000, 40959]
+LIST_N = [1, 2, 31, 32, 33, 64, 100, 511, 1000, 2047, 2048, 2559, 2560, 3333, 5119, 5120, 7777,
+          10239, 10240, 13001, 20479, 20480, 33333, 40959]
+BUILD_N = [1, 2, 15, 16, 17, 31, 33, 64, 100, 511, 1000, 2047, 2559, 2560, 3333, 5119, 5120, 7777,
+           10239, 10240, 13001, 20479, 20480, 33333, 40959]
+
+
+def _bits(traits):
+    from scoary_amd.engine import pack_bits_rows
+    return (pack_bits_rows((traits == 1).astype(np.uint8)),
+            pack_bits_rows((traits != 2).astype(np.uint8)))
+
+
+def _traits(rng, T, N, p_missing):
+    traits = (rng.random((T, N)) < rng.uniform(0.05, 0.95)).astype(np.uint8)
+    for t in range(T):
+        if rng.random() < p_missing:
+            traits[t, rng.random(N) < rng.uniform(0.0, 0.3)] = 2
+    return traits
+
+
+def tiles_case(eng, case, seed=11):
+    """Label tiles (all three generator kernels) == transposed row-major labels of
+    k_perm_generate: spec S4 draws, tile layout, zero row N, zero padding columns."""
+    rng = np.random.default_rng([seed, case])
+    N = int(rng.choice(TILE_N))
+    T = int(rng.integers(1, 5))
+    P = int(rng.choice([1, 31, 64, 65, 500, 513, 1200]))
+    if case % 10 == 9:
+        T, P = 3, 22000                                   # >= 1024 wavefronts: one-wavefront kernel
+        N = int(rng.choice([64, 100, 333]))
+    base = int(rng.integers(0, 1000))
+    traits = _traits(rng, T, N, 0.6)
+    tb, mb = _bits(traits)
+    masks, trv = eng.vecrows(mb, N), eng.vecrows(tb, N)
+    _, margins = eng.counts(eng.pack_dense(np.ones((1, N), dtype=np.uint8)), trv, masks)
+    rows = eng.perm_generate(masks, margins, N, P, base, 5 + case).cpu().numpy().view(np.uint32)
+    tiles = eng.perm_generate_tiles(masks, margins, N, P, base, 5 + case).cpu().numpy().view(np.uint32)
+    tw_, stride, _g, _c, _p = eng.list_params(N)
+    RS, tperm = stride // 4, tw_ * 32
+    ntiles = -(-P // tperm)
+    tw = int(eng.lib.scoary_list_tile_words(N))
+    tiles = tiles.reshape(T, ntiles, tw)[:, :, :(N + 1) * RS].reshape(T, ntiles, N + 1, RS)
+    bits = np.unpackbits(rows.view(np.uint8).reshape(T, P, -1), axis=2, bitorder="little")[:, :, :N]
+    ok = True
+    for t in range(T):
+        for tile in range(ntiles):
+            tb_ = np.unpackbits(np.ascontiguousarray(tiles[t, tile]).view(np.uint8), axis=1,
+                                bitorder="little")
+            lo, hi = tile * tperm, min(P, tile * tperm + tperm)
+            ok &= (not tb_[N].any() and np.array_equal(tb_[:N, :hi - lo], bits[t, lo:hi].T)
+                   and not tb_[:N, hi - lo:].any())
+    return bool(ok), "tiles N=%d T=%d P=%d base=%d" % (N, T, P, base)
+
+
+def _gene_freq(rng, dens, G):
+    return {"uniform": rng.uniform(0, 1, (G, 1)), "sparse": rng.uniform(0, 0.03, (G, 1)),
+            "dense": rng.uniform(0.97, 1, (G, 1)), "half": np.full((G, 1), 0.5),
+            "ties": np.full((G, 1), 0.2)}[dens]
+
+
+def lists_case(eng, case, seed=23):
+    """List-driven permutation kernel == dense kernel (itself oracle-checked in
+    test_gpu_parity.py): identical r for every (gene, trait)."""
+    import torch
+    rng = np.random.default_rng([seed, case])
+    N = int(rng.choice(LIST_N))
+    G = int(rng.choice([1, 3, 15, 16, 17, 63, 64, 65, 300, 1000, 4097]))
+    T = int(rng.integers(1, 4))
+    P = int(rng.choice([1, 100, 128, 129, 512, 513, 700]))
+    dens = str(rng.choice(["uniform", "sparse", "dense", "half"]))
+    genes = (rng.random((G, N)) < _gene_freq(rng, dens, G)).astype(np.uint8)
+    traits = _traits(rng, T, N, 0.5)
+    tb, mb = _bits(traits)
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    d = eng.associate(gm, trv, mkv, permutations=P, seed=case, use_lists=False)["r"]
+    eng.build_lists(gm)
+    l = eng.associate(gm, trv, mkv, permutations=P, seed=case, use_lists=True)["r"]
+    return bool(torch.equal(d, l)), "lists G=%d N=%d T=%d P=%d %s" % (G, N, T, P, dens)
+
+
+def listbuild_case(eng, case, seed=91):
+    """Device list builder (scoary_lists_plan / _fill) == host builder (scoary_lists_build,
+    the checker): every array and every index entry."""
+    from scoary_amd import io_native
+    from scoary_amd.engine import pack_bits_rows
+    rng = np.random.default_rng([seed, case])
+    N = int(rng.choice(BUILD_N))
+    G = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 63, 64, 65, 300, 1000, 2047, 2049, 4097, 9000]))
+    dens = str(rng.choice(["uniform", "sparse", "dense", "half", "ties"]))
+    genes = (rng.random((G, N)) < _gene_freq(rng, dens, G)).astype(np.uint8)
+    if dens == "ties" and G > 4:                     # many equal lengths: the sort must be stable
+        genes[G // 2:] = genes[:G - G // 2]
+    gm = eng.pack_dense(genes)
+    L = eng.build_lists(gm)
+    lanes, stride, gpw, classes, piece = eng.list_params(N)
+    H = io_native.build_lists(pack_bits_rows(genes), N, stride, gpw, classes, piece)
+    ok = (L.entries == H["entries"]
+          and np.array_equal(L.order.cpu().numpy(), H["order"])
+          and np.array_equal(L.flipped.cpu().numpy(), H["flipped"])
+          and np.array_equal(L.start.cpu().numpy(), H["start"])
+          and np.array_equal(L.ngroups.cpu().numpy(), H["ngroups"])
+          and np.array_equal(L.idx.cpu().numpy().view(np.uint32)[:L.entries], H["idx"][:L.entries]))
+    return bool(ok), "listbuild G=%d N=%d %s" % (G, N, dens)
+
+
+BIG_SHAPES = [(200000, 5000, 1, 512, "rare"), (30000, 10000, 50, 128, "uniform"),
+              (100000, 2559, 3, 1024, "uniform")]
+
+
+def big_case(eng, shape):
+    """Large shapes (one per tile width 8 / 4 / 16): list kernel == dense kernel on every
+    (gene, trait) pair."""
+    import torch
+    from scoary_amd import synth
+    G, N, T, P, kind = shape
+    rng = np.random.default_rng(G + N)
+    genes = synth.make_genes(G, N, rng, kind=kind, core_frac=0.02)
+    traits = synth.make_traits(T, N, rng, missing_traits=(0,))
+    tb, mb = _bits(traits)
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    d = eng.associate(gm, trv, mkv, permutations=P, seed=5, use_lists=False)["r"]
+    eng.build_lists(gm)
+    l = eng.associate(gm, trv, mkv, permutations=P, seed=5, use_lists=True)["r"]
+    return bool(torch.equal(d, l)), "big G=%d N=%d T=%d P=%d %s" % shape

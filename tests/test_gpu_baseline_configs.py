@@ -4,8 +4,9 @@ Every test names the config it runs (`synth.make_config`): cfg2 in full, cfg3
 at its full permutation count, cfg4 in full (200 000 rare variants x 5000
 isolates, the regime of very short and empty minority lists).  The CPU oracle
 checks a gene subsample bit for bit at the config's own P; the dense kernel
-(an independent implementation of the same counts) checks every gene at a
-reduced P.  Reference semantics: scoary/methods.py:804-814 (skip rule -- most
+(an independent implementation of the same counts) checks EVERY gene at the
+config's full P as well (round 3; cfg5 at its full shard size lives in
+test_gpu_full_size.py).  Reference semantics: scoary/methods.py:804-814 (skip rule -- most
 rare variants sit next to it), :1365 (estimator).
 """
 import numpy as np
@@ -75,7 +76,8 @@ def test_cfg3_full_permutations_vs_oracle_subsample(eng, orc):
     """BASELINE configs[2] (cfg3, the headline) with its full P = 10 000 -- the
     20-tiles-per-trait launch bench.py times: every 97th gene (516 genes x 10
     traits x 10 000 permutations = 5.2e7 tests) against the oracle bit for bit,
-    and r <= P / r == P on skip-rule genes for all 500 000 pairs."""
+    r <= P / r == P on skip-rule genes for all 500 000 pairs, and list kernel == dense
+    kernel on all 500 000 pairs at the full P."""
     from scoary_amd import synth
     genes, traits, P, seed = synth.make_config("cfg3")
     G, N = genes.shape
@@ -84,9 +86,14 @@ def test_cfg3_full_permutations_vs_oracle_subsample(eng, orc):
     tb, mb = _bits(traits)
     gm = eng.pack_dense(genes)
     eng.build_lists(gm)
-    res = eng.associate(gm, eng.vecrows(tb, N), eng.vecrows(mb, N), permutations=P, seed=seed,
-                        use_lists=True)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=True)
     counts, p, r = _check_subsample(orc, res, genes, tb, mb, N, P, seed, np.arange(0, G, 97))
+    # every one of the 500 000 (gene, trait) pairs at the FULL P against the dense
+    # AND+popcount kernel, an independent implementation of the same counts (16 ms of GPU)
+    dense = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=False)
+    assert np.array_equal(dense["r"].cpu().numpy().view(np.uint32), r)
+    assert np.array_equal(dense["counts"].cpu().numpy(), counts)
     assert r.max() <= P
     skipped = (counts[:, :, 0] + counts[:, :, 2] == 0) | (counts[:, :, 1] + counts[:, :, 3] == 0)
     assert skipped.sum() > 0 and np.all(r[skipped] == P)
@@ -102,7 +109,7 @@ def test_cfg4_rare_variants_full(eng, orc):
     ~ Beta(0.3, 3)) x 5000 isolates x 1 trait, P = 10 000, whole matrix on one
     GPU.  Most lists are very short or empty (wave groups with no list steps at
     all).  The oracle checks every 400th gene at the full P; the dense kernel
-    checks ALL genes at P = 256."""
+    checks ALL genes at the full P too."""
     from scoary_amd import synth
     genes, traits, P, seed = synth.make_config("cfg4")
     G, N = genes.shape
@@ -118,9 +125,12 @@ def test_cfg4_rare_variants_full(eng, orc):
     assert r.max() <= P
     skipped = (counts[:, :, 0] + counts[:, :, 2] == 0) | (counts[:, :, 1] + counts[:, :, 3] == 0)
     assert skipped.sum() > 1000 and np.all(r[skipped] == P)
-    # list kernel == dense kernel on every gene, reduced P
-    P2 = 256
+    # list kernel == dense kernel on EVERY gene at the config's full P (2e9 tests through
+    # both), and once more at a P that is not a multiple of the tile width
+    dense = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=False)
+    assert np.array_equal(dense["r"].cpu().numpy().view(np.uint32), r)
+    assert np.array_equal(dense["counts"].cpu().numpy(), counts)
+    P2 = 300
     small = eng.associate(gm, trv, mkv, permutations=P2, seed=seed, use_lists=True)
     dense = eng.associate(gm, trv, mkv, permutations=P2, seed=seed, use_lists=False)
     assert np.array_equal(small["r"].cpu().numpy(), dense["r"].cpu().numpy())
-    assert np.array_equal(small["counts"].cpu().numpy(), dense["counts"].cpu().numpy())

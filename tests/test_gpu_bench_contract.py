@@ -47,6 +47,16 @@ def test_bench_json_contract(extra):
     # overridden shape: no committed PMC profile applies -> counters refused, not invented
     assert r["frac"] is None and r["achieved"] is None and "overridden" in r["counters_refused"]
     k3 = "k_permute" if "dense" in extra else "k_permute_lists"
+    # the useful part of the issue (full-adder lane-ops from the list plan) needs no counters
+    if "dense" in extra:
+        assert r["useful_lane_ops"] is None and r["useful_frac"] is None
+    else:
+        assert r["useful_lane_ops"] > 0 and 0 < r["useful_frac_unpadded"] <= r["useful_frac"] < 1
+        assert r["minority_entries_per_gene"] <= r["padded_entries_per_gene"] <= 1000 + 16
+        # 2 * 31/32 lane-ops per padded entry and 32 permutations
+        want = r["padded_entries_per_gene"] * 2 * 31 / 32 / 32
+        assert abs(r["adder_ops_per_test"] - want) < 0.02 * want
+        assert r["overhead_ops_per_test"] is None and r["measured_op_peak"] == 56.1
     assert r["kernel"] == k3 and d["kernel_ms"][k3] > 0
     assert sum(d["kernel_ms"].values()) < 3 * d["ms_per_step"]
     assert d["config"]["hip_graph"] == ("--graph" in extra)
