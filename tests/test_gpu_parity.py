@@ -764,3 +764,33 @@ def test_fisher_symmetric_margins_and_large_n(eng, orc):
         assert base + (base + span - 1) == centre2, (a, b, c, d, base, span)
         checked += 1
     assert checked > 150
+
+
+def test_more_isolates_than_the_list_kernel_takes(eng, orc, caplog):
+    """N > 40959 (one 32-permutation label tile no longer fits the 160 KB of LDS): the list
+    builder refuses, associate() and the command line's _associate fall back to the dense
+    kernels -- and say so in the log -- with results equal to the
+    oracle's.  No BASELINE config is this wide."""
+    import logging
+    from scoary_amd import methods as M
+    from scoary_amd.engine import pack_bits_rows
+    rng = np.random.default_rng(50)
+    G, N, T, P = 150, 50_000, 2, 64
+    genes, traits = _random_case(rng, G, N, T)
+    assert not eng.lists_supported(N) and eng.lists_supported(40_959)
+    gm = eng.pack_dense(genes)
+    with pytest.raises(ValueError):
+        eng.build_lists(gm)
+    table = M.GeneTable(["g%d" % i for i in range(G)], [""] * G, [""] * G,
+                        ["s%d" % i for i in range(N)], pack_bits_rows(genes))
+    M._ENGINE = eng
+    try:
+        with caplog.at_level(logging.INFO, logger=M.log.name):
+            out = M._associate(table, traits, permutations=P, seed=77)
+    finally:
+        M._ENGINE = None
+    assert any("dense permutation kernels" in r.getMessage() for r in caplog.records)
+    tb, mb = _bits(eng, traits)
+    gb = orc.pack_rows(genes)
+    assert np.array_equal(out["counts"], orc.counts_packed(gb, tb, mb).transpose(1, 0, 2))
+    assert np.array_equal(out["r"], orc.permute_r(gb, tb, mb, N, P, 77).T)

@@ -32,9 +32,9 @@ sys.path.insert(0, ROOT)
 from scoary_amd import synth  # noqa: E402
 from scoary_amd.engine import AssociationEngine, pack_bits_rows  # noqa: E402
 
-SHAPES = {   # G, N, T, P, gene kind: the BASELINE shapes with fewer genes (the per-gene host loop that
-             # balances the classes is slow; both variants get the same genes, lengths and launch geometry)
-    "cfg3": (12_500, 2_000, 10, 10_000, "uniform"),
+SHAPES = {   # G, N, T, P, gene kind: the BASELINE shapes, cfg4 / cfg5 with fewer genes (the per-gene host
+             # loop that balances the classes is slow; all variants get the same genes, lengths and geometry)
+    "cfg3": (50_000, 2_000, 10, 10_000, "uniform"),
     "cfg4": (25_000, 5_000, 1, 10_000, "rare"),
     "cfg5": (7_500, 10_000, 50, 12_800, "uniform"),
 }
@@ -87,7 +87,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", nargs="+", default=["cfg3", "cfg4", "cfg5"])
     ap.add_argument("--variant", default="all", choices=["random", "balanced", "shuffled", "all"])
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--genes-scale", type=float, default=1.0)
     args = ap.parse_args()
     eng = AssociationEngine(0)
@@ -111,21 +112,23 @@ def main():
             if variant == "shuffled":
                 shuffle_entries(eng, gm, rng)
             ws = eng.workspace(gm, T, P, use_lists=True)
-            eng.associate(gm, trv, mkv, permutations=P, seed=3, use_lists=True, workspace=ws)
+            # sustained: the steps run back to back like bench.py's (a synchronize between steps
+            # lets the clock drop and the kernel restart below the power cap)
+            for _ in range(args.warmup):
+                eng.associate(gm, trv, mkv, permutations=P, seed=3, use_lists=True, workspace=ws)
             torch.cuda.synchronize()
             eng.set_timing(True)
-            ms = []
             for _ in range(args.steps):
                 eng.associate(gm, trv, mkv, permutations=P, seed=3, use_lists=True, workspace=ws)
-                torch.cuda.synchronize()
-                ms.append(eng.kernel_ms("k_permute_lists"))
+            torch.cuda.synchronize()
+            ms = [eng.kernel_ms("k_permute_lists")]              # mean over the timed launches
             eng.set_timing(False)
             if variant == "random":
                 ref_r = ws.r.clone()
             elif variant == "shuffled" and ref_r is not None:      # the order never changes the counts
                 assert torch.equal(ref_r, ws.r), "shuffled lists changed r"
             out[variant] = sorted(ms)[len(ms) // 2]
-            print("%-5s %-9s G=%d N=%d T=%d P=%d C=%d entries=%d  k_permute_lists %.3f ms (median of %d)"
+            print("%-5s %-9s G=%d N=%d T=%d P=%d C=%d entries=%d  k_permute_lists %.3f ms (mean of %d back-to-back steps)"
                   % (name, variant, G, N, T, P, C, gm.lists.entries, out[variant], args.steps), flush=True)
             del ws, gm
         if "random" in out and "balanced" in out:

@@ -13,7 +13,7 @@ for shape in cfg3 cfg4 cfg5; do
 for v in random balanced shuffled; do
   rm -rf /tmp/abc_$v
   rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU \
-      -d /tmp/abc_$v -o p -- python $REPO/tools/ab_conflicts.py --shapes $shape --variant $v --steps 2 > /dev/null 2>&1
+      -d /tmp/abc_$v -o p -- python $REPO/tools/ab_conflicts.py --shapes $shape --variant $v --steps 2 --warmup 1 > /dev/null 2>&1
   python - "$shape" "$v" /tmp/abc_$v <<'PY'
 import sqlite3, sys, glob
 shape, v, d = sys.argv[1:4]
