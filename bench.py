@@ -52,7 +52,7 @@ VALU_PEAK_AND_BCNT = 4.1e13
 # 6.06e13 at 8 waves per SIMD (out of its reach: <= 64 VGPRs)
 VALU_PEAK_BITOP3_4WAVES = 5.61e13
 VALU_PEAK_BITOP3_8WAVES = 6.06e13
-KERNEL_SOURCES = ("scoary_lists.hip", "scoary_assoc.hip", "scoary_common.hpp",
+KERNEL_SOURCES = ("scoary_lists.hip", "scoary_list_walk.inc", "scoary_assoc.hip", "scoary_common.hpp",
                   "scoary_ctr_regs.inc", "scoary_vgpr_banks.inc")
 
 
@@ -347,7 +347,7 @@ def list_adder_work(eng, gm, genes, T, P, batch):
     tile loads -- is overhead."""
     tw, _stride, gpw, _classes, _piece = eng.list_params(gm.N)
     nw = tw // (64 // gpw)
-    nhalf = gm.lists.ngroups.cpu().numpy().astype(np.int64)[::gpw]        # one per wave group
+    nhalf = gm.lists.ngroups.cpu().numpy().astype(np.int64).reshape(-1, gm.G)[:, ::gpw]   # per (segment,) wave group
     tile_perms = 32 * tw
     launches = -(-P // batch)
     tiles_per_launch = sum(-(-min(batch, P - b) // tile_perms) for b in range(0, P, batch)) / launches

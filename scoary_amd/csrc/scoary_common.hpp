@@ -58,14 +58,35 @@ inline int64_t tiled_quads(int64_t N) {
 // N <= 5119, 4 (tiles of 128) up to N <= 10239, 2 (tiles of 64, two words per lane)
 // up to N <= 20479, 1 (tiles of 32, one word per lane) up to N <= 40959.  A gene takes
 // max(TW/4, 1) lanes and a wavefront 64 / that many genes of similar list length.
+// Wider matrices (N <= 122496) keep TW = 1 and cut the isolates into 2 or 3 SEGMENTS of
+// kSegRows rows: a block loads one segment of its tile at a time and a gene's list is one
+// sub-list per segment (k_permute_seglists; the counter planes live across the reloads).
+constexpr int kSegRows = 40832;                      // 319 * 128: whole word quads, (rows + 1) dwords fit 160 KB
+constexpr int kSegStride = (kSegRows + 1 + 3) / 4 * 4;   // dwords from one segment of a tile to the next
+constexpr int kMaxSegments = 3;                      // N / 2 < 2^16: sixteen counter planes
+__host__ __device__ constexpr int list_segments(int64_t N) {
+  return N <= 40959 ? 1 : (N <= (int64_t)kMaxSegments * kSegRows ? (int)((N + kSegRows - 1) / kSegRows) : 0);
+}
 __host__ __device__ constexpr int list_tw(int64_t N) {
-  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : (N <= 20479 ? 2 : (N <= 40959 ? 1 : 0))));
+  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : (N <= 20479 ? 2 : (list_segments(N) ? 1 : 0))));
 }
 __host__ __device__ constexpr int list_lpg(int TW) { return TW >= 4 ? TW / 4 : 1; }   // lanes per gene
 __host__ __device__ constexpr int list_nw(int TW) { return TW >= 4 ? 4 : TW; }        // words per lane
 // dwords per label tile in HBM: rows 0..N plus padding to a 16-byte multiple
 __host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int TW) {
   return ((N + 1) * TW + 3) / 4 * 4;
+}
+// the same for any N the list path takes; segmented tiles (TW = 1, N > 40959): kSegStride dwords
+// per segment, each with its own all-zero row after its last isolate
+__host__ __device__ constexpr int64_t list_tile_dwords_seg(int64_t N, int TW) {
+  return list_segments(N) > 1 ? (int64_t)list_segments(N) * kSegStride : list_tile_dwords(N, TW);
+}
+// rows of segment s, and the dword of row `row` inside a (TW = 1) tile
+__host__ __device__ constexpr int64_t list_seg_rows(int64_t N, int s) {
+  return list_segments(N) > 1 ? (N - (int64_t)s * kSegRows < kSegRows ? N - (int64_t)s * kSegRows : kSegRows) : N;
+}
+__host__ __device__ constexpr int64_t list_row_dword(int64_t N, int64_t row) {
+  return list_segments(N) > 1 ? row / kSegRows * kSegStride + row % kSegRows : row;
 }
 
 constexpr int kListPad = 16;        // list lengths are padded to a multiple of this many entries (half a 32-entry step)

@@ -15,8 +15,8 @@ __host__ __device__ inline int64_t lb_align8(int64_t x) { return (x + 7) / 8 * 8
 
 // Scratch layout (bytes), shared by scoary_lists_plan and scoary_lists_fill.
 struct ListScratch {
-  int64_t len, ord_a, ord_b, hist, base, padded, total;
-  int64_t nblk, nwg;
+  int64_t len, ord_a, ord_b, hist, base, padded, seglen, total;
+  int64_t nblk, nwg, nseg;
 };
 inline ListScratch list_scratch(int64_t G, int64_t N) {
   ListScratch s{};
@@ -24,13 +24,15 @@ inline ListScratch list_scratch(int64_t G, int64_t N) {
   const int64_t gpw = TW ? kWave / list_lpg(TW) : 64;
   s.nblk = (G + kSortItems - 1) / kSortItems;
   s.nwg = (G + gpw - 1) / gpw;
+  s.nseg = list_segments(N) > 1 ? list_segments(N) : 1;      // sub-lists per gene (N > 40959)
   int64_t off = 0;
   s.len = off;    off += lb_align8(4 * G);
   s.ord_a = off;  off += lb_align8(4 * G);
   s.ord_b = off;  off += lb_align8(4 * G);
   s.hist = off;   off += lb_align8(4 * 256 * s.nblk);
-  s.base = off;   off += 8 * (s.nwg + 1);
-  s.padded = off; off += lb_align8(4 * s.nwg);
+  s.base = off;   off += 8 * (s.nwg * s.nseg + 1);           // [nwg][nseg] + the total
+  s.padded = off; off += lb_align8(4 * s.nwg * s.nseg);       // [nwg][nseg]
+  s.seglen = off; off += s.nseg > 1 ? lb_align8(4 * G * s.nseg) : 0;   // [nseg][G]
   s.total = off;
   return s;
 }
@@ -286,6 +288,186 @@ __global__ __launch_bounds__(256) void k_lists_fill(const uint4* __restrict__ ti
   for (int n = total + c; n < L; n += C) idx[at(n)] = zero_row;
 }
 
+// ---- segmented lists (N > 40959, scoary_common.hpp): one sub-list per gene and segment ----
+// Order and flip are the whole row's (k_lists_len + sort); the sub-lists of a wave group are
+// padded to the longest of the group in that segment; entries are byte addresses inside the
+// segment's tile (row - segment start) * 4, padding points at the segment's own zero row.
+// Segments start on multiples of 128 isolates, so a position's residue class mod 64 is the
+// same inside the segment as in the row.
+
+// lane = gene: minority count inside every segment
+__global__ __launch_bounds__(256) void k_lists_seglen(const uint4* __restrict__ tiled, int64_t Gp,
+                                                      int G, int N, int nseg,
+                                                      const uint8_t* __restrict__ flipped,
+                                                      int32_t* __restrict__ seglen) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= G) return;
+  const uint32_t inv = flipped[g] ? 0xffffffffu : 0u;
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    const int row0 = sgm * kSegRows, rows = (int)list_seg_rows(N, sgm);
+    int n = 0;
+    for (int qd = row0 / 128; qd < (row0 + rows + 127) / 128; ++qd) {
+      const uint4 v = tiled[(int64_t)qd * Gp + g];
+      const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        const int first = 32 * (4 * qd + w4);
+        uint32_t bits = words[w4] ^ inv;
+        if (first + 32 > N) bits &= first < N ? ((1u << (N - first)) - 1u) : 0u;
+        n += __popc(bits);
+      }
+    }
+    seglen[(int64_t)sgm * G + g] = n;
+  }
+}
+// thread = wave group: padded sub-list length per segment = the group's longest, rounded up
+__global__ __launch_bounds__(256) void k_lists_segpad(const int32_t* __restrict__ seglen,
+                                                      const int32_t* __restrict__ order, int G,
+                                                      int gpw, int64_t nwg, int nseg,
+                                                      int32_t* __restrict__ padded) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= nwg) return;
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    int m = 0;
+    for (int j = 0; j < gpw; ++j) {
+      const int64_t k = q * gpw + j;
+      if (k < G) m = max(m, seglen[(int64_t)sgm * G + order[k]]);
+    }
+    padded[q * nseg + sgm] = (m + kListPad - 1) / kListPad * kListPad;
+  }
+}
+// base[i] = entries before item i (item = (wave group, segment), padded[i] * gpw entries each),
+// base[n] = all entries: exclusive prefix sum, one block
+__global__ __launch_bounds__(1024) void k_lists_base(const int32_t* __restrict__ padded, int64_t n,
+                                                     int gpw, int64_t* __restrict__ base) {
+  __shared__ int64_t wsum[16];
+  __shared__ int64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t i0 = 0; i0 < n; i0 += 1024) {
+    const int64_t i = i0 + tid;
+    const int64_t x = i < n ? (int64_t)padded[i] * gpw : 0;
+    int64_t s = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int64_t y = __shfl_up(s, off);
+      if (lane >= off) s += y;
+    }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    int64_t wo = 0;
+    for (int w = 0; w < wave; ++w) wo += wsum[w];
+    const int64_t carry = carry_s;
+    if (i < n) base[i] = carry + wo + s - x;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wo + s;
+    __syncthreads();
+  }
+  if (tid == 0) base[n] = carry_s;
+}
+__global__ __launch_bounds__(256) void k_lists_segslots(const int32_t* __restrict__ padded,
+                                                        const int64_t* __restrict__ base, int G,
+                                                        int gpw, int nseg, int32_t* __restrict__ start,
+                                                        int32_t* __restrict__ ngroups) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= G) return;
+  const int64_t q = k / gpw;
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    start[(int64_t)sgm * G + k] = (int32_t)(base[q * nseg + sgm] / kListStartUnit);
+    ngroups[(int64_t)sgm * G + k] = padded[q * nseg + sgm] / kListPad;
+  }
+}
+// The entry order of spec S6 inside every segment (k_lists_fill<64> with a segment loop):
+// wavefront = list slot, lane = residue class.
+__global__ __launch_bounds__(256) void k_lists_fill_seg(const uint4* __restrict__ tiled, int64_t Gp,
+                                                        int G, int N, int nseg,
+                                                        const int32_t* __restrict__ seglen,
+                                                        const int32_t* __restrict__ order,
+                                                        const uint8_t* __restrict__ flipped,
+                                                        const int64_t* __restrict__ base,
+                                                        const int32_t* __restrict__ padded,
+                                                        int64_t nslots, uint32_t* __restrict__ idx) {
+  __shared__ int32_t s_cnt[256];
+  constexpr int C = 64, gpw = 64, piece = 4;
+  constexpr uint32_t row_stride = 4u;
+  const int tid = threadIdx.x, c = tid & 63, wave = tid >> 6;
+  const int64_t k = (int64_t)blockIdx.x * 4 + wave;
+  const bool exists = k < nslots, live = k < G;
+  const int64_t q = exists ? k / gpw : 0;
+  const int j = (int)(k - q * gpw);
+  const int g = live ? order[k] : 0;
+  const uint32_t inv = (live && flipped[g]) ? 0xffffffffu : 0u;
+  const uint32_t cmask = 1u << (c & 31);       // class c: bit c & 31 of the words of parity c >> 5
+  auto class_bits = [&](uint32_t word, int w) -> uint32_t {
+    const int first = 32 * w;
+    uint32_t bits = word ^ inv;
+    if (first + 32 > N) bits &= first < N ? ((1u << (N - first)) - 1u) : 0u;
+    if ((w & 1) != (c >> 5)) return 0u;
+    return bits & cmask;
+  };
+  const int32_t* cnt = s_cnt + (tid - c);      // the 64 class counts of this slot
+  const int dk = (int)((c - k) & (C - 1));
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    const int row0 = sgm * kSegRows, rows = (int)list_seg_rows(N, sgm);
+    const int qd0 = row0 / 128, qd1 = (row0 + rows + 127) / 128;
+    const int L = exists ? padded[q * nseg + sgm] : 0;
+    const int64_t b0 = exists ? base[q * nseg + sgm] : 0;
+    const int total = live ? seglen[(int64_t)sgm * G + g] : 0;
+    auto at = [&](int n) -> int64_t {
+      return b0 + ((int64_t)(n / piece) * gpw + j) * piece + n % piece;
+    };
+    int my_cnt = 0;
+    if (live)
+      for (int qd = qd0; qd < qd1; ++qd) {
+        const uint4 v = tiled[(int64_t)qd * Gp + g];
+        my_cnt += __popc(class_bits(v.x, 4 * qd)) + __popc(class_bits(v.y, 4 * qd + 1)) +
+                  __popc(class_bits(v.z, 4 * qd + 2)) + __popc(class_bits(v.w, 4 * qd + 3));
+      }
+    __syncthreads();                           // the previous segment's counts have been used
+    s_cnt[tid] = my_cnt;
+    __syncthreads();
+    auto filled = [&](int x) -> int {
+      int f = 0;
+      for (int xc = 0; xc < C; ++xc) {
+        const int dx = (int)((xc - k) & (C - 1));
+        f += min(cnt[xc], max(0, (x - dx + C - 1) / C));
+      }
+      return f;
+    };
+    const int filled_total = filled(total);
+    if (live) {
+      int rho = 0;
+      for (int qd = qd0; qd < qd1; ++qd) {
+        const uint4 v = tiled[(int64_t)qd * Gp + g];
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          uint32_t bits = class_bits(words[w4], 4 * qd + w4);
+          while (bits) {
+            const int b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            int pos = rho * C + dk;
+            if (pos >= total) {
+              const int ov = filled(pos) - filled_total;
+              int lo = 0, hi = total - 1;
+              while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (mid + 1 - filled(mid + 1) >= ov + 1) hi = mid; else lo = mid + 1;
+              }
+              pos = lo;
+            }
+            idx[at(pos)] = (uint32_t)(32 * (4 * qd + w4) + b - row0) * row_stride;
+            ++rho;
+          }
+        }
+      }
+    }
+    const uint32_t zero_row = (uint32_t)rows * row_stride;
+    for (int n = total + c; n < L; n += C) idx[at(n)] = zero_row;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_lists_slack(uint32_t* __restrict__ idx, int64_t entries) {
   if (threadIdx.x < kListSlack) idx[entries + threadIdx.x] = 0u;
 }
@@ -339,12 +521,24 @@ int scoary_lists_plan(scoary_handle h, const uint32_t* d_tiled, int64_t G, int64
     hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)L.nblk), dim3(64), 0, s, in, len, (int)G,
                        kmax, 8 * p, (int)L.nblk, hist, out);
   }
-  hipLaunchKernelGGL(k_lists_plan, dim3(1), dim3(1024), 0, s, len, d_order, (int)G, gpw, L.nwg,
-                     padded, base);
-  hipLaunchKernelGGL(k_lists_slots, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, padded, base,
-                     (int)G, gpw, d_start, d_ngroups);
+  if (L.nseg > 1) {           // N > 40959: sub-lists per segment, d_start / d_ngroups are [nseg][G]
+    int32_t* seglen = reinterpret_cast<int32_t*>(sc + L.seglen);
+    hipLaunchKernelGGL(k_lists_seglen, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const uint4*>(d_tiled), Gp, (int)G, (int)N, (int)L.nseg,
+                       d_flipped, seglen);
+    hipLaunchKernelGGL(k_lists_segpad, dim3((unsigned)((L.nwg + 255) / 256)), dim3(256), 0, s, seglen,
+                       d_order, (int)G, gpw, L.nwg, (int)L.nseg, padded);
+    hipLaunchKernelGGL(k_lists_base, dim3(1), dim3(1024), 0, s, padded, L.nwg * L.nseg, gpw, base);
+    hipLaunchKernelGGL(k_lists_segslots, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, padded,
+                       base, (int)G, gpw, (int)L.nseg, d_start, d_ngroups);
+  } else {
+    hipLaunchKernelGGL(k_lists_plan, dim3(1), dim3(1024), 0, s, len, d_order, (int)G, gpw, L.nwg,
+                       padded, base);
+    hipLaunchKernelGGL(k_lists_slots, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, padded, base,
+                       (int)G, gpw, d_start, d_ngroups);
+  }
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemcpyAsync(entries_out, base + L.nwg, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(h, hipMemcpyAsync(entries_out, base + L.nwg * L.nseg, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));
   return SCOARY_OK;
 }
@@ -371,6 +565,15 @@ int scoary_lists_fill(scoary_handle h, const uint32_t* d_tiled, int64_t G, int64
   const int spb = 4 * (64 / C);                      // slots per block of four wavefronts
   const dim3 grid((unsigned)((nslots + spb - 1) / spb));
   KernelTimer kt(h, s, "k_lists_fill");
+  if (L.nseg > 1) {
+    hipLaunchKernelGGL(k_lists_fill_seg, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, s,
+                       reinterpret_cast<const uint4*>(d_tiled), Gp, (int)G, (int)N, (int)L.nseg,
+                       reinterpret_cast<const int32_t*>(sc + L.seglen), d_order, d_flipped, base,
+                       padded, nslots, d_idx);
+    hipLaunchKernelGGL(k_lists_slack, dim3(1), dim3(256), 0, s, d_idx, entries);
+    HIP_TRY(h, hipGetLastError());
+    return SCOARY_OK;
+  }
 #define FILL(CV)                                                                               \
   hipLaunchKernelGGL((k_lists_fill<CV>), grid, dim3(256), 0, s,                                \
                      reinterpret_cast<const uint4*>(d_tiled), Gp, (int)G, (int)N, Qn, len,     \

@@ -133,7 +133,7 @@ struct TileOut {
 };
 template <int TW>
 __device__ __forceinline__ TileOut tile_out(uint32_t* tiles, int t, int ntiles, int64_t wave, int N) {
-  const int64_t tile_dw = list_tile_dwords(N, TW);
+  const int64_t tile_dw = TW == 1 ? list_tile_dwords_seg(N, TW) : list_tile_dwords(N, TW);
   if constexpr (TW >= 2) {
     const int waves_per_tile = TW / 2;
     const int tile = (int)(wave / waves_per_tile);
@@ -144,6 +144,30 @@ __device__ __forceinline__ TileOut tile_out(uint32_t* tiles, int t, int ntiles, 
     uint32_t* base = tiles + ((int64_t)t * ntiles + 2 * wave) * tile_dw;
     return {base, 2 * wave + 1 < ntiles ? base + tile_dw : nullptr, 1};
   }
+}
+// dword of tile row `row` relative to out.lo / out.hi: row * stride, except in the segmented
+// one-dword tiles of N > 40959 (scoary_common.hpp: every segment its own zero row)
+template <int TW>
+__device__ __forceinline__ int64_t tile_row_off(const TileOut& out, int N, int row) {
+  if constexpr (TW == 1) return list_row_dword(N, row);
+  return (int64_t)row * out.stride;
+}
+// the all-zero row(s) that list padding points at (one thread)
+template <int TW>
+__device__ __forceinline__ void tile_zero_rows(const TileOut& out, int N) {
+  if constexpr (TW == 1) {
+    const int nseg = list_segments(N);
+    if (nseg > 1) {
+      for (int sgm = 0; sgm < nseg; ++sgm) {
+        const int64_t z = (int64_t)sgm * kSegStride + list_seg_rows(N, sgm);
+        out.lo[z] = 0u;
+        if (out.hi) out.hi[z] = 0u;
+      }
+      return;
+    }
+  }
+  out.lo[(int64_t)N * out.stride] = 0u;
+  if (out.hi) out.hi[(int64_t)N * out.stride] = 0u;
 }
 template <int TW>
 __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __restrict__ masks,
@@ -186,18 +210,16 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
         if ((iso & 63) == 63 || iso == nw * 32 - 1) {  // 64 isolates collected: one row per lane
           const int row = (iso & ~63) + lane;
           if (row < N) {
-            out.lo[(int64_t)row * out.stride] = (uint32_t)mine;
-            if (out.hi) out.hi[(int64_t)row * out.stride] = (uint32_t)(mine >> 32);
+            const int64_t ro = tile_row_off<TW>(out, N, row);
+            out.lo[ro] = (uint32_t)mine;
+            if (out.hi) out.hi[ro] = (uint32_t)(mine >> 32);
           }
           mine = 0;
         }
       }
     }
   }
-  if (lane == 0) {  // the all-zero row that list padding points at
-    out.lo[(int64_t)N * out.stride] = 0u;
-    if (out.hi) out.hi[(int64_t)N * out.stride] = 0u;
-  }
+  if (lane == 0) tile_zero_rows<TW>(out, N);
 }
 
 // The same tiles from a workgroup per 64 permutations, for launches with fewer
@@ -305,16 +327,14 @@ __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_til
         select_rows<0, false>(x, mw, livemask, needed, lo, hi);
       const int row = cc * kGenChunk + lane;
       if (row < N) {
-        out.lo[(int64_t)row * out.stride] = lo;
-        if (out.hi) out.hi[(int64_t)row * out.stride] = hi;
+        const int64_t ro = tile_row_off<TW>(out, N, row);
+        out.lo[ro] = lo;
+        if (out.hi) out.hi[ro] = hi;
       }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {  // the all-zero row that list padding points at
-    out.lo[(int64_t)N * out.stride] = 0u;
-    if (out.hi) out.hi[(int64_t)N * out.stride] = 0u;
-  }
+  if (threadIdx.x == 0) tile_zero_rows<TW>(out, N);
 }
 
 // The middle regime (one to eight wavefronts per SIMD): four wavefronts per 64
@@ -370,16 +390,14 @@ __global__ __launch_bounds__(kWave * 4) void k_perm_generate_tiles_wg4(
         select_rows<0, false>(x, mw, livemask, needed, lo, hi);
       const int row = c * kGenChunk + lane;
       if (row < N) {
-        out.lo[(int64_t)row * out.stride] = lo;
-        if (out.hi) out.hi[(int64_t)row * out.stride] = hi;
+        const int64_t ro = tile_row_off<TW>(out, N, row);
+        out.lo[ro] = lo;
+        if (out.hi) out.hi[ro] = hi;
       }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {  // the all-zero row that list padding points at
-    out.lo[(int64_t)N * out.stride] = 0u;
-    if (out.hi) out.hi[(int64_t)N * out.stride] = 0u;
-  }
+  if (threadIdx.x == 0) tile_zero_rows<TW>(out, N);
 }
 
 // Per (trait, list slot): the ACCEPTANCE interval of the two-sided test in terms of the
@@ -587,113 +605,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     uint32_t c0[16], c1[16], c2[16], c3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) c0[k] = c1[k] = c2[k] = c3[k] = 0u;
-    Rows4 xa, xb;
-    auto s4 = [&](const Rows4& x) -> Carry4 {
-      Carry4 b;
-      b.w[0] = sum4<0>(c0, x.w0);
-      b.w[1] = NW > 1 ? sum4<1>(c1, x.w1) : 0u;
-      if constexpr (NW > 2) {
-        b.w[2] = sum4<2>(c2, x.w2);
-        b.w[3] = sum4<3>(c3, x.w3);
-      } else {
-        b.w[2] = b.w[3] = 0u;
-      }
-      return b;
-    };
-#define FA4(PLANE, A, B)                                               \
-  Carry4 {                                                             \
-    {                                                                  \
-      full_add<0, PLANE>(c0[PLANE], (A).w[0], (B).w[0]),               \
-          NW > 1 ? full_add<1, PLANE>(c1[PLANE], (A).w[1], (B).w[1]) : 0u, \
-          NW > 2 ? full_add<2, PLANE>(c2[PLANE], (A).w[2], (B).w[2]) : 0u, \
-          NW > 2 ? full_add<3, PLANE>(c3[PLANE], (A).w[3], (B).w[3]) : 0u  \
-    }                                                                  \
-  }
-    // pieces of 4*LPG entries; the index loads run three pieces ahead in a ring of
-    // four vectors (a region of four steps is a multiple of four pieces, so the ring
-    // slot of every piece is a compile-time constant).  Reads past the end of the
-    // list re-read its last piece (valid rows, never summed).
-    int piece = 0;                                   // piece whose vector is ring[piece % 4]
-    auto load_piece = [&](int p) -> Ent { return load_from(cur, p); };
-    read4x4<LPG, 0, NW>(xa, ring[0].e, colb);
-    // sub-step S of step K (both literals): issue the reads of the next sub-step into
-    // `other`, sum `mine`
-#define SUBSTEP(K, S, MINE, OTHER)                                          \
-  [&]() -> Carry4 {                                                         \
-    constexpr int kSub = (K) * 8 + (S);          /* sub-step within the region */ \
-    constexpr int kCur = (kSub / LPG) % 4;       /* ring slot in use */           \
-    constexpr int Hn = (kSub + 1) % LPG;                                     \
-    if constexpr (Hn == 0) {                     /* piece finished: refill its slot */ \
-      ring[kCur] = load_piece(piece + 4);                                    \
-      ++piece;                                                               \
-      read4x4<LPG, 0, NW>(OTHER, ring[(kCur + 1) % 4].e, colb);               \
-    } else {                                                                 \
-      read4x4<LPG, Hn, NW>(OTHER, ring[kCur].e, colb);                        \
-    }                                                                        \
-    return s4(MINE);                                                         \
-  }()
-    // Carries are kept pending level by level (weights 4, 8, ..., 64 inside a region of four
-    // steps) and only the top one ripples through the upper planes.  kDeep: one more pending
-    // level -- regions of eight steps, the two weight-128 carries meet in plane 7 and the
-    // ripple starts at plane 8 -- where the four extra VGPRs are available.
-    constexpr bool kDeep = LPG == 4;
-    constexpr int kRegion = kDeep ? 8 : 4;
-    const Carry4 zero = {{0u, 0u, 0u, 0u}};
-    for (int sg = 0; sg < nsuper; sg += kRegion) {
-#define STEP(K)                                   /* 32 listed isolates */ \
-  [&]() -> Carry4 {                                                         \
-    const int left = nhalf - 2 * (sg + (K));     /* half-steps left, wave-uniform */ \
-    if (left <= 0) return zero;                                             \
-    const Carry4 b0 = SUBSTEP(K, 0, xa, xb);                                \
-    const Carry4 b1 = SUBSTEP(K, 1, xb, xa);                                \
-    const Carry4 d0 = FA4(2, b0, b1);                                       \
-    const Carry4 b2 = SUBSTEP(K, 2, xa, xb);                                \
-    const Carry4 b3 = SUBSTEP(K, 3, xb, xa);                                \
-    const Carry4 d1 = FA4(2, b2, b3);                                       \
-    const Carry4 e0 = FA4(3, d0, d1);                                       \
-    Carry4 e1 = zero;                                                       \
-    if (left > 1) {                              /* the second 16 entries exist */ \
-      const Carry4 b4 = SUBSTEP(K, 4, xa, xb);                              \
-      const Carry4 b5 = SUBSTEP(K, 5, xb, xa);                              \
-      const Carry4 d2 = FA4(2, b4, b5);                                     \
-      const Carry4 b6 = SUBSTEP(K, 6, xa, xb);                              \
-      const Carry4 b7 = SUBSTEP(K, 7, xb, xa);                              \
-      const Carry4 d3 = FA4(2, b6, b7);                                     \
-      e1 = FA4(3, d2, d3);                                                  \
-    }                                                                       \
-    return FA4(4, e0, e1);                       /* weight 32 */            \
-  }()
-#define QUAD(K0)                                  /* four steps -> carry of weight 128 */ \
-  [&]() -> Carry4 {                                                         \
-    const Carry4 f0 = STEP(K0), f1 = STEP((K0) + 1);                        \
-    const Carry4 g0 = FA4(5, f0, f1);                                       \
-    const Carry4 f2 = STEP((K0) + 2), f3 = STEP((K0) + 3);                  \
-    const Carry4 g1 = FA4(5, f2, f3);                                       \
-    return FA4(6, g0, g1);                                                  \
-  }()
-      Carry4 carry = QUAD(0);
-      if constexpr (kDeep) {
-        const Carry4 h1 = sg + 4 < nsuper ? QUAD(4) : zero;
-        carry = FA4(7, carry, h1);
-      }
-#define RIPPLE(K)                                                       \
-  if constexpr (K < KC && K >= (kDeep ? 8 : 7)) {                       \
-    Carry4 nc = {{c0[K] & carry.w[0], c1[K] & carry.w[1], c2[K] & carry.w[2], c3[K] & carry.w[3]}}; \
-    Ctr<0, K>::xor2(c0[K], carry.w[0]);                                 \
-    if constexpr (NW > 1) Ctr<1, K>::xor2(c1[K], carry.w[1]);           \
-    if constexpr (NW > 2) {                                             \
-      Ctr<2, K>::xor2(c2[K], carry.w[2]);                               \
-      Ctr<3, K>::xor2(c3[K], carry.w[3]);                               \
-    }                                                                   \
-    carry = nc;                                                         \
-  }
-      RIPPLE(7) RIPPLE(8) RIPPLE(9) RIPPLE(10) RIPPLE(11) RIPPLE(12) RIPPLE(13) RIPPLE(14)
-#undef RIPPLE
-    }
-#undef QUAD
-#undef STEP
-#undef SUBSTEP
-#undef FA4
+#include "scoary_list_walk.inc"
     // next group of this wavefront: open it and request its first index vectors now
     if (q + nwaves < q_hi) {
       cur = open_group(q + nwaves);
@@ -730,6 +642,105 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   }
 }
 
+// N > 40959: one 32-permutation tile no longer fits the 160 KB of LDS, so the isolates are cut
+// into nseg segments of kSegRows rows (scoary_common.hpp).  A gene's index list is one sub-list
+// per segment (entries = LDS byte addresses inside the segment, lstart / lngroups are [nseg][G]);
+// the block walks its wave groups in ROUNDS of one group per wavefront and, inside a round,
+// loads the tile segment by segment: the counter planes stay in registers across the reloads
+// and the region test comes after the last segment.  One lane per gene, one permutation word
+// per lane (the TW = 1 geometry), 16 counter planes (N / 2 < 2^16).  The walk itself is the
+// code of k_permute_lists (scoary_list_walk.inc).
+template <int KC>
+__global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __restrict__ tiles,
+                                                           const uint32_t* __restrict__ lidx,
+                                                           const int32_t* __restrict__ lstart,
+                                                           const int32_t* __restrict__ lngroups,
+                                                           const uint2* __restrict__ lcrit, int G,
+                                                           int N, int64_t P, int ntiles,
+                                                           int groups_per_block, int64_t lidx_bytes,
+                                                           int nseg, uint16_t* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
+  scoary_bank_defs();
+  constexpr int LPG = 1, NW = 1, TW = 1, GPW = kWave;
+  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = 0;
+  const int ngroups = (G + GPW - 1) / GPW;
+  const int q_lo = blockIdx.y * groups_per_block;
+  const int q_hi = min(ngroups, q_lo + groups_per_block);
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  uint16_t* out = partial + (int64_t)blockIdx.x * ((int64_t)ngroups * GPW);
+  struct alignas(16) Ent { uint32_t e[4]; };
+  constexpr int kListLoadPolicy = SCOARY_LIST_LOAD_POLICY;
+  struct Group { int nhalf, last; __amdgpu_buffer_rsrc_t rsrc; };
+  auto open_group = [&](int qq, int sgm) -> Group {
+    const int64_t slot = (int64_t)sgm * G + (int64_t)qq * GPW;
+    const int64_t start = (int64_t)__builtin_amdgcn_readfirstlane(lstart[slot]);
+    const int nh = __builtin_amdgcn_readfirstlane(lngroups[slot]);
+    const int64_t gbytes = lidx_bytes - start * 128;
+    return Group{nh, max(nh * (4 / LPG) - 1, 0),
+                 __builtin_amdgcn_make_buffer_rsrc(
+                     const_cast<Ent*>(reinterpret_cast<const Ent*>(lidx) + start * 8), 0,
+                     (int)min(gbytes, (int64_t)0x7fffffff), 0x00020000)};
+  };
+  auto load_from = [&](const Group& gr, int p) -> Ent {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+        gr.rsrc, lane_off, min(p, gr.last) * (kWave * (int)sizeof(Ent)), kListLoadPolicy);
+    return Ent{{v.x, v.y, v.z, v.w}};
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds;
+  const uint32_t* src = tiles + (int64_t)blockIdx.x * ((int64_t)nseg * kSegStride);
+  // rounds and segments are block-uniform: every wavefront meets every barrier, whether or not
+  // it has a wave group in this round
+  const int rounds = (q_hi - q_lo + nwaves - 1) / nwaves;
+  for (int rnd = 0; rnd < rounds; ++rnd) {
+    const int q = q_lo + rnd * nwaves + wave;
+    const bool active = q < q_hi;                                        // wave-uniform
+    uint32_t c0[16], c1[16], c2[16], c3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c0[k] = c1[k] = c2[k] = c3[k] = 0u;
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+      __syncthreads();                       // the previous segment has been walked by everyone
+      {
+        const uint4* src4 = reinterpret_cast<const uint4*>(src + (int64_t)sgm * kSegStride);
+        constexpr int n4 = kSegStride / 4;
+        for (int i = wave * kWave; i < n4; i += nwaves * kWave)
+          if (i + lane < n4) {
+            uint32_t m0_saved;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_saved)
+                         : "s"(lds0 + (uint32_t)i * 16u), "v"(lane_off), "s"(src4 + i)
+                         : "memory");
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (active) {
+        const Group cur = open_group(q, sgm);
+        Ent ring[4] = {load_from(cur, 0), load_from(cur, 1), load_from(cur, 2), load_from(cur, 3)};
+        const int nhalf = cur.nhalf;
+        const int nsuper = (nhalf + 1) >> 1;
+        const uint32_t colb = lds0;                    // one lane per gene: column 0
+#include "scoary_list_walk.inc"
+      }
+    }
+    if (active) {
+      const int lg = fresh_lane();
+      const int slot = min(q * GPW + lg, G - 1);
+      const bool have = q * GPW + lg < G;
+      const uint2 cr = lcrit[(int64_t)t * G + slot];
+      const int64_t p_first = (int64_t)tile * 32;
+      const uint32_t valid = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
+      int cnt = __popc(region_bits<KC>(c0, cr.x, cr.y) & valid);
+      if (!have) cnt = 0;
+      out[(int64_t)q * GPW + lg] = (uint16_t)cnt;                  // cnt <= 32
+    }
+  }
+  (void)col;
+}
+
 // r[t][gene of slot k] (+)= sum over the tiles of partial[t][tile][k]
 __global__ __launch_bounds__(256) void k_lists_reduce(const uint16_t* __restrict__ partial,
                                                       int ntiles, int64_t gs, int G,
@@ -754,10 +765,11 @@ int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
   if (!TW) return 0;
   const int64_t tile_perms = TW * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  return T * ntiles * list_tile_dwords(N, TW);
+  return T * ntiles * list_tile_dwords_seg(N, TW);
 }
-int64_t scoary_list_tile_words(int64_t N) { return list_tw(N) ? list_tile_dwords(N, list_tw(N)) : 0; }
-int64_t scoary_list_max_isolates(void) { return 40959; }
+int64_t scoary_list_tile_words(int64_t N) { return list_tw(N) ? list_tile_dwords_seg(N, list_tw(N)) : 0; }
+int64_t scoary_list_max_isolates(void) { return (int64_t)kMaxSegments * kSegRows; }
+int64_t scoary_list_segments(int64_t N) { return N < 1 ? 0 : list_segments(N); }
 int scoary_list_params(int64_t N, int64_t* out5) {
   if (!out5) return SCOARY_ERR_ARG;
   const int TW = list_tw(N);
@@ -900,6 +912,55 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }
+// N > 40959: the segmented kernel (k_permute_seglists), same scratch layout and geometry
+static int launch_permute_seglists(scoary_handle h, hipStream_t s, const uint32_t* d_tiles,
+                                   const uint32_t* d_lidx, int64_t entries, const int32_t* d_lstart,
+                                   const int32_t* d_lngroups, const int32_t* d_lorder,
+                                   const uint8_t* d_lflipped, const uint32_t* d_crit,
+                                   const uint32_t* d_lcrit_in, const int32_t* d_margins,
+                                   uint32_t* d_scratch, int64_t G, int64_t T, int64_t N, int64_t P,
+                                   uint32_t* d_r, int accumulate) {
+  constexpr int KC = 16;
+  uint32_t* d_lcrit_sc = d_scratch;
+  uint16_t* d_partial = reinterpret_cast<uint16_t*>(d_scratch + 2 * T * G);
+  const uint32_t* d_lcrit = d_lcrit_in ? d_lcrit_in : d_lcrit_sc;
+  if (!d_lcrit_in) {
+    KernelTimer kt(h, s, "k_lists_crit");
+    hipLaunchKernelGGL(k_lists_crit, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                       reinterpret_cast<const uint2*>(d_crit), d_margins, d_lorder, d_lflipped,
+                       (int)G, reinterpret_cast<uint2*>(d_lcrit_sc));
+  }
+  const ListGeom g = list_geom(h->num_cu, G, T, N, P, entries);
+  if (T * g.ntiles > 0x7fffffffLL || g.chunks > 65535)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: grid too large");
+  const size_t lds = (size_t)kSegStride * sizeof(uint32_t);
+  const void* fn = reinterpret_cast<const void*>(&k_permute_seglists<KC>);
+  constexpr int kOptinBit = 32;                         // next to the tile widths 16 / 8 / 4 / 2 / 1
+  if (!(h->lists_lds_optin & kOptinBit)) {
+    hipFuncAttributes attr;
+    HIP_TRY(h, hipFuncGetAttributes(&attr, fn));
+    if (attr.sharedSizeBytes != 0)
+      return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: k_permute_seglists has static LDS; the "
+                                      "label tile would not sit at LDS address 0");
+    HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    h->lists_lds_optin |= kOptinBit;
+  }
+  {
+    KernelTimer kt(h, s, "k_permute_lists");
+    hipLaunchKernelGGL((k_permute_seglists<KC>), dim3((unsigned)(T * g.ntiles), (unsigned)g.chunks),
+                       dim3(1024), lds, s, d_tiles, d_lidx, d_lstart, d_lngroups,
+                       reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P, (int)g.ntiles,
+                       (int)g.gpb, (entries + kListSlack) * (int64_t)sizeof(uint32_t),
+                       list_segments(N), d_partial);
+  }
+  {
+    KernelTimer kt(h, s, "k_lists_reduce");
+    hipLaunchKernelGGL(k_lists_reduce, dim3((unsigned)((G + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                       d_partial, (int)g.ntiles, g.gs, (int)G, d_lorder, accumulate, d_r);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
 }  // extern "C++"
 
 int64_t scoary_permute_lists_scratch_bytes(int64_t G, int64_t T, int64_t N, int64_t P) {
@@ -926,6 +987,10 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   uint32_t* sc = static_cast<uint32_t*>(d_scratch);
+  if (list_segments(N) > 1)
+    return launch_permute_seglists(h, s, d_tiles, d_lidx, entries, d_lstart, d_lngroups, d_lorder,
+                                   d_lflipped, d_crit, d_lcrit, d_margins, sc, G, T, N, P, d_r,
+                                   accumulate);
   // counter planes KC: lists hold <= N/2 entries, N/2 < 2^KC (and N + 1 < 2^(KC+1))
 #define LAUNCH(TWV, KCV)                                                                        \
   return launch_permute_lists<TWV, KCV>(h, s, d_tiles, d_lidx, entries, d_lstart, d_lngroups,   \

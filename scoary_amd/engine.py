@@ -39,7 +39,8 @@ class GeneMatrix:
 
 
 class GeneLists:
-    """Minority index lists of a gene matrix on the device (scoary_lists_plan / _fill)."""
+    """Minority index lists of a gene matrix on the device (scoary_lists_plan / _fill).
+    start / ngroups: int32 [G] per list slot, or [segments, G] for N > 40959."""
 
     def __init__(self, idx, start, ngroups, order, flipped, entries):
         self.idx, self.start, self.ngroups = idx, start, ngroups
@@ -211,8 +212,10 @@ class AssociationEngine:
         G, N = genes.G, genes.N
         scratch = self._empty((int(self.lib.scoary_lists_scratch_bytes(G, N)) // 8 + 1,),
                               torch.int64)
-        start = self._empty((G,), torch.int32)
-        ngroups = self._empty((G,), torch.int32)
+        nseg = max(1, int(self.lib.scoary_list_segments(N)))      # N > 40959: sub-lists per segment
+        shape = (G,) if nseg == 1 else (nseg, G)
+        start = self._empty(shape, torch.int32)
+        ngroups = self._empty(shape, torch.int32)
         order = self._empty((G,), torch.int32)
         flipped = self._empty((G,), torch.uint8)
         entries = ctypes.c_int64()

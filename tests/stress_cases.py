@@ -8,9 +8,9 @@ Every function returns (ok, description).
 import numpy as np
 
 TILE_N = [1, 5, 63, 64, 65, 127, 128, 129, 500, 1000, 2559, 2560, 4000, 5120, 9000, 10240, 15000,
-          20480, 31000, 40959]
+          20480, 31000, 40959, 40960, 70001, 122496]
 LIST_N = [1, 2, 31, 32, 33, 64, 100, 511, 1000, 2047, 2048, 2559, 2560, 3333, 5119, 5120, 7777,
-          10239, 10240, 13001, 20479, 20480, 33333, 40959]
+          10239, 10240, 13001, 20479, 20480, 33333, 40959, 40960, 61111, 100003]
 BUILD_N = [1, 2, 15, 16, 17, 31, 33, 64, 100, 511, 1000, 2047, 2559, 2560, 3333, 5119, 5120, 7777,
            10239, 10240, 13001, 20479, 20480, 33333, 40959]
 
@@ -50,7 +50,16 @@ def tiles_case(eng, case, seed=11):
     RS, tperm = stride // 4, tw_ * 32
     ntiles = -(-P // tperm)
     tw = int(eng.lib.scoary_list_tile_words(N))
-    tiles = tiles.reshape(T, ntiles, tw)[:, :, :(N + 1) * RS].reshape(T, ntiles, N + 1, RS)
+    S = int(eng.lib.scoary_list_segments(N))
+    if S > 1:         # N > 40959: segments of 40832 rows, 40836 dwords apart, each with its zero row
+        seg = tiles.reshape(T, ntiles, S, 40836)
+        n_s = [min(40832, N - k * 40832) for k in range(S)]
+        zero = all(not seg[:, :, k, n_s[k]].any() for k in range(S))
+        body = np.concatenate([seg[:, :, k, :n_s[k]] for k in range(S)], axis=2)     # (T, ntiles, N)
+        tiles = np.concatenate([body, np.zeros((T, ntiles, 1), dtype=np.uint32) if zero
+                                else np.ones((T, ntiles, 1), dtype=np.uint32)], axis=2)[..., None]
+    else:
+        tiles = tiles.reshape(T, ntiles, tw)[:, :, :(N + 1) * RS].reshape(T, ntiles, N + 1, RS)
     bits = np.unpackbits(rows.view(np.uint8).reshape(T, P, -1), axis=2, bitorder="little")[:, :, :N]
     ok = True
     for t in range(T):
@@ -79,6 +88,8 @@ def lists_case(eng, case, seed=23):
     T = int(rng.integers(1, 4))
     P = int(rng.choice([1, 100, 128, 129, 512, 513, 700]))
     dens = str(rng.choice(["uniform", "sparse", "dense", "half"]))
+    if N > 40959:                                    # segmented lists: keep the host generation short
+        G, P = min(G, 300), min(P, 129)
     genes = (rng.random((G, N)) < _gene_freq(rng, dens, G)).astype(np.uint8)
     traits = _traits(rng, T, N, 0.5)
     tb, mb = _bits(traits)

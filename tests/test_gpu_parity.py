@@ -435,7 +435,7 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, null, null, p, p, 4, 1, 100, 10, p, 1, null) == -1
     assert lib.scoary_permute(h, p, p, p, 1, 70000, 10, 10, p, null) == -3          # T > 65535
     assert lib.scoary_perm_generate(h, p, p, 1, 10, 2**33, 0, 0, 1, p, null) == -3   # index >= 2^32
-    assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, p, null, p, p, 4, 1, 40960, 10, p, 1, null) == -3
+    assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, p, null, p, p, 4, 1, 122497, 10, p, 1, null) == -3
     assert b"LDS" in lib.scoary_last_error(h)
     assert lib.scoary_tree_pairs(h, p, 3, 40, p, p, 1, 1, 2, p, null) == -3          # stack_depth > 32
     assert lib.scoary_counts(null, p, p, p, 1, 1, 1, p, p, null) == -1
@@ -447,8 +447,11 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_list_params(5120, params) == 0 and list(params) == [4, 16, 64, 16, 4]
     assert lib.scoary_list_params(10240, params) == 0 and list(params) == [2, 8, 64, 32, 4]
     assert lib.scoary_list_params(20480, params) == 0 and list(params) == [1, 4, 64, 64, 4]
-    assert lib.scoary_list_params(40960, params) == -3 and params[0] == 0
-    assert lib.scoary_list_max_isolates() == 40959
+    assert lib.scoary_list_params(40960, params) == 0 and list(params) == [1, 4, 64, 64, 4]   # 2 segments
+    assert lib.scoary_list_params(122497, params) == -3 and params[0] == 0
+    assert lib.scoary_list_max_isolates() == 122496 == 3 * 40832
+    assert [lib.scoary_list_segments(n) for n in (1, 40959, 40960, 81664, 81665, 122496, 122497)] == \
+        [1, 1, 2, 2, 3, 3, 0]
 
 
 # ------------------------------------------- spec S6: device list builder -----
@@ -767,17 +770,18 @@ def test_fisher_symmetric_margins_and_large_n(eng, orc):
 
 
 def test_more_isolates_than_the_list_kernel_takes(eng, orc, caplog):
-    """N > 40959 (one 32-permutation label tile no longer fits the 160 KB of LDS): the list
-    builder refuses, associate() and the command line's _associate fall back to the dense
-    kernels -- and say so in the log -- with results equal to the
-    oracle's.  No BASELINE config is this wide."""
+    """N > 122 496 (more than three 40 832-isolate segments: the list counts would need a
+    17th counter plane): the list builder refuses, associate() and the command line's
+    _associate fall back to the dense kernels -- and say so in the log (VERDICT round 2,
+    item 8) -- with results equal to the oracle's.  No BASELINE config is this wide."""
     import logging
     from scoary_amd import methods as M
     from scoary_amd.engine import pack_bits_rows
     rng = np.random.default_rng(50)
-    G, N, T, P = 150, 50_000, 2, 64
+    G, N, T, P = 100, 122_497, 2, 40
     genes, traits = _random_case(rng, G, N, T)
-    assert not eng.lists_supported(N) and eng.lists_supported(40_959)
+    assert not eng.lists_supported(N) and eng.lists_supported(N - 1)
+    assert eng.lib.scoary_list_segments(N) == 0 and eng.lib.scoary_list_segments(N - 1) == 3
     gm = eng.pack_dense(genes)
     with pytest.raises(ValueError):
         eng.build_lists(gm)
@@ -794,3 +798,75 @@ def test_more_isolates_than_the_list_kernel_takes(eng, orc, caplog):
     gb = orc.pack_rows(genes)
     assert np.array_equal(out["counts"], orc.counts_packed(gb, tb, mb).transpose(1, 0, 2))
     assert np.array_equal(out["r"], orc.permute_r(gb, tb, mb, N, P, 77).T)
+
+
+@pytest.mark.parametrize("G,N,T,P", [(150, 40_960, 2, 70), (333, 50_000, 2, 33), (70, 90_001, 1, 100),
+                                     (64, 122_496, 1, 32)])
+def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
+    """40 959 < N <= 122 496 (round 3; the dense kernels took over here before): the isolates
+    are cut into 2 or 3 segments of 40 832, a block loads its 32-permutation tile one segment
+    at a time, every gene has one sub-list per segment and the counter planes live across the
+    reloads (k_permute_seglists).  Checked: (1) the label tiles hold the rows of
+    k_perm_generate, every segment with its own zero row; (2) every sub-list holds exactly the
+    gene's minority positions of that segment, as LDS addresses, zero-row padded; (3) r is
+    bit-identical to the dense kernels' and to the oracle's."""
+    rng = np.random.default_rng(G + N)
+    genes, traits = _random_case(rng, G, N, T)
+    genes[5] = (rng.random(N) < 0.0005)                   # sub-lists that are empty in a segment
+    genes[6, :40_832] = 0
+    tb, mb = _bits(eng, traits)
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    S = int(eng.lib.scoary_list_segments(N))
+    SEG, STRIDE = 40_832, 40_836
+    assert S == -(-N // SEG) and eng.list_params(N) == (1, 4, 64, 64, 4)
+    # (1) tiles
+    _, margins = eng.counts(gm, trv, mkv)
+    rows = eng.perm_generate(mkv, margins, N, P, 3, 17).cpu().numpy().view(np.uint32)
+    tiles = eng.perm_generate_tiles(mkv, margins, N, P, 3, 17).cpu().numpy().view(np.uint32)
+    ntiles = -(-P // 32)
+    assert int(eng.lib.scoary_list_tile_words(N)) == S * STRIDE
+    tiles = tiles.reshape(T, ntiles, S, STRIDE)
+    bits = np.unpackbits(rows.view(np.uint8).reshape(T, P, -1), axis=2, bitorder="little")[:, :, :N]
+    for s in range(S):
+        n_s = min(SEG, N - s * SEG)
+        tb_ = np.unpackbits(np.ascontiguousarray(tiles[:, :, s, :n_s + 1]).view(np.uint8)
+                            .reshape(T, ntiles, n_s + 1, 4), axis=3, bitorder="little")
+        assert not tb_[:, :, n_s].any()                   # the segment's zero row
+        for tile in range(ntiles):
+            lo, hi = tile * 32, min(P, tile * 32 + 32)
+            assert np.array_equal(tb_[:, tile, :n_s, :hi - lo],
+                                  bits[:, lo:hi, s * SEG:s * SEG + n_s].transpose(0, 2, 1))
+            assert not tb_[:, tile, :n_s, hi - lo:].any()
+    # (2) lists
+    L = eng.build_lists(gm)
+    idx = L.idx.cpu().numpy().view(np.uint32)
+    start = L.start.cpu().numpy().astype(np.int64).reshape(S, G) * 32
+    nhalf = L.ngroups.cpu().numpy().astype(np.int64).reshape(S, G)
+    order, flipped = L.order.cpu().numpy(), L.flipped.cpu().numpy()
+    ones = genes.sum(1, dtype=np.int64)
+    assert np.array_equal(flipped.astype(bool), 2 * ones > N)
+    lens = np.minimum(ones, N - ones)
+    assert np.array_equal(np.sort(order), np.arange(G)) and np.all(np.diff(lens[order]) <= 0)
+    total = 0
+    for k in range(G):
+        q, j = divmod(k, 64)
+        g = order[k]
+        minority = genes[g] == (0 if flipped[g] else 1)
+        for s in range(S):
+            n_s = min(SEG, N - s * SEG)
+            n = np.arange(nhalf[s, q * 64] * 16)
+            at = start[s, q * 64] + ((n // 4) * 64 + j) * 4 + n % 4
+            vals = idx[at]
+            want = np.flatnonzero(minority[s * SEG:s * SEG + n_s]) * 4
+            assert np.array_equal(np.sort(vals[:len(want)]), want)
+            assert np.all(vals[len(want):] == n_s * 4)
+            assert nhalf[s, k] == nhalf[s, q * 64] and start[s, k] == start[s, q * 64]
+        total = max(total, int(at.max()) + 1 if len(at) else total)
+    assert L.entries >= total
+    # (3) r
+    dense = eng.associate(gm, trv, mkv, permutations=P, seed=9, use_lists=False)
+    res = eng.associate(gm, trv, mkv, permutations=P, seed=9, use_lists=True)
+    assert np.array_equal(res["r"].cpu().numpy(), dense["r"].cpu().numpy())
+    assert np.array_equal(res["r"].cpu().numpy().view(np.uint32),
+                          orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, 9).T)
