@@ -484,3 +484,63 @@ def test_cli_cfg2_sized_table_every_row_vs_oracle(tmp_path):
                    for b, q in zip(bonf, naive))
     top = list(csv.reader(io.StringIO(files["tr0.results.csv"])))[1]
     assert top[0] == "g00011"                          # the planted gene wins its trait
+
+
+def test_cli_wide_table_takes_the_segmented_list_path(tmp_path, caplog):
+    """The command line on a table WIDER than one LDS label tile (41 000 isolates > 40 959;
+    round 3): the list-driven permutation path stays in charge -- two isolate segments,
+    k_permute_seglists -- instead of the dense fallback, and every output row (counts,
+    Naive_p, Empirical_p) equals the oracle's.  Also the native reader on 41 014-column rows."""
+    import logging
+    from oracle import oracle as orc
+    from scoary_amd import methods as M
+    from scoary_amd.engine import pack_bits_rows
+    rng = np.random.default_rng(41)
+    G, N, T, P, seed = 60, 41_000, 2, 96, 5
+    dense = rng.random((G, N)) < rng.beta(0.5, 0.5, (G, 1))
+    dense[3] = rng.random(N) < 0.3
+    lab = np.where(rng.random((T, N)) < 0.4, "1", "0").astype(object)
+    lab[0] = np.where(dense[3] ^ (rng.random(N) < 0.05), "1", "0")
+    lab[1, rng.random(N) < 0.02] = "NA"
+    iso = ["s%05d" % i for i in range(N)]
+    meta = ["Gene", "Non-unique Gene name", "Annotation", "No. isolates", "No. sequences",
+            "Avg sequences per isolate", "Genome Fragment", "Order within Fragment",
+            "Accessory Fragment", "Accessory Order with Fragment", "QC", "Min group size nuc",
+            "Max group size nuc", "Avg group size nuc"]
+    cells = np.where(dense, "x", "")
+    gtxt = ",".join(meta + iso) + "\n" + "".join(
+        "g%03d,,wide,%s,%s\n" % (g, ",".join(["1"] * 11), ",".join(cells[g])) for g in range(G))
+    ttxt = "," + ",".join("tr%d" % t for t in range(T)) + "\n" + "".join(
+        iso[i] + "," + ",".join(lab[:, i]) + "\n" for i in range(N))
+    (tmp_path / "g.csv").write_text(gtxt)
+    (tmp_path / "t.csv").write_text(ttxt)
+    with caplog.at_level(logging.INFO, logger=M.log.name):
+        files = run_cli(["-g", str(tmp_path / "g.csv"), "-t", str(tmp_path / "t.csv"),
+                         "--no_pairwise", "-e", str(P), "--seed", str(seed), "-p", "1.0"],
+                        tmp_path / "out")
+    assert not any("dense permutation kernels" in r.getMessage() for r in caplog.records)
+    ids, strains, genes, names, traits = read_dense(gtxt, ttxt)
+    assert strains == iso and len(ids) == G
+    gb = orc.pack_rows(genes)
+    tb = pack_bits_rows((traits == 1).astype(np.uint8))
+    mb = pack_bits_rows((traits != 2).astype(np.uint8))
+    r = orc.permute_r(gb, tb, mb, N, P, seed)
+    cnt_all = orc.counts_packed(gb, tb, mb)
+    for t, trait in enumerate(names):
+        rows = list(csv.reader(io.StringIO(files[trait + ".results.csv"])))
+        col = {c: k for k, c in enumerate(rows[0])}
+        cnt = cnt_all[:, t]
+        _, p = orc.fisher_many(cnt)
+        keep = [g for g in range(G) if cnt[g, 0] + cnt[g, 2] and cnt[g, 1] + cnt[g, 3]]
+        assert 50 <= len(keep) < G and len(rows) - 1 == len(keep)     # skip rule at this width too
+        seen = set()
+        for d in rows[1:]:
+            g = int(d[0][1:])
+            seen.add(g)
+            assert [int(d[col[c]]) for c in
+                    ("Number_pos_present_in", "Number_neg_present_in",
+                     "Number_pos_not_present_in", "Number_neg_not_present_in")] == \
+                [cnt[g, 0], cnt[g, 2], cnt[g, 1], cnt[g, 3]]
+            assert abs(float(d[col["Naive_p"]]) - p[g]) <= 1e-12 + 1e-11 * p[g]
+            assert d[col["Empirical_p"]] == repr((float(r[g, t]) + 1.0) / (P + 1.0))
+        assert seen == set(keep)
