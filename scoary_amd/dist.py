@@ -95,13 +95,19 @@ def init_from_env():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # SCOARY_SHARE_GPU=1: rank r uses device r % visible devices, and SCOARY_DIST_BACKEND=gloo
+        # replaces RCCL (which wants one device per rank): a functional check of the sharded
+        # command line on a single-GPU box (tests/test_gpu_two_ranks.py), not a way to run it
+        backend = os.environ.get("SCOARY_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
+            if os.environ.get("SCOARY_SHARE_GPU") == "1":
+                local_rank %= torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
         if not dist.is_initialized():
-            if torch.cuda.is_available():
+            if backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group(backend)
     return world, rank, local_rank
 
 
@@ -119,9 +125,15 @@ def all_gather_genes(rec_local, G, group=None):
     if Gs != cap:
         send = torch.zeros((T, cap, W), dtype=rec_local.dtype, device=rec_local.device)
         send[:, :Gs] = rec_local
-    # concatenated-along-dim-0 output form: accepted by both RCCL and gloo
-    recv = torch.empty((world * T, cap, W), dtype=rec_local.dtype, device=rec_local.device)
-    dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    # concatenated-along-dim-0 output form: accepted by both RCCL and gloo; gloo moves host
+    # memory, so device tensors are staged through the host for it (functional checks only)
+    dev = rec_local.device
+    staged = dist.get_backend(group) != "nccl" and dev.type == "cuda"
+    send = send.contiguous().cpu() if staged else send.contiguous()
+    recv = torch.empty((world * T, cap, W), dtype=rec_local.dtype, device=send.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    if staged:
+        recv = recv.to(dev)
     recv = recv.view(world, T, cap, W)
     parts = [recv[r, :, :b - a] for r, (a, b) in enumerate(bounds)]
     return torch.cat(parts, dim=1).contiguous()

@@ -54,3 +54,44 @@ def test_bench_two_ranks_share_the_gpu(scaling):
         assert r["kernel_ms"]["k_permute_lists"] > 0 and r["kernel_ms"]["k_counts"] > 0
         assert r["exchange_exposed_ms"] is not None and 0 <= r["exchange_exposed_ms"] < 5000
         assert r["ms_per_step"] <= d["ms_per_step"] * (1 + 1e-9)      # value uses the MAX over ranks
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("extra", [["--no_pairwise", "-e", "200", "--seed", "7"], ["--collapse", "-c", "I", "-p", "0.05"]],
+                         ids=["fisher-permutations", "pairwise-collapse"])
+def test_command_line_two_ranks_share_the_gpu(exampledir, tmp_path, extra):
+    """`python -m scoary_amd` under torch.distributed.run with two ranks on the one GPU
+    (SCOARY_SHARE_GPU=1, SCOARY_DIST_BACKEND=gloo): every rank parses one byte range of the
+    gene table, takes one contiguous gene shard through the kernels, the per-gene records are
+    all-gathered, rank 0 writes -- and the result files are byte-identical to a single-process
+    run's (Tree.nwk included in default mode).  Reference analogue: scoary/methods.py:1076-1122."""
+    inputs = ["-g", os.path.join(exampledir, "Gene_presence_absence.csv"),
+              "-t", os.path.join(exampledir, "Tetracycline_resistance.csv")]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    one, two = tmp_path / "one", tmp_path / "two"
+    cmd = [sys.executable, "-m", "scoary_amd"] + inputs + extra + ["--no-time", "-u"]
+    out = subprocess.run(cmd + ["-o", str(one)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    env2 = dict(env, SCOARY_SHARE_GPU="1", SCOARY_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          "-m", "scoary_amd"] + inputs + extra + ["--no-time", "-u", "-o", str(two)],
+                         capture_output=True, text=True, timeout=900, env=env2, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "byte ranges" in out.stdout                       # the ranks split the reading
+    names = sorted(f for f in os.listdir(one) if not f.startswith("scoary"))
+    assert any(f.endswith(".results.csv") for f in names)
+    assert names == sorted(f for f in os.listdir(two) if not f.startswith("scoary"))
+    for f in names:
+        assert (one / f).read_bytes() == (two / f).read_bytes(), f
+    assert os.path.exists(two / "scoary.rank1.log")          # rank 1 ran, logged, wrote no results
