@@ -167,15 +167,14 @@ int scoary_permute_seq(scoary_handle h, const uint32_t *d_tiled, const uint32_t 
  * different data flow: genes as lists of the isolates that carry their
  * minority value (built once per dataset, on the device: scoary_lists_plan /
  * scoary_lists_fill below), permuted labels as isolate-major tiles of 512 / 256 /
- * 128 / 64 / 32 permutations (N <= 2559 / 5119 / 10239 / 20479 / 40959) that live
- * in LDS, overlap counts as bit-sliced counters, 128 (64, 32 for the last two)
- * permutations per lane.  Cost
+ * 128 / 64 permutations (N <= 2559 / 5119 / 10239 / beyond) that live in LDS, overlap
+ * counts as bit-sliced counters, 128 (64 for the last) permutations per lane.  Cost
  * is proportional to the list length, so sparse (or near-core) genes are
- * cheap.  One tile fits in LDS up to N = 40959; wider matrices, up to N =
- * scoary_list_max_isolates() = 122496, are cut into scoary_list_segments(N) = 2 or 3
- * SEGMENTS of 40832 isolates: a block loads its 32-permutation tile one segment at a
- * time, a gene's list is one sub-list per segment, the counters live across the reloads
- * (round 3; the dense kernels took over at N = 40960 before).
+ * cheap.  One 64-permutation tile fits in LDS up to N = 20479; wider matrices, up to N =
+ * scoary_list_max_isolates() = 131070, are cut into scoary_list_segments(N) = 2 ... 7
+ * SEGMENTS of 20352 isolates: a block loads its tile one segment at a time, a gene's
+ * list is one sub-list per segment, the counters live across the reloads (round 3; the
+ * dense kernels took over at N = 40960 before).
  *   d_tiles : uint32 [scoary_list_tiles_words(N, P, T)]
  *   d_lidx / d_lstart / d_lngroups / d_lorder / d_lflipped : the index lists of the
  *             gene matrix, built on the device by scoary_lists_plan + scoary_lists_fill
@@ -193,9 +192,9 @@ int scoary_permute_seq(scoary_handle h, const uint32_t *d_tiled, const uint32_t 
 int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T);
 int64_t scoary_list_tile_words(int64_t N);   /* dwords per (trait, tile) */
 int64_t scoary_list_max_isolates(void);
-int64_t scoary_list_segments(int64_t N);     /* 1 for N <= 40959, else ceil(N / 40832); 0: too large */
+int64_t scoary_list_segments(int64_t N);     /* 1 for N <= 20479, else ceil(N / 20352); 0: too large */
 /* out5 = { tile row width in dwords of 32 permutations (16 for N <= 2559, 8 for N <= 5119,
- * 4 for N <= 10239, 2 for N <= 20479, 1 for N <= 40959), row stride in bytes, genes per wavefront, residue classes,
+ * 4 for N <= 10239, 2 beyond), row stride in bytes, genes per wavefront, residue classes,
  * interleave piece } -- the last four are the arguments scoary_lists_build
  * wants.  Error if N is too large. */
 int scoary_list_params(int64_t N, int64_t *out5);
@@ -223,13 +222,13 @@ int scoary_permute_lists(scoary_handle h, const uint32_t *d_tiles, const uint32_
  *   scoary_lists_plan : popcount -> flip -> radix sort by length -> padded lengths
  *       and group bases (prefix sum).  Writes d_order (int32 [G], per list slot),
  *       d_start / d_ngroups (int32 [scoary_list_segments(N)][G]: per segment and list
- *       slot -- plain [G] for N <= 40959) and d_flipped (uint8 [G], per gene); *entries_out (HOST)
+ *       slot -- plain [G] for N <= 20479) and d_flipped (uint8 [G], per gene); *entries_out (HOST)
  *       = total number of entries.  Synchronises `stream` (the caller needs the
  *       count to allocate d_idx).
  *   scoary_lists_fill : d_idx = uint32 [entries + scoary_lists_slack_entries()],
  *       entry = position * row stride (the LDS byte offset of that isolate's label
- *       row), padding = N * row stride (the all-zero row).  Segmented lists (N > 40959):
- *       entry = (position - segment start) * 4, padding = the segment's own zero row.
+ *       row), padding = N * row stride (the all-zero row).  Segmented lists (N > 20479):
+ *       entry = (position - segment start) * 8, padding = the segment's own zero row.
  *   d_scratch : scoary_lists_scratch_bytes(G, N) bytes, the SAME buffer in both calls
  *       (plan leaves the lengths and group bases in it). */
 int64_t scoary_lists_scratch_bytes(int64_t G, int64_t N);

@@ -56,19 +56,21 @@ inline int64_t tiled_quads(int64_t N) {
 // TW = tile row width in dwords (32 permutations each): 16 while a tile of 512
 // permutations x (N+1) rows fits in LDS (N <= 2559), 8 (tiles of 256) up to
 // N <= 5119, 4 (tiles of 128) up to N <= 10239, 2 (tiles of 64, two words per lane)
-// up to N <= 20479, 1 (tiles of 32, one word per lane) up to N <= 40959.  A gene takes
-// max(TW/4, 1) lanes and a wavefront 64 / that many genes of similar list length.
-// Wider matrices (N <= 122496) keep TW = 1 and cut the isolates into 2 or 3 SEGMENTS of
-// kSegRows rows: a block loads one segment of its tile at a time and a gene's list is one
-// sub-list per segment (k_permute_seglists; the counter planes live across the reloads).
-constexpr int kSegRows = 40832;                      // 319 * 128: whole word quads, (rows + 1) dwords fit 160 KB
-constexpr int kSegStride = (kSegRows + 1 + 3) / 4 * 4;   // dwords from one segment of a tile to the next
-constexpr int kMaxSegments = 3;                      // N / 2 < 2^16: sixteen counter planes
+// beyond.  A gene takes max(TW/4, 1) lanes and a wavefront 64 / that many genes of
+// similar list length.  A two-dword tile fits LDS whole up to N = 20479; wider matrices
+// (N <= 131070) cut the isolates into SEGMENTS of kSegRows rows: a block loads one segment
+// of its tile at a time and a gene's list is one sub-list per segment (k_permute_seglists;
+// the counter planes live across the reloads).  (Round 3 first did this with one-dword
+// tiles, 32 permutations per lane: 2.1x slower per listed row, tools/sweep_isolates.py.)
+constexpr int kSegRows = 20352;                      // 159 * 128: whole word quads; (rows + 1) * 8 B fit 160 KB
+constexpr int kSegTW = 2;                            // dwords per row of a segmented tile
+constexpr int kSegStride = ((kSegRows + 1) * kSegTW + 3) / 4 * 4;   // dwords from one segment of a tile to the next
+constexpr int kMaxListIsolates = 131070;             // N / 2 < 2^16: sixteen counter planes; at most 7 segments
 __host__ __device__ constexpr int list_segments(int64_t N) {
-  return N <= 40959 ? 1 : (N <= (int64_t)kMaxSegments * kSegRows ? (int)((N + kSegRows - 1) / kSegRows) : 0);
+  return N <= 20479 ? 1 : (N <= kMaxListIsolates ? (int)((N + kSegRows - 1) / kSegRows) : 0);
 }
 __host__ __device__ constexpr int list_tw(int64_t N) {
-  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : (N <= 20479 ? 2 : (list_segments(N) ? 1 : 0))));
+  return N <= 2559 ? 16 : (N <= 5119 ? 8 : (N <= 10239 ? 4 : (list_segments(N) ? 2 : 0)));
 }
 __host__ __device__ constexpr int list_lpg(int TW) { return TW >= 4 ? TW / 4 : 1; }   // lanes per gene
 __host__ __device__ constexpr int list_nw(int TW) { return TW >= 4 ? 4 : TW; }        // words per lane
@@ -76,17 +78,17 @@ __host__ __device__ constexpr int list_nw(int TW) { return TW >= 4 ? 4 : TW; }  
 __host__ __device__ constexpr int64_t list_tile_dwords(int64_t N, int TW) {
   return ((N + 1) * TW + 3) / 4 * 4;
 }
-// the same for any N the list path takes; segmented tiles (TW = 1, N > 40959): kSegStride dwords
-// per segment, each with its own all-zero row after its last isolate
+// the same for any N the list path takes; segmented tiles (N > 20479): kSegStride dwords per
+// segment, each with its own all-zero row after its last isolate
 __host__ __device__ constexpr int64_t list_tile_dwords_seg(int64_t N, int TW) {
   return list_segments(N) > 1 ? (int64_t)list_segments(N) * kSegStride : list_tile_dwords(N, TW);
 }
-// rows of segment s, and the dword of row `row` inside a (TW = 1) tile
+// rows of segment s, and the first dword of row `row` inside a two-dword tile
 __host__ __device__ constexpr int64_t list_seg_rows(int64_t N, int s) {
   return list_segments(N) > 1 ? (N - (int64_t)s * kSegRows < kSegRows ? N - (int64_t)s * kSegRows : kSegRows) : N;
 }
 __host__ __device__ constexpr int64_t list_row_dword(int64_t N, int64_t row) {
-  return list_segments(N) > 1 ? row / kSegRows * kSegStride + row % kSegRows : row;
+  return list_segments(N) > 1 ? row / kSegRows * kSegStride + row % kSegRows * kSegTW : row * kSegTW;
 }
 
 constexpr int kListPad = 16;        // list lengths are padded to a multiple of this many entries (half a 32-entry step)

@@ -24,7 +24,7 @@ inline ListScratch list_scratch(int64_t G, int64_t N) {
   const int64_t gpw = TW ? kWave / list_lpg(TW) : 64;
   s.nblk = (G + kSortItems - 1) / kSortItems;
   s.nwg = (G + gpw - 1) / gpw;
-  s.nseg = list_segments(N) > 1 ? list_segments(N) : 1;      // sub-lists per gene (N > 40959)
+  s.nseg = list_segments(N) > 1 ? list_segments(N) : 1;      // sub-lists per gene (N > 20479)
   int64_t off = 0;
   s.len = off;    off += lb_align8(4 * G);
   s.ord_a = off;  off += lb_align8(4 * G);
@@ -288,11 +288,11 @@ __global__ __launch_bounds__(256) void k_lists_fill(const uint4* __restrict__ ti
   for (int n = total + c; n < L; n += C) idx[at(n)] = zero_row;
 }
 
-// ---- segmented lists (N > 40959, scoary_common.hpp): one sub-list per gene and segment ----
+// ---- segmented lists (N > 20479, scoary_common.hpp): one sub-list per gene and segment ----
 // Order and flip are the whole row's (k_lists_len + sort); the sub-lists of a wave group are
 // padded to the longest of the group in that segment; entries are byte addresses inside the
-// segment's tile (row - segment start) * 4, padding points at the segment's own zero row.
-// Segments start on multiples of 128 isolates, so a position's residue class mod 64 is the
+// segment's tile (row - segment start) * 8, padding points at the segment's own zero row.
+// Segments start on multiples of 128 isolates, so a position's residue class mod 32 is the
 // same inside the segment as in the row.
 
 // lane = gene: minority count inside every segment
@@ -378,8 +378,9 @@ __global__ __launch_bounds__(256) void k_lists_segslots(const int32_t* __restric
     ngroups[(int64_t)sgm * G + k] = padded[q * nseg + sgm] / kListPad;
   }
 }
-// The entry order of spec S6 inside every segment (k_lists_fill<64> with a segment loop):
-// wavefront = list slot, lane = residue class.
+// The entry order of spec S6 inside every segment (k_lists_fill with a segment loop): C lanes
+// per slot (lane = residue class), 64 / C slots per wavefront; C = 32 for the two-dword tiles.
+template <int C>
 __global__ __launch_bounds__(256) void k_lists_fill_seg(const uint4* __restrict__ tiled, int64_t Gp,
                                                         int G, int N, int nseg,
                                                         const int32_t* __restrict__ seglen,
@@ -389,24 +390,26 @@ __global__ __launch_bounds__(256) void k_lists_fill_seg(const uint4* __restrict_
                                                         const int32_t* __restrict__ padded,
                                                         int64_t nslots, uint32_t* __restrict__ idx) {
   __shared__ int32_t s_cnt[256];
-  constexpr int C = 64, gpw = 64, piece = 4;
-  constexpr uint32_t row_stride = 4u;
-  const int tid = threadIdx.x, c = tid & 63, wave = tid >> 6;
-  const int64_t k = (int64_t)blockIdx.x * 4 + wave;
+  static_assert(C <= 32, "a class is a set of bits of every 32-bit word");
+  constexpr int SPW = 64 / C, gpw = 64, piece = 4;
+  constexpr uint32_t row_stride = 4u * kSegTW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane % C;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * SPW + lane / C;
   const bool exists = k < nslots, live = k < G;
   const int64_t q = exists ? k / gpw : 0;
   const int j = (int)(k - q * gpw);
   const int g = live ? order[k] : 0;
   const uint32_t inv = (live && flipped[g]) ? 0xffffffffu : 0u;
-  const uint32_t cmask = 1u << (c & 31);       // class c: bit c & 31 of the words of parity c >> 5
+  uint32_t cmask = 0u;                         // bits of a 32-bit word that belong to class c
+  for (int b = c; b < 32; b += C) cmask |= 1u << b;
   auto class_bits = [&](uint32_t word, int w) -> uint32_t {
     const int first = 32 * w;
     uint32_t bits = word ^ inv;
     if (first + 32 > N) bits &= first < N ? ((1u << (N - first)) - 1u) : 0u;
-    if ((w & 1) != (c >> 5)) return 0u;
     return bits & cmask;
   };
-  const int32_t* cnt = s_cnt + (tid - c);      // the 64 class counts of this slot
+  const int32_t* cnt = s_cnt + (tid - c);      // the C class counts of this slot
   const int dk = (int)((c - k) & (C - 1));
   for (int sgm = 0; sgm < nseg; ++sgm) {
     const int row0 = sgm * kSegRows, rows = (int)list_seg_rows(N, sgm);
@@ -521,7 +524,7 @@ int scoary_lists_plan(scoary_handle h, const uint32_t* d_tiled, int64_t G, int64
     hipLaunchKernelGGL(k_sort_scatter, dim3((unsigned)L.nblk), dim3(64), 0, s, in, len, (int)G,
                        kmax, 8 * p, (int)L.nblk, hist, out);
   }
-  if (L.nseg > 1) {           // N > 40959: sub-lists per segment, d_start / d_ngroups are [nseg][G]
+  if (L.nseg > 1) {           // N > 20479: sub-lists per segment, d_start / d_ngroups are [nseg][G]
     int32_t* seglen = reinterpret_cast<int32_t*>(sc + L.seglen);
     hipLaunchKernelGGL(k_lists_seglen, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const uint4*>(d_tiled), Gp, (int)G, (int)N, (int)L.nseg,
@@ -566,7 +569,8 @@ int scoary_lists_fill(scoary_handle h, const uint32_t* d_tiled, int64_t G, int64
   const dim3 grid((unsigned)((nslots + spb - 1) / spb));
   KernelTimer kt(h, s, "k_lists_fill");
   if (L.nseg > 1) {
-    hipLaunchKernelGGL(k_lists_fill_seg, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, s,
+    static_assert(64 / kSegTW == 32, "residue classes of the segmented tiles");
+    hipLaunchKernelGGL((k_lists_fill_seg<32>), dim3((unsigned)((nslots + 7) / 8)), dim3(256), 0, s,
                        reinterpret_cast<const uint4*>(d_tiled), Gp, (int)G, (int)N, (int)L.nseg,
                        reinterpret_cast<const int32_t*>(sc + L.seglen), d_order, d_flipped, base,
                        padded, nslots, d_idx);
@@ -579,8 +583,7 @@ int scoary_lists_fill(scoary_handle h, const uint32_t* d_tiled, int64_t G, int64
                      reinterpret_cast<const uint4*>(d_tiled), Gp, (int)G, (int)N, Qn, len,     \
                      d_order, d_flipped, base, padded, gpw, piece, (uint32_t)(TW * 4), nslots, \
                      d_idx)
-  if (C == 4) FILL(4); else if (C == 8) FILL(8); else if (C == 16) FILL(16);
-  else if (C == 32) FILL(32); else FILL(64);
+  if (C == 4) FILL(4); else if (C == 8) FILL(8); else if (C == 16) FILL(16); else FILL(32);
 #undef FILL
   hipLaunchKernelGGL(k_lists_slack, dim3(1), dim3(256), 0, s, d_idx, entries);
   HIP_TRY(h, hipGetLastError());

@@ -123,9 +123,8 @@ __device__ __forceinline__ uint32_t full_add(uint32_t& c, uint32_t x, uint32_t y
 // zero; dword j of a row = labels of permutations tile*TW*32 + 32j .. +31.
 // One wavefront generates 64 consecutive permutations (spec S4, same draws as
 // k_perm_generate) and transposes them with ballots.
-// Where the 64 permutations of generator wavefront `wave` go: dwords lo / hi of tile rows
-// `stride` dwords apart.  TW >= 2: two adjacent dwords of one tile; TW == 1: the rows of two
-// consecutive 32-permutation tiles (hi == nullptr when the second tile does not exist).
+// Where the 64 permutations of generator wavefront `wave` go: two adjacent dwords lo / hi of the
+// rows of one tile, `stride` dwords apart.
 struct TileOut {
   uint32_t* lo;
   uint32_t* hi;
@@ -133,41 +132,37 @@ struct TileOut {
 };
 template <int TW>
 __device__ __forceinline__ TileOut tile_out(uint32_t* tiles, int t, int ntiles, int64_t wave, int N) {
-  const int64_t tile_dw = TW == 1 ? list_tile_dwords_seg(N, TW) : list_tile_dwords(N, TW);
-  if constexpr (TW >= 2) {
-    const int waves_per_tile = TW / 2;
-    const int tile = (int)(wave / waves_per_tile);
-    const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
-    uint32_t* base = tiles + ((int64_t)t * ntiles + tile) * tile_dw + col;
-    return {base, base + 1, TW};
-  } else {
-    uint32_t* base = tiles + ((int64_t)t * ntiles + 2 * wave) * tile_dw;
-    return {base, 2 * wave + 1 < ntiles ? base + tile_dw : nullptr, 1};
-  }
+  static_assert(TW >= 2, "a generator wavefront writes two dwords of a tile row");
+  const int64_t tile_dw = TW == kSegTW ? list_tile_dwords_seg(N, TW) : list_tile_dwords(N, TW);
+  const int waves_per_tile = TW / 2;
+  const int tile = (int)(wave / waves_per_tile);
+  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
+  uint32_t* base = tiles + ((int64_t)t * ntiles + tile) * tile_dw + col;
+  return {base, base + 1, TW};
 }
 // dword of tile row `row` relative to out.lo / out.hi: row * stride, except in the segmented
-// one-dword tiles of N > 40959 (scoary_common.hpp: every segment its own zero row)
+// two-dword tiles of N > 20479 (scoary_common.hpp: every segment its own zero row)
 template <int TW>
 __device__ __forceinline__ int64_t tile_row_off(const TileOut& out, int N, int row) {
-  if constexpr (TW == 1) return list_row_dword(N, row);
+  if constexpr (TW == kSegTW) return list_row_dword(N, row);
   return (int64_t)row * out.stride;
 }
 // the all-zero row(s) that list padding points at (one thread)
 template <int TW>
 __device__ __forceinline__ void tile_zero_rows(const TileOut& out, int N) {
-  if constexpr (TW == 1) {
+  if constexpr (TW == kSegTW) {
     const int nseg = list_segments(N);
     if (nseg > 1) {
       for (int sgm = 0; sgm < nseg; ++sgm) {
-        const int64_t z = (int64_t)sgm * kSegStride + list_seg_rows(N, sgm);
+        const int64_t z = (int64_t)sgm * kSegStride + list_seg_rows(N, sgm) * kSegTW;
         out.lo[z] = 0u;
-        if (out.hi) out.hi[z] = 0u;
+        out.hi[z] = 0u;
       }
       return;
     }
   }
   out.lo[(int64_t)N * out.stride] = 0u;
-  if (out.hi) out.hi[(int64_t)N * out.stride] = 0u;
+  out.hi[(int64_t)N * out.stride] = 0u;
 }
 template <int TW>
 __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __restrict__ masks,
@@ -212,7 +207,7 @@ __global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __re
           if (row < N) {
             const int64_t ro = tile_row_off<TW>(out, N, row);
             out.lo[ro] = (uint32_t)mine;
-            if (out.hi) out.hi[ro] = (uint32_t)(mine >> 32);
+            out.hi[ro] = (uint32_t)(mine >> 32);
           }
           mine = 0;
         }
@@ -329,7 +324,7 @@ __global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_til
       if (row < N) {
         const int64_t ro = tile_row_off<TW>(out, N, row);
         out.lo[ro] = lo;
-        if (out.hi) out.hi[ro] = hi;
+        out.hi[ro] = hi;
       }
     }
     __syncthreads();
@@ -392,7 +387,7 @@ __global__ __launch_bounds__(kWave * 4) void k_perm_generate_tiles_wg4(
       if (row < N) {
         const int64_t ro = tile_row_off<TW>(out, N, row);
         out.lo[ro] = lo;
-        if (out.hi) out.hi[ro] = hi;
+        out.hi[ro] = hi;
       }
     }
     __syncthreads();
@@ -642,13 +637,13 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   }
 }
 
-// N > 40959: one 32-permutation tile no longer fits the 160 KB of LDS, so the isolates are cut
+// N > 20479: one 64-permutation tile no longer fits the 160 KB of LDS, so the isolates are cut
 // into nseg segments of kSegRows rows (scoary_common.hpp).  A gene's index list is one sub-list
 // per segment (entries = LDS byte addresses inside the segment, lstart / lngroups are [nseg][G]);
 // the block walks its wave groups in ROUNDS of one group per wavefront and, inside a round,
 // loads the tile segment by segment: the counter planes stay in registers across the reloads
-// and the region test comes after the last segment.  One lane per gene, one permutation word
-// per lane (the TW = 1 geometry), 16 counter planes (N / 2 < 2^16).  The walk itself is the
+// and the region test comes after the last segment.  One lane per gene, two permutation words
+// per lane (the TW = 2 geometry), 16 counter planes (N / 2 < 2^16).  The walk itself is the
 // code of k_permute_lists (scoary_list_walk.inc).
 template <int KC>
 __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __restrict__ tiles,
@@ -661,7 +656,8 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
                                                            int nseg, uint16_t* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
   scoary_bank_defs();
-  constexpr int LPG = 1, NW = 1, TW = 1, GPW = kWave;
+  constexpr int LPG = 1, NW = kSegTW, TW = kSegTW, GPW = kWave;
+  static_assert(kSegTW == 2, "two permutation words per lane");
   const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -722,7 +718,7 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
         Ent ring[4] = {load_from(cur, 0), load_from(cur, 1), load_from(cur, 2), load_from(cur, 3)};
         const int nhalf = cur.nhalf;
         const int nsuper = (nhalf + 1) >> 1;
-        const uint32_t colb = lds0;                    // one lane per gene: column 0
+        const uint32_t colb = lds0;                    // one lane per gene: column 0 (both words)
 #include "scoary_list_walk.inc"
       }
     }
@@ -731,11 +727,16 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
       const int slot = min(q * GPW + lg, G - 1);
       const bool have = q * GPW + lg < G;
       const uint2 cr = lcrit[(int64_t)t * G + slot];
-      const int64_t p_first = (int64_t)tile * 32;
-      const uint32_t valid = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
-      int cnt = __popc(region_bits<KC>(c0, cr.x, cr.y) & valid);
+      uint32_t valid[NW];                              // permutations of this tile that exist
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const int64_t p_first = ((int64_t)tile * TW + w) * 32;
+        valid[w] = p_first >= P ? 0u : (P - p_first >= 32 ? 0xffffffffu : ((1u << (P - p_first)) - 1u));
+      }
+      int cnt = __popc(region_bits<KC>(c0, cr.x, cr.y) & valid[0]) +
+                __popc(region_bits<KC>(c1, cr.x, cr.y) & valid[1]);
       if (!have) cnt = 0;
-      out[(int64_t)q * GPW + lg] = (uint16_t)cnt;                  // cnt <= 32
+      out[(int64_t)q * GPW + lg] = (uint16_t)cnt;                  // cnt <= 64
     }
   }
   (void)col;
@@ -768,7 +769,7 @@ int64_t scoary_list_tiles_words(int64_t N, int64_t P, int64_t T) {
   return T * ntiles * list_tile_dwords_seg(N, TW);
 }
 int64_t scoary_list_tile_words(int64_t N) { return list_tw(N) ? list_tile_dwords_seg(N, list_tw(N)) : 0; }
-int64_t scoary_list_max_isolates(void) { return (int64_t)kMaxSegments * kSegRows; }
+int64_t scoary_list_max_isolates(void) { return kMaxListIsolates; }
 int64_t scoary_list_segments(int64_t N) { return N < 1 ? 0 : list_segments(N); }
 int scoary_list_params(int64_t N, int64_t* out5) {
   if (!out5) return SCOARY_ERR_ARG;
@@ -796,8 +797,8 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t tile_perms = TW * 32;
   const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  // one generator wavefront per 64 permutations of a tile row (TW = 1: per two 32-permutation tiles)
-  const dim3 grid((unsigned)(TW >= 2 ? ntiles * (tile_perms / kWave) : (ntiles + 1) / 2), (unsigned)T);
+  // one generator wavefront per 64 permutations of a tile row
+  const dim3 grid((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T);
   KernelTimer kt(h, s, "k_perm_generate_tiles");
   // three kernels for the same tiles, by how many 64-permutation wavefronts there are per
   // SIMD: < 1: a workgroup of 8 (Philox producers + one selection wavefront, latency
@@ -820,7 +821,7 @@ int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const i
     hipLaunchKernelGGL((k_perm_generate_tiles<TWV>), grid, dim3(kWave), 0, s, d_masks, d_margins, \
                        (int)N, (int)scoary_row_words(N), P, perm_base, (int)trait_base,           \
                        (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
-  if (TW == 16) { GEN_TILES(16); } else if (TW == 8) { GEN_TILES(8); } else if (TW == 4) { GEN_TILES(4); } else if (TW == 2) { GEN_TILES(2); } else { GEN_TILES(1); }
+  if (TW == 16) { GEN_TILES(16); } else if (TW == 8) { GEN_TILES(8); } else if (TW == 4) { GEN_TILES(4); } else { GEN_TILES(2); }
 #undef GEN_TILES
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
@@ -912,7 +913,7 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }
-// N > 40959: the segmented kernel (k_permute_seglists), same scratch layout and geometry
+// N > 20479: the segmented kernel (k_permute_seglists), same scratch layout and geometry
 static int launch_permute_seglists(scoary_handle h, hipStream_t s, const uint32_t* d_tiles,
                                    const uint32_t* d_lidx, int64_t entries, const int32_t* d_lstart,
                                    const int32_t* d_lngroups, const int32_t* d_lorder,
@@ -935,7 +936,7 @@ static int launch_permute_seglists(scoary_handle h, hipStream_t s, const uint32_
     return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: grid too large");
   const size_t lds = (size_t)kSegStride * sizeof(uint32_t);
   const void* fn = reinterpret_cast<const void*>(&k_permute_seglists<KC>);
-  constexpr int kOptinBit = 32;                         // next to the tile widths 16 / 8 / 4 / 2 / 1
+  constexpr int kOptinBit = 32;                         // next to the tile widths 16 / 8 / 4 / 2
   if (!(h->lists_lds_optin & kOptinBit)) {
     hipFuncAttributes attr;
     HIP_TRY(h, hipFuncGetAttributes(&attr, fn));
@@ -999,8 +1000,7 @@ int scoary_permute_lists(scoary_handle h, const uint32_t* d_tiles, const uint32_
   if (TW == 16) LAUNCH(16, 11);
   if (TW == 8) LAUNCH(8, 12);
   if (TW == 4) LAUNCH(4, 13);
-  if (TW == 2) LAUNCH(2, 14);
-  LAUNCH(1, 15);
+  LAUNCH(2, 14);
 #undef LAUNCH
 }
 

@@ -40,7 +40,7 @@ class GeneMatrix:
 
 class GeneLists:
     """Minority index lists of a gene matrix on the device (scoary_lists_plan / _fill).
-    start / ngroups: int32 [G] per list slot, or [segments, G] for N > 40959."""
+    start / ngroups: int32 [G] per list slot, or [segments, G] for N > 20479."""
 
     def __init__(self, idx, start, ngroups, order, flipped, entries):
         self.idx, self.start, self.ngroups = idx, start, ngroups
@@ -212,7 +212,7 @@ class AssociationEngine:
         G, N = genes.G, genes.N
         scratch = self._empty((int(self.lib.scoary_lists_scratch_bytes(G, N)) // 8 + 1,),
                               torch.int64)
-        nseg = max(1, int(self.lib.scoary_list_segments(N)))      # N > 40959: sub-lists per segment
+        nseg = max(1, int(self.lib.scoary_list_segments(N)))      # N > 20479: sub-lists per segment
         shape = (G,) if nseg == 1 else (nseg, G)
         start = self._empty(shape, torch.int32)
         ngroups = self._empty(shape, torch.int32)

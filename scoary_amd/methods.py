@@ -621,8 +621,8 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
             # list-driven permutation kernel: cost follows each gene's minority count
             eng.build_lists(gm)
         elif permutations > 0 and not early_abort and not eng.lists_supported(N) and a == 0:
-            # one label tile of 32 permutations no longer fits the 160 KB of LDS: the dense
-            # AND + popcount kernels take over (same results, ~3.4x the time per test)
+            # more than 131 070 isolates: the list counts would need a 17th counter plane; the
+            # dense AND + popcount kernels take over (same results, 1.5-3x the time per test)
             log.info("%d isolates: more than the list-driven permutation kernel takes (%d); "
                      "using the dense permutation kernels" % (N, eng.lib.scoary_list_max_isolates()))
         if early_abort and permutations > 0:

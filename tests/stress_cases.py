@@ -8,11 +8,11 @@ Every function returns (ok, description).
 import numpy as np
 
 TILE_N = [1, 5, 63, 64, 65, 127, 128, 129, 500, 1000, 2559, 2560, 4000, 5120, 9000, 10240, 15000,
-          20480, 31000, 40959, 40960, 70001, 122496]
+          20480, 31000, 40959, 40960, 70001, 131070]
 LIST_N = [1, 2, 31, 32, 33, 64, 100, 511, 1000, 2047, 2048, 2559, 2560, 3333, 5119, 5120, 7777,
           10239, 10240, 13001, 20479, 20480, 33333, 40959, 40960, 61111, 100003]
 BUILD_N = [1, 2, 15, 16, 17, 31, 33, 64, 100, 511, 1000, 2047, 2559, 2560, 3333, 5119, 5120, 7777,
-           10239, 10240, 13001, 20479, 20480, 33333, 40959]
+           10239, 10240, 13001, 20479]
 
 
 def _bits(traits):
@@ -51,13 +51,13 @@ def tiles_case(eng, case, seed=11):
     ntiles = -(-P // tperm)
     tw = int(eng.lib.scoary_list_tile_words(N))
     S = int(eng.lib.scoary_list_segments(N))
-    if S > 1:         # N > 40959: segments of 40832 rows, 40836 dwords apart, each with its zero row
-        seg = tiles.reshape(T, ntiles, S, 40836)
-        n_s = [min(40832, N - k * 40832) for k in range(S)]
-        zero = all(not seg[:, :, k, n_s[k]].any() for k in range(S))
-        body = np.concatenate([seg[:, :, k, :n_s[k]] for k in range(S)], axis=2)     # (T, ntiles, N)
-        tiles = np.concatenate([body, np.zeros((T, ntiles, 1), dtype=np.uint32) if zero
-                                else np.ones((T, ntiles, 1), dtype=np.uint32)], axis=2)[..., None]
+    if S > 1:         # N > 20479: segments of 20352 two-dword rows, 40708 dwords apart, each with its zero row
+        seg = tiles.reshape(T, ntiles, S, 40708)
+        n_s = [min(20352, N - k * 20352) for k in range(S)]
+        zero = all(not seg[:, :, k, 2 * n_s[k]:2 * n_s[k] + 2].any() for k in range(S))
+        body = np.concatenate([seg[:, :, k, :2 * n_s[k]] for k in range(S)], axis=2)     # (T, ntiles, 2 N)
+        tiles = np.concatenate([body, np.zeros((T, ntiles, 2), dtype=np.uint32) if zero
+                                else np.ones((T, ntiles, 2), dtype=np.uint32)], axis=2).reshape(T, ntiles, N + 1, 2)
     else:
         tiles = tiles.reshape(T, ntiles, tw)[:, :, :(N + 1) * RS].reshape(T, ntiles, N + 1, RS)
     bits = np.unpackbits(rows.view(np.uint8).reshape(T, P, -1), axis=2, bitorder="little")[:, :, :N]
@@ -88,7 +88,7 @@ def lists_case(eng, case, seed=23):
     T = int(rng.integers(1, 4))
     P = int(rng.choice([1, 100, 128, 129, 512, 513, 700]))
     dens = str(rng.choice(["uniform", "sparse", "dense", "half"]))
-    if N > 40959:                                    # segmented lists: keep the host generation short
+    if N > 40959:                                    # long segmented lists: keep the host generation short
         G, P = min(G, 300), min(P, 129)
     genes = (rng.random((G, N)) < _gene_freq(rng, dens, G)).astype(np.uint8)
     traits = _traits(rng, T, N, 0.5)
@@ -124,6 +124,51 @@ def listbuild_case(eng, case, seed=91):
           and np.array_equal(L.ngroups.cpu().numpy(), H["ngroups"])
           and np.array_equal(L.idx.cpu().numpy().view(np.uint32)[:L.entries], H["idx"][:L.entries]))
     return bool(ok), "listbuild G=%d N=%d %s" % (G, N, dens)
+
+
+SEG_N = [20480, 20481, 31000, 40704, 40705, 61111, 100003, 131070]
+
+
+def seglists_case(eng, case, seed=57):
+    """Segmented lists (N > 20479: one sub-list per gene and 20 352-isolate segment, no host
+    builder to compare with): order / flip of the whole row, and every sub-list holds exactly the
+    gene's minority positions of its segment as LDS addresses ((row - segment start) * 8),
+    padded with the segment's zero row to the wave group's common length."""
+    rng = np.random.default_rng([seed, case])
+    N = int(rng.choice(SEG_N))
+    G = int(rng.choice([1, 3, 63, 64, 65, 130, 300]))
+    dens = str(rng.choice(["uniform", "sparse", "dense", "half", "ties"]))
+    genes = (rng.random((G, N)) < _gene_freq(rng, dens, G)).astype(np.uint8)
+    if dens == "ties" and G > 4:
+        genes[G // 2:] = genes[:G - G // 2]
+    if G > 2:
+        genes[1, :20352] = genes[1, 0]                # a sub-list that is empty or full in segment 0
+    gm = eng.pack_dense(genes)
+    L = eng.build_lists(gm)
+    S, SEG = int(eng.lib.scoary_list_segments(N)), 20352
+    idx = L.idx.cpu().numpy().view(np.uint32)
+    start = L.start.cpu().numpy().astype(np.int64).reshape(S, G) * 32
+    nhalf = L.ngroups.cpu().numpy().astype(np.int64).reshape(S, G)
+    order, flipped = L.order.cpu().numpy(), L.flipped.cpu().numpy()
+    ones = genes.sum(1, dtype=np.int64)
+    lens = np.minimum(ones, N - ones)
+    ok = (np.array_equal(flipped.astype(bool), 2 * ones > N) and np.array_equal(np.sort(order), np.arange(G))
+          and bool(np.all(np.diff(lens[order]) <= 0))
+          and np.array_equal(order, np.argsort(-lens, kind="stable")))       # stable length sort
+    for k in range(G):
+        q, j = divmod(k, 64)
+        g = order[k]
+        minority = genes[g] == (0 if flipped[g] else 1)
+        for s in range(S):
+            n_s = min(SEG, N - s * SEG)
+            n = np.arange(nhalf[s, q * 64] * 16)
+            at = start[s, q * 64] + ((n // 4) * 64 + j) * 4 + n % 4
+            vals = idx[at]
+            want = np.flatnonzero(minority[s * SEG:s * SEG + n_s]) * 8
+            ok = ok and len(want) <= len(vals) and np.array_equal(np.sort(vals[:len(want)]), want) \
+                and bool(np.all(vals[len(want):] == n_s * 8)) and (len(at) == 0 or at.max() < L.entries) \
+                and nhalf[s, k] == nhalf[s, q * 64]
+    return bool(ok), "seglists G=%d N=%d %s" % (G, N, dens)
 
 
 BIG_SHAPES = [(200000, 5000, 1, 512, "rare"), (30000, 10000, 50, 128, "uniform"),

@@ -487,9 +487,9 @@ def test_cli_cfg2_sized_table_every_row_vs_oracle(tmp_path):
 
 
 def test_cli_wide_table_takes_the_segmented_list_path(tmp_path, caplog):
-    """The command line on a table WIDER than one LDS label tile (41 000 isolates > 40 959;
-    round 3): the list-driven permutation path stays in charge -- two isolate segments,
-    k_permute_seglists -- instead of the dense fallback, and every output row (counts,
+    """The command line on a table WIDER than one LDS label tile (41 000 isolates > 20 479, and
+    past the 40 959 at which the dense kernels used to take over; round 3): the list-driven
+    permutation path stays in charge -- three isolate segments, k_permute_seglists -- and every output row (counts,
     Naive_p, Empirical_p) equals the oracle's.  Also the native reader on 41 014-column rows."""
     import logging
     from oracle import oracle as orc

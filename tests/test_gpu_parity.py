@@ -323,7 +323,7 @@ def test_headline_config_properties(eng, orc):
     (90, 5000, 2, 257), (40, 5119, 1, 100),          # 8-dword tile rows, tiles of 256
     (50, 5120, 1, 129), (120, 7000, 2, 200), (70, 10000, 1, 130), (33, 10239, 1, 64),   # 4-dword
     (40, 10240, 1, 65), (130, 12001, 2, 130), (70, 16000, 1, 200), (65, 20479, 1, 64),   # 2-dword, two words per lane
-    (40, 20480, 1, 33), (100, 30001, 2, 70), (65, 40959, 1, 32),                         # 1-dword, one word per lane
+    (40, 20480, 1, 33), (100, 30001, 2, 70), (65, 40959, 1, 32),     # 2-dword tiles in 2 / 2 / 3 isolate segments
 ])
 def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
     """The list-driven kernel (minority lists + bit-sliced counters) gives
@@ -352,11 +352,11 @@ def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
 
 @pytest.mark.parametrize("N,T,P", [(333, 2, 700), (2700, 2, 700), (6000, 2, 700), (64, 1, 64),
                                    (333, 4, 17000), (100, 3, 180000), (12001, 2, 130),
-                                   (20479, 1, 70), (30001, 2, 100), (40959, 1, 33)])
+                                   (20479, 1, 70)])
 def test_perm_tiles_are_the_transposed_row_labels(eng, N, T, P):
     """k_perm_generate_tiles writes the same spec-S4 labels as k_perm_generate,
-    isolate-major in tiles of 512 / 256 / 128 / 64 / 32 permutations, zero row + zero ragged
-    tail.  Few (trait, 64-permutation) wavefronts -> the workgroup variant with
+    isolate-major in tiles of 512 / 256 / 128 / 64 permutations, zero row + zero ragged
+    tail (the segmented tiles of N > 20479: test_segmented_list_path_vs_dense_and_oracle).  Few (trait, 64-permutation) wavefronts -> the workgroup variant with
     Philox producer wavefronts; 1024..8191 of them (last-but-one case) -> the
     four-wavefront workgroup; more (last case) -> one wavefront each."""
     rng = np.random.default_rng(2)
@@ -435,7 +435,7 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, null, null, p, p, 4, 1, 100, 10, p, 1, null) == -1
     assert lib.scoary_permute(h, p, p, p, 1, 70000, 10, 10, p, null) == -3          # T > 65535
     assert lib.scoary_perm_generate(h, p, p, 1, 10, 2**33, 0, 0, 1, p, null) == -3   # index >= 2^32
-    assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, p, null, p, p, 4, 1, 122497, 10, p, 1, null) == -3
+    assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, p, null, p, p, 4, 1, 131071, 10, p, 1, null) == -3
     assert b"LDS" in lib.scoary_last_error(h)
     assert lib.scoary_tree_pairs(h, p, 3, 40, p, p, 1, 1, 2, p, null) == -3          # stack_depth > 32
     assert lib.scoary_counts(null, p, p, p, 1, 1, 1, p, p, null) == -1
@@ -446,24 +446,24 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_list_params(5000, params) == 0 and list(params) == [8, 32, 32, 8, 8]
     assert lib.scoary_list_params(5120, params) == 0 and list(params) == [4, 16, 64, 16, 4]
     assert lib.scoary_list_params(10240, params) == 0 and list(params) == [2, 8, 64, 32, 4]
-    assert lib.scoary_list_params(20480, params) == 0 and list(params) == [1, 4, 64, 64, 4]
-    assert lib.scoary_list_params(40960, params) == 0 and list(params) == [1, 4, 64, 64, 4]   # 2 segments
-    assert lib.scoary_list_params(122497, params) == -3 and params[0] == 0
-    assert lib.scoary_list_max_isolates() == 122496 == 3 * 40832
-    assert [lib.scoary_list_segments(n) for n in (1, 40959, 40960, 81664, 81665, 122496, 122497)] == \
-        [1, 1, 2, 2, 3, 3, 0]
+    assert lib.scoary_list_params(20480, params) == 0 and list(params) == [2, 8, 64, 32, 4]   # 2 segments
+    assert lib.scoary_list_params(131071, params) == -3 and params[0] == 0
+    assert lib.scoary_list_max_isolates() == 131070
+    assert [lib.scoary_list_segments(n) for n in (1, 20479, 20480, 40704, 40705, 122112, 122113, 131070, 131071)] \
+        == [1, 1, 2, 2, 3, 6, 7, 7, 0]
 
 
 # ------------------------------------------- spec S6: device list builder -----
 @pytest.mark.parametrize("G,N", [(1, 1), (5, 31), (203, 333), (1000, 500), (3000, 2000), (700, 2559),
                                  (900, 2560), (650, 5000), (300, 5120), (257, 10000), (130, 10240),
-                                 (100, 20479), (70, 20480), (40, 40959)])
+                                 (100, 20479)])
 def test_device_list_builder_equals_host_builder(eng, G, N):
     """scoary_lists_plan + scoary_lists_fill (device, product path) write the same
     arrays -- order, start, ngroups, flipped and every index entry -- as the host
     builder scoary_lists_build (the checker; an independent implementation of spec
-    S6), for all five tile widths, ties in the length sort, empty and full genes and
-    a ragged last wave group."""
+    S6), for all four tile widths, ties in the length sort, empty and full genes and
+    a ragged last wave group (the segmented lists of N > 20479 are checked position by position
+    in test_segmented_list_path_vs_dense_and_oracle)."""
     from scoary_amd import io_native
     from scoary_amd.engine import pack_bits_rows
     rng = np.random.default_rng(G * 31 + N)
@@ -770,18 +770,17 @@ def test_fisher_symmetric_margins_and_large_n(eng, orc):
 
 
 def test_more_isolates_than_the_list_kernel_takes(eng, orc, caplog):
-    """N > 122 496 (more than three 40 832-isolate segments: the list counts would need a
-    17th counter plane): the list builder refuses, associate() and the command line's
+    """N > 131 070 (the list counts would need a 17th counter plane): the list builder refuses, associate() and the command line's
     _associate fall back to the dense kernels -- and say so in the log (VERDICT round 2,
     item 8) -- with results equal to the oracle's.  No BASELINE config is this wide."""
     import logging
     from scoary_amd import methods as M
     from scoary_amd.engine import pack_bits_rows
     rng = np.random.default_rng(50)
-    G, N, T, P = 100, 122_497, 2, 40
+    G, N, T, P = 100, 131_071, 2, 40
     genes, traits = _random_case(rng, G, N, T)
     assert not eng.lists_supported(N) and eng.lists_supported(N - 1)
-    assert eng.lib.scoary_list_segments(N) == 0 and eng.lib.scoary_list_segments(N - 1) == 3
+    assert eng.lib.scoary_list_segments(N) == 0 and eng.lib.scoary_list_segments(N - 1) == 7
     gm = eng.pack_dense(genes)
     with pytest.raises(ValueError):
         eng.build_lists(gm)
@@ -800,41 +799,41 @@ def test_more_isolates_than_the_list_kernel_takes(eng, orc, caplog):
     assert np.array_equal(out["r"], orc.permute_r(gb, tb, mb, N, P, 77).T)
 
 
-@pytest.mark.parametrize("G,N,T,P", [(150, 40_960, 2, 70), (333, 50_000, 2, 33), (70, 90_001, 1, 100),
-                                     (64, 122_496, 1, 32)])
+@pytest.mark.parametrize("G,N,T,P", [(150, 20_480, 2, 70), (333, 50_000, 2, 133), (70, 90_001, 1, 100),
+                                     (64, 131_070, 1, 64)])
 def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
-    """40 959 < N <= 122 496 (round 3; the dense kernels took over here before): the isolates
-    are cut into 2 or 3 segments of 40 832, a block loads its 32-permutation tile one segment
-    at a time, every gene has one sub-list per segment and the counter planes live across the
-    reloads (k_permute_seglists).  Checked: (1) the label tiles hold the rows of
-    k_perm_generate, every segment with its own zero row; (2) every sub-list holds exactly the
-    gene's minority positions of that segment, as LDS addresses, zero-row padded; (3) r is
-    bit-identical to the dense kernels' and to the oracle's."""
+    """20 479 < N <= 131 070 (round 3; one-dword tiles up to 40 959 and the dense kernels beyond
+    it before): the isolates are cut into 2 ... 7 segments of 20 352, a block loads its
+    64-permutation tile one segment at a time, every gene has one sub-list per segment and the
+    counter planes live across the reloads (k_permute_seglists).  Checked: (1) the label tiles
+    hold the rows of k_perm_generate, every segment with its own zero row; (2) every sub-list
+    holds exactly the gene's minority positions of that segment, as LDS addresses, zero-row
+    padded; (3) r is bit-identical to the dense kernels' and to the oracle's."""
     rng = np.random.default_rng(G + N)
     genes, traits = _random_case(rng, G, N, T)
     genes[5] = (rng.random(N) < 0.0005)                   # sub-lists that are empty in a segment
-    genes[6, :40_832] = 0
+    genes[6, :20_352] = 0
     tb, mb = _bits(eng, traits)
     gm = eng.pack_dense(genes)
     trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
     S = int(eng.lib.scoary_list_segments(N))
-    SEG, STRIDE = 40_832, 40_836
-    assert S == -(-N // SEG) and eng.list_params(N) == (1, 4, 64, 64, 4)
-    # (1) tiles
+    SEG, STRIDE = 20_352, 40_708
+    assert S == -(-N // SEG) and eng.list_params(N) == (2, 8, 64, 32, 4)
+    # (1) tiles: [T][tiles][S][STRIDE dwords], row r of segment s = dwords 2r, 2r + 1
     _, margins = eng.counts(gm, trv, mkv)
     rows = eng.perm_generate(mkv, margins, N, P, 3, 17).cpu().numpy().view(np.uint32)
     tiles = eng.perm_generate_tiles(mkv, margins, N, P, 3, 17).cpu().numpy().view(np.uint32)
-    ntiles = -(-P // 32)
+    ntiles = -(-P // 64)
     assert int(eng.lib.scoary_list_tile_words(N)) == S * STRIDE
     tiles = tiles.reshape(T, ntiles, S, STRIDE)
     bits = np.unpackbits(rows.view(np.uint8).reshape(T, P, -1), axis=2, bitorder="little")[:, :, :N]
     for s in range(S):
         n_s = min(SEG, N - s * SEG)
-        tb_ = np.unpackbits(np.ascontiguousarray(tiles[:, :, s, :n_s + 1]).view(np.uint8)
-                            .reshape(T, ntiles, n_s + 1, 4), axis=3, bitorder="little")
+        tb_ = np.unpackbits(np.ascontiguousarray(tiles[:, :, s, :2 * (n_s + 1)]).view(np.uint8)
+                            .reshape(T, ntiles, n_s + 1, 8), axis=3, bitorder="little")
         assert not tb_[:, :, n_s].any()                   # the segment's zero row
         for tile in range(ntiles):
-            lo, hi = tile * 32, min(P, tile * 32 + 32)
+            lo, hi = tile * 64, min(P, tile * 64 + 64)
             assert np.array_equal(tb_[:, tile, :n_s, :hi - lo],
                                   bits[:, lo:hi, s * SEG:s * SEG + n_s].transpose(0, 2, 1))
             assert not tb_[:, tile, :n_s, hi - lo:].any()
@@ -848,7 +847,6 @@ def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
     assert np.array_equal(flipped.astype(bool), 2 * ones > N)
     lens = np.minimum(ones, N - ones)
     assert np.array_equal(np.sort(order), np.arange(G)) and np.all(np.diff(lens[order]) <= 0)
-    total = 0
     for k in range(G):
         q, j = divmod(k, 64)
         g = order[k]
@@ -858,12 +856,11 @@ def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
             n = np.arange(nhalf[s, q * 64] * 16)
             at = start[s, q * 64] + ((n // 4) * 64 + j) * 4 + n % 4
             vals = idx[at]
-            want = np.flatnonzero(minority[s * SEG:s * SEG + n_s]) * 4
+            want = np.flatnonzero(minority[s * SEG:s * SEG + n_s]) * 8
             assert np.array_equal(np.sort(vals[:len(want)]), want)
-            assert np.all(vals[len(want):] == n_s * 4)
+            assert np.all(vals[len(want):] == n_s * 8)
             assert nhalf[s, k] == nhalf[s, q * 64] and start[s, k] == start[s, q * 64]
-        total = max(total, int(at.max()) + 1 if len(at) else total)
-    assert L.entries >= total
+            assert len(at) == 0 or at.max() < L.entries
     # (3) r
     dense = eng.associate(gm, trv, mkv, permutations=P, seed=9, use_lists=False)
     res = eng.associate(gm, trv, mkv, permutations=P, seed=9, use_lists=True)

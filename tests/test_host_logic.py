@@ -629,11 +629,11 @@ def test_build_refuses_a_list_kernel_that_spills_or_grew_static_lds():
         one = _REMARKS % vals
         seg = (_REMARKS % dict(vals, **(seg_kw or {}))).replace("15k_permute_listsILi4ELi4ELi11E",
                                                               "18k_permute_seglistsILi16E")
-        return ge.parse_resource_usage("".join(one.replace("Li11E", "Li%dE" % (11 + i)) for i in range(5)) + seg)
+        return ge.parse_resource_usage("".join(one.replace("Li11E", "Li%dE" % (11 + i)) for i in range(4)) + seg)
 
     seg_kw = None
     ok = report()
-    assert len(ok) == 6 and all(v["VGPRs"] == 127 and v["ScratchSize"] == 0 for v in ok.values())
+    assert len(ok) == 5 and all(v["VGPRs"] == 127 and v["ScratchSize"] == 0 for v in ok.values())
     ge.check_kernel_resources(ok)
     for bad in (dict(scratch=16), dict(spill=3), dict(vgprs=130), dict(lds=64)):
         with pytest.raises(RuntimeError):
@@ -643,7 +643,7 @@ def test_build_refuses_a_list_kernel_that_spills_or_grew_static_lds():
             ge.check_kernel_resources(report())
     seg_kw = None
     with pytest.raises(RuntimeError):                     # an instance went missing
-        ge.check_kernel_resources({k: v for k, v in list(ok.items())[:4] + list(ok.items())[5:]})
+        ge.check_kernel_resources({k: v for k, v in list(ok.items())[:3] + list(ok.items())[4:]})
     with pytest.raises(RuntimeError):                     # the segmented kernel went missing
         ge.check_kernel_resources({k: v for k, v in ok.items() if "seglists" not in k})
     ge.check_ctr_banks()                                  # the committed register table is consistent
