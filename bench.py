@@ -426,7 +426,7 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms, ad
         "operand_bw_frac": operand_bytes / sec / 1e9 / HBM_PEAK_GBS,
         "operand_bytes_per_launch": operand_bytes,
         "clock_note": "the list kernel runs at the socket power cap: 1.31-1.38 kW, shader clock 2.14-2.22 "
-                      "of 2.4 GHz (profiles/r02_clock_power.txt)" if use_lists else None,
+                      "of 2.4 GHz (profiles/r02_clock_power.txt, profiles/r03_clock_power.txt)" if use_lists else None,
     }
     return out
 
