@@ -654,13 +654,15 @@ def test_pack_records_kernel_equals_the_host_side_packing(eng):
     assert torch.equal(none, sd.pack_records(res["counts"], res["p"], res["odds"], None))
 
 
-def test_list_path_in_batches_equals_one_shot_and_oracle(eng, orc, monkeypatch):
+@pytest.mark.parametrize("G,N,T,P", [(500, 600, 2, 1700), (90, 21_000, 2, 1100)],
+                         ids=["one-tile", "segmented-tiles"])
+def test_list_path_in_batches_equals_one_shot_and_oracle(eng, orc, monkeypatch, G, N, T, P):
     """The list-driven path with the permutations split into batches of label tiles (what a
     cfg5-size run does to bound the tile and per-tile-count buffers): r accumulates over the
-    batches, permutation indices stay global -- identical to the one-batch run and the oracle;
-    list_batch keeps the 16-bit count scratch of a cfg5 shard under 4 GB."""
+    batches, permutation indices stay global -- identical to the one-batch run and the oracle,
+    also through the segmented kernel of N > 20479; list_batch keeps the 16-bit count scratch
+    of a cfg5 shard under 4 GB."""
     rng = np.random.default_rng(41)
-    G, N, T, P = 500, 600, 2, 1700
     genes, traits = _random_case(rng, G, N, T)
     tb, mb = _bits(eng, traits)
     gm = eng.pack_dense(genes)
