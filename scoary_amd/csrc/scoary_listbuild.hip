@@ -219,18 +219,13 @@ __global__ __launch_bounds__(256) void k_lists_fill(const uint4* __restrict__ ti
   const int g = live ? order[k] : 0;
   const int total = live ? len[g] : 0;
   const uint32_t inv = (live && flipped[g]) ? 0xffffffffu : 0u;
+  static_assert(C <= 32, "a class is a set of bits of every 32-bit word");
   uint32_t cmask = 0u;                       // bits of a 32-bit word that belong to class c
-  if constexpr (C <= 32) {
-    for (int b = c; b < 32; b += C) cmask |= 1u << b;
-  } else {
-    cmask = 1u << (c & 31);                  // C == 64: words of parity c >> 5 only
-  }
+  for (int b = c; b < 32; b += C) cmask |= 1u << b;
   auto class_bits = [&](uint32_t word, int w) -> uint32_t {
     const int first = 32 * w;
     uint32_t bits = word ^ inv;
     if (first + 32 > N) bits &= first < N ? ((1u << (N - first)) - 1u) : 0u;
-    if constexpr (C == 64)
-      if ((w & 1) != (c >> 5)) return 0u;
     return bits & cmask;
   };
   auto at = [&](int n) -> int64_t {          // interleaved position of entry n of this slot
