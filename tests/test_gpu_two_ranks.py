@@ -22,10 +22,10 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(extra):
+def _bench(extra, ranks=2):
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--share-gpu",
                           "--backend", "gloo", "--config", "cfg2", "--steps", "4", "--warmup", "1",
                           "--verify-gather"] + extra,
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -63,6 +63,17 @@ def _free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def test_bench_three_ranks_uneven_strong_shards():
+    """Three ranks, strong scaling: 10 000 genes do not divide by three (3334 / 3333 / 3333), so
+    the gather pads the shorter shards to the longest and rank 0 trims them again; every
+    record still equals the single-rank run's."""
+    d = _bench(["--scaling", "strong"], ranks=3)
+    assert d["n_gpus"] == 3 and d["rccl_ranks"] == 3 and d["gather_matches_single_rank"] is True
+    assert d["config"]["genes_total"] == 10_000
+    assert [r["genes"] for r in d["per_rank"]] == [3334, 3333, 3333]
+    assert [r["exchange_bytes"] for r in d["per_rank"]] == [3334 * 40, 3333 * 40, 3333 * 40]
 
 
 @pytest.mark.parametrize("extra", [["--no_pairwise", "-e", "200", "--seed", "7"], ["--collapse", "-c", "I", "-p", "0.05"]],
