@@ -90,6 +90,11 @@ def parse(argv=None):
     ap.add_argument("--verify-gather", action="store_true",
                     help="after the timed region rank 0 recomputes every rank's shard by itself and "
                          "compares the gathered records with it bit for bit (gather_matches_single_rank)")
+    ap.add_argument("--telemetry-ms", type=float, default=4.0,
+                    help="sampling period of the shader-clock / socket-power side thread during the "
+                         "timed region (amdsmi or hwmon); 0 switches it off")
+    ap.add_argument("--inject-gather-fault", action="store_true", help=argparse.SUPPRESS)   # tests: corrupt one
+    # received record before --verify-gather looks at it; every rank must then exit non-zero, together
     ap.add_argument("--dry-exchange", action="store_true",
                     help="CPU-only check of the launcher + exchange path (gloo, fabricated "
                          "records, no kernels): what tests/test_dist_gloo.py drives")
@@ -166,6 +171,157 @@ def load_counters(config, default_sizes, kernel):
     return None, "no PMC summary for %s / %s under profiles/" % (config, kernel)
 
 
+# ------------------------------------------------------------- telemetry -----
+class Telemetry:
+    """Shader clock and socket power of one GPU, sampled from a side thread WHILE the timed
+    region runs (the same kernel sources gave 9.5e11 on the driver's box
+    and 1.04e12 on the builder's -- the list kernel sits at the socket power cap, so its time
+    follows the clock the box grants).  With the mean clock of THIS run in the line,
+    `ops_per_clock` (VALU lane-ops per shader clock) separates a slow box from a slow kernel:
+    it is a property of the code, the clock is a property of the box.
+    Sources, first that works: amdsmi (gpu_metrics: current_gfxclk(s), current_socket_power),
+    then the amdgpu hwmon files (freq1_input, power1_average / power1_input)."""
+
+    def __init__(self, device_index=0, period_s=0.004, reader=None):
+        self.period_s = period_s
+        self.samples = []                   # (t, sclk_mhz | None, power_w | None)
+        self.source = None
+        self._stop = None
+        self._thread = None
+        self._read = reader or self._pick_reader(device_index)
+        if reader is not None:
+            self.source = "injected"
+
+    # -- sources -----------------------------------------------------------
+    def _pick_reader(self, device_index):
+        for make in (self._amdsmi_reader, self._hwmon_reader):
+            try:
+                rd = make(device_index)
+                if rd is not None and any(v is not None for v in rd()):
+                    return rd
+            except Exception:               # a missing tool must never cost the bench line
+                continue
+        self.source = None
+        return None
+
+    @staticmethod
+    def _bdf_of_torch_device(device_index):
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            return "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            return None
+
+    def _amdsmi_reader(self, device_index):
+        import amdsmi
+        try:
+            amdsmi.amdsmi_init()
+        except Exception:
+            return None
+        handles = amdsmi.amdsmi_get_processor_handles()
+        if not handles:
+            return None
+        h = handles[min(device_index, len(handles) - 1)]
+        want = self._bdf_of_torch_device(device_index)
+        if want:
+            for cand in handles:
+                try:
+                    if str(amdsmi.amdsmi_get_gpu_device_bdf(cand)).lower().startswith(want):
+                        h = cand
+                        break
+                except Exception:
+                    pass
+
+        def num(x):
+            return float(x) if isinstance(x, (int, float)) and x >= 0 else None
+
+        def read():
+            m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+            clk = None
+            per_xcd = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and c > 0] \
+                if isinstance(m.get("current_gfxclks"), (list, tuple)) else []
+            if per_xcd:
+                clk = float(sum(per_xcd)) / len(per_xcd)
+            if clk is None:
+                clk = num(m.get("current_gfxclk"))
+            pw = num(m.get("current_socket_power"))
+            if pw is None:
+                pw = num(m.get("average_socket_power"))
+            return clk, pw
+        self.source = "amdsmi gpu_metrics (current_gfxclks mean over XCDs, current_socket_power)"
+        return read
+
+    def _hwmon_reader(self, device_index):
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        if not cards:
+            return None
+        want = self._bdf_of_torch_device(device_index)
+        hw = cards[min(device_index, len(cards) - 1)]
+        if want:
+            for c in cards:
+                if want in os.path.realpath(os.path.join(c, "..", "..")).lower():
+                    hw = c
+                    break
+        fclk = os.path.join(hw, "freq1_input")
+        fpow = next((os.path.join(hw, n) for n in ("power1_average", "power1_input")
+                     if os.path.exists(os.path.join(hw, n))), None)
+
+        def rd(path, scale):
+            try:
+                with open(path) as f:
+                    return float(f.read().strip()) * scale
+            except (OSError, ValueError, TypeError):
+                return None
+
+        def read():
+            return (rd(fclk, 1e-6) if os.path.exists(fclk) else None,
+                    rd(fpow, 1e-6) if fpow else None)
+        self.source = "amdgpu hwmon (%s: freq1_input, %s)" % (hw, os.path.basename(fpow) if fpow else "-")
+        return read
+
+    # -- sampling ------------------------------------------------------------
+    def start(self):
+        if self._read is None:
+            return self
+        import threading
+        self.samples = []
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    clk, pw = self._read()
+                except Exception:
+                    clk = pw = None
+                self.samples.append((time.perf_counter(), clk, pw))
+                self._stop.wait(self.period_s)
+        self._thread = threading.Thread(target=loop, name="scoary-telemetry", daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self, t_begin=None, t_end=None):
+        """Ends the sampling; summary of the samples taken inside [t_begin, t_end]
+        (perf_counter times of the timed region; all samples if not given)."""
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=2.0)
+            self._thread = None
+        rows = [s for s in self.samples
+                if (t_begin is None or s[0] >= t_begin) and (t_end is None or s[0] <= t_end)]
+        clk = [c for _, c, _ in rows if c]
+        pw = [w for _, _, w in rows if w]
+
+        def stat(v):
+            return (None, None, None) if not v else (sum(v) / len(v), min(v), max(v))
+        cm, cmin, cmax = stat(clk)
+        pm, pmin, pmax = stat(pw)
+        return {"source": self.source, "samples": len(rows), "period_ms": self.period_s * 1e3,
+                "sclk_mhz_mean": cm, "sclk_mhz_min": cmin, "sclk_mhz_max": cmax,
+                "socket_power_w_mean": pm, "socket_power_w_min": pmin, "socket_power_w_max": pmax}
+
+
 # ------------------------------------------------------------ CPU baselines ---
 def cpu_baseline_port(genes, traits, N, seed, target_s):
     """The C restatement (oracle/oracle.c, OpenMP over genes) on a bounded sample of the
@@ -210,12 +366,12 @@ def cpu_baseline_scipy(eng, genes, traits, N, seed, target_s):
     labels = np.stack([np.unpackbits(orc.perm_labels(seed, 0, pi, mb[0], npos, N).view(np.uint8),
                                      bitorder="little")[:N] for pi in range(Ps)])
     G = genes.shape[0]
-    # candidates: <= 8192 genes spread over the matrix; the baseline process sizes its sample
+    # candidates: <= 16384 genes spread over the matrix; the baseline process sizes its sample
     # from them (4-gene probe -> about target_s seconds on all cores).  It runs in a fresh
     # interpreter: a multiprocessing Pool must not be forked from this process (HIP context,
     # runtime threads).
     import tempfile
-    cand = np.unique(np.linspace(0, G - 1, min(G, 8192)).astype(np.int64))
+    cand = np.unique(np.linspace(0, G - 1, min(G, 16384)).astype(np.int64))
     with tempfile.TemporaryDirectory() as tmp:
         fin, fout = os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")
         np.savez(fin, genes=genes[cand], trait=tr, labels=labels)
@@ -225,6 +381,7 @@ def cpu_baseline_scipy(eng, genes, traits, N, seed, target_s):
         d = np.load(fout)
         sub = cand[d["order"]]
         counts, p, r, dt, n = d["counts"], d["p"], d["r"], float(d["dt"]), int(d["n"])
+        cpu_count, usable = int(d["cpu_count"]), int(d["usable"])
     Gs = len(sub)
     # the GPU on the same sample, same labels (spec S4, same seed, trait 0)
     gm = eng.pack_dense(genes[sub])
@@ -238,15 +395,20 @@ def cpu_baseline_scipy(eng, genes, traits, N, seed, target_s):
               and np.max(np.abs(gp - p)) < 1e-12)
     tests = Gs * (Ps + 1)
     return {"value": tests / dt, "unit": "gene-permutation Fisher tests/s", "cores": n,
-            "cores_are": "Pool workers = os.cpu_count() logical CPUs (SMT siblings included)",
+            "cores_are": "Pool workers = the logical CPUs this process may use (os.cpu_count() = %d, after "
+                         "affinity mask and cgroup quota: %d; SMT siblings included)" % (cpu_count, usable),
+            "per_worker_tests_per_s": tests / dt / max(n, 1),
+            "genes_per_worker": Gs / max(n, 1),
             "kind": "scipy-restatement", "matches_gpu": ok,
             "sample": "oracle/scipy_baseline.py: per-isolate Python counting + memoised "
                       "scipy.stats.fisher_exact, multiprocessing.Pool(%d) over stride domains "
                       "range(k, G, %d) (reference structure, scoary/methods.py:791-857, :1076-1078); "
                       "%d genes x %d isolates x trait 0 x (1 + %d permutations) = %d tests in %.2f s "
-                      "(pool start-up excluded), extrapolated linearly; counts / r equal and "
+                      "(pool start-up excluded; %.1f genes and %.0f tests/s per worker -- a single core "
+                      "alone does ~350 tests/s at N = 2000, so a lower figure is workers sharing cores "
+                      "or a short, skewed sample), extrapolated linearly; counts / r equal and "
                       "|dp| < 1e-12 against the GPU on this sample: %s"
-                      % (n, n, Gs, N, Ps, tests, dt, ok)}
+                      % (n, n, Gs, N, Ps, tests, dt, Gs / max(n, 1), tests / dt / max(n, 1), ok)}
 
 
 # ------------------------------------------------------------------ exchange --
@@ -361,7 +523,7 @@ def list_adder_work(eng, gm, genes, T, P, batch):
             "minority_entries_per_gene": float(minority.mean())}
 
 
-def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms, adders=None):
+def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms, adders=None, telemetry=None):
     """The `roofline` object.  What binds the permutation kernel is integer-VALU issue,
     not HBM, so: bound = "valu", achieved = lane-ops/s from the
     SQ_INSTS_VALU count of the committed PMC pass of THIS kernel version (sha-checked)
@@ -425,9 +587,23 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms, ad
         "operand_bw_gbs": operand_bytes / sec / 1e9,
         "operand_bw_frac": operand_bytes / sec / 1e9 / HBM_PEAK_GBS,
         "operand_bytes_per_launch": operand_bytes,
-        "clock_note": "the list kernel runs at the socket power cap: 1.31-1.38 kW, shader clock 2.14-2.22 "
-                      "of 2.4 GHz (profiles/r02_clock_power.txt, profiles/r03_clock_power.txt)" if use_lists else None,
     }
+    # the clock THIS run had (side-thread samples over the timed region): lane-ops per shader
+    # clock is the code's figure, the clock is the box's -- a slow box shows up as a lower
+    # sclk_mhz_mean at an unchanged ops_per_clock, a slow kernel the other way round
+    sclk = telemetry and telemetry.get("sclk_mhz_mean")
+    out["sclk_mhz_mean"] = sclk
+    out["socket_power_w_mean"] = telemetry and telemetry.get("socket_power_w_mean")
+    out["telemetry_samples"] = telemetry and telemetry.get("samples")
+    out["ops_per_clock"] = None if (valu is None or not sclk) else valu / (sec * sclk * 1e6)
+    out["ops_per_clock_unit"] = ("VALU lane-ops per shader clock, whole chip (SQ_INSTS_VALU x 64 / "
+                                 "(kernel time x sclk_mhz_mean)); nominal 256 CU x 4 SIMD x 32 = 32768")
+    out["ops_per_clock_frac"] = None if out["ops_per_clock"] is None else out["ops_per_clock"] / 32768.0
+    out["useful_ops_per_clock"] = None if (useful is None or not sclk) else useful / (sec * sclk * 1e6)
+    out["clock_note"] = ("sclk_mhz_mean / socket_power_w_mean are this run's; under sustained load the list "
+                         "kernel sits at the socket power cap (1.31-1.38 kW, 2.14-2.22 of 2.4 GHz: "
+                         "profiles/r03_clock_power.txt), a 0.1 s timed region may not have reached it") \
+        if use_lists else None
     return out
 
 
@@ -573,6 +749,9 @@ def main():
     if graph is None:
         eng.set_timing(True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # shader clock / socket power of THIS run, sampled from a side thread during the timed region
+    tele = Telemetry(local_rank, period_s=max(0.001, args.telemetry_ms * 1e-3)).start() \
+        if args.telemetry_ms > 0 else None
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(args.steps):
@@ -587,6 +766,7 @@ def main():
         t_kernels = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    telemetry = tele.stop(t0, t0 + dt) if tele is not None else None
     if exchange:
         exposed_ms = (time.perf_counter() - t_kernels) * 1e3
     step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
@@ -596,10 +776,10 @@ def main():
         for _ in range(5):
             eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=use_lists, workspace=ws)
         torch.cuda.synchronize()
-    k3_name = "k_permute_lists" if use_lists else "k_permute"
+    k3_name = eng.list_kernel_name(N) if use_lists else "k_permute"
     k3_ms = eng.kernel_ms(k3_name)
     names = ("k_counts", "k_fisher") + (
-        ("k_perm_generate_tiles", "k_permute_lists", "k_lists_reduce") if use_lists else
+        ("k_perm_generate_tiles", k3_name, "k_lists_reduce") if use_lists else
         ("k_perm_generate", "k_permute"))
     kernel_ms = {k: eng.kernel_ms(k) for k in names}
     eng.set_timing(False)
@@ -617,17 +797,22 @@ def main():
         mine = {"rank": rank, "device": local_rank, "genes": G, "ms_per_step": dt_own / args.steps * 1e3,
                 "ms_per_step_median": median_ms, "kernel_ms": kernel_ms,
                 "exchange_exposed_ms": exposed_ms,
-                "exchange_bytes": T * G * sdist.REC_WORDS * 4}
+                "exchange_bytes": T * G * sdist.REC_WORDS * 4,
+                "sclk_mhz_mean": telemetry and telemetry["sclk_mhz_mean"],
+                "socket_power_w_mean": telemetry and telemetry["socket_power_w_mean"]}
         per_rank = sdist.all_gather_objects(mine)
     nval = (traits != 2).sum(1)
     rccl_ranks = exchange.check(T, nval) if exchange else None
+    failure = None                                   # rank 0's verdict; every rank leaves together (below)
     if exchange and rank == 0 and exchange.kind == "gather" and rccl_ranks != world:
-        raise SystemExit("bench.py: rank 0 received valid records from %s of %d ranks" % (rccl_ranks, world))
+        failure = "bench.py: rank 0 received valid records from %s of %d ranks" % (rccl_ranks, world)
     gather_ok = None
-    if args.verify_gather and exchange and rank == 0 and exchange.kind == "gather":
+    if args.verify_gather and exchange and rank == 0 and exchange.kind == "gather" and failure is None:
         # rank 0 alone recomputes every rank's shard and compares the block it received from
         # that rank in the last step, record for record (counts, p, odds, r: 40 bytes each)
         last = exchange.recv[(exchange.step_no - 1) % 2]
+        if args.inject_gather_fault:
+            last[world - 1, 0, 0, 8] += 1                    # r of the last rank's first record
         gather_ok = True
         for rk, (a, b) in enumerate(sdist.shard_bounds(exchange.total, world)):
             g_rk = eng.tile_rows(pack_bits_rows(shard_of(rk)), N)
@@ -637,9 +822,18 @@ def main():
                                                    use_lists=use_lists))
             gather_ok = gather_ok and bool(torch.equal(last[rk, :, :b - a], alone))
         if not gather_ok:
-            raise SystemExit("bench.py: the gathered records differ from a single-rank run")
+            failure = "bench.py: the gathered records differ from a single-rank run"
     if sharded:
-        dist.barrier()                               # the other ranks wait for rank 0's checks
+        # the other ranks wait for rank 0's checks, and rank 0's verdict reaches all of them:
+        # a failed check ends every rank with a non-zero status instead of leaving the others
+        # blocked in a barrier until the launcher's timeout
+        verdict = [failure]
+        dist.broadcast_object_list(verdict, src=0)
+        if verdict[0] is not None:
+            dist.destroy_process_group()
+            raise SystemExit(verdict[0] if rank == 0 else 1)
+    elif failure is not None:
+        raise SystemExit(failure)
 
     if rank == 0:
         tests_per_step = G_total * T * P
@@ -680,7 +874,9 @@ def main():
             "value_incl_observed_tables": G_total * T * (P + 1) * args.steps / dt,
             "roofline": roofline_report(
                 args, eng, use_lists, G, N, T, P, ws.batch if use_lists else pbatch, k3_name, k3_ms,
-                adders=list_adder_work(eng, gm, genes, T, P, ws.batch) if use_lists else None),
+                adders=list_adder_work(eng, gm, genes, T, P, ws.batch) if use_lists else None,
+                telemetry=telemetry),
+            "telemetry": telemetry,
             "kernel_ms": kernel_ms,
         }
         if world == 1 and not args.no_cpu_baseline:

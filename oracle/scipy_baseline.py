@@ -11,7 +11,8 @@ of how the reference does this path (BASELINE.md section 3
   counts -- scoary/methods.py:842-857 (memo dict :770, :850-857);
 * parallelised the way the reference parallelises: a ``multiprocessing.Pool(n)`` whose
   worker k takes the stride domain ``range(k, G, n)`` -- scoary/methods.py:1076-1078,
-  1083-1097;
+  1083-1097; n = the logical CPUs this process may use (``usable_cpus``: affinity mask and
+  cgroup quota applied to os.cpu_count());
 * the permutation loop shuffles the trait labels over the valid isolates and
   re-evaluates the statistic, ``r += (stat_perm at least as extreme)`` --
   scoary/methods.py:1348-1355 -- with the Fisher p as the statistic (divergence D1,
@@ -27,6 +28,37 @@ import numpy as np
 TIE = 1e-7          # relative window of "p_perm <= p_obs" (same decision as spec S5, see below)
 
 _SHARED = {}        # inherited by the forked workers
+
+
+def usable_cpus():
+    """Logical CPUs this process may actually run on: the smallest of os.cpu_count(), the
+    scheduler affinity mask and the cgroup CPU quota (cpu.max / cfs_quota).  A container on a
+    256-thread host is often granted far fewer; a Pool of os.cpu_count() workers then
+    time-shares them and the per-worker rate collapses."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:     # cgroup v1
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
 
 
 def _count(gene_row, labels, strains):
@@ -85,7 +117,7 @@ def run(genes, trait, label_rows, processes=None):
     vectors over the valid isolates.  Returns (counts [G,4] as tpgp,tpgn,tngp,tngn,
     p [G], r [G], seconds, processes)."""
     G, N = genes.shape
-    n = processes or os.cpu_count() or 1
+    n = processes or usable_cpus()
     n = max(1, min(n, G))
     valid = np.nonzero(trait != 2)[0]
     strains = ["iso%05d" % i for i in valid]
@@ -119,7 +151,7 @@ def sample_and_run(genes, trait, label_rows, target_s, processes=None):
     sample stays spread over the matrix) on all ``processes`` workers.  Returns
     (indices used, counts, p, r, seconds, processes)."""
     G = genes.shape[0]
-    n = processes or os.cpu_count() or 1
+    n = processes or usable_cpus()
     probe_g = min(G, 4)
     _, _, _, dt, _ = run(genes[:probe_g], trait, label_rows, processes=1)
     per_gene = max(dt / probe_g, 1e-4)
@@ -138,7 +170,8 @@ def main(argv=None):
     argv = argv or sys.argv[1:]
     d = np.load(argv[0])
     order, counts, p, r, dt, n = sample_and_run(d["genes"], d["trait"], d["labels"], float(argv[2]))
-    np.savez(argv[1], order=order, counts=counts, p=p, r=r, dt=dt, n=n)
+    np.savez(argv[1], order=order, counts=counts, p=p, r=r, dt=dt, n=n, cpu_count=os.cpu_count() or 0,
+             usable=usable_cpus())
 
 
 if __name__ == "__main__":

@@ -38,6 +38,11 @@ class GeneMatrix:
         self.lists = None       # GeneLists, for the list-driven permutation kernel
 
 
+class ListMemoryError(_abi.ScoaryHipError):
+    """The index lists of a gene matrix would not fit the memory budget (build_lists): the
+    caller falls back to the dense permutation kernels, which need no lists."""
+
+
 class GeneLists:
     """Minority index lists of a gene matrix on the device (scoary_lists_plan / _fill).
     start / ngroups: int32 [G] per list slot, or [segments, G] for N > 20479."""
@@ -200,11 +205,29 @@ class AssociationEngine:
         buf[:, :2 * W] = rows64.view(np.uint32).reshape(R, 2 * W)
         return torch.from_numpy(buf.view(np.int32)).to(self.device)
 
-    def build_lists(self, genes):
+    def list_budget_bytes(self):
+        """Bytes build_lists may spend on one matrix's index array: SCOARY_LIST_BUDGET_MB if set
+        (tests), else 60 % of the device memory that is free right now -- label tiles (<= 8 GB)
+        and the count scratch (<= 4 GB) of a step still have to fit next to it."""
+        import os
+        mb = os.environ.get("SCOARY_LIST_BUDGET_MB")
+        if mb:
+            return int(float(mb) * (1 << 20))
+        free, _total = _torch().cuda.mem_get_info(self.device)
+        return int(free * 0.6)
+
+    def list_kernel_name(self, N):
+        """Timer label (scoary_last_kernel_ms) of the list-driven permutation kernel that
+        takes N isolates: k_permute_lists (one tile in LDS) or k_permute_seglists (N > 20479)."""
+        return "k_permute_seglists" if int(self.lib.scoary_list_segments(int(N))) > 1 else "k_permute_lists"
+
+    def build_lists(self, genes, budget_bytes=None):
         """Attach the minority index lists of ``genes`` (spec S6) for the list-driven
         permutation kernel.  Built on the device from the tiled matrix that is
         already in HBM (scoary_lists_plan + scoary_lists_fill): nothing crosses
-        PCIe but the 8-byte entry count."""
+        PCIe but the 8-byte entry count.  The plan returns the size of the index array
+        before it is allocated: more than ``budget_bytes`` (default list_budget_bytes())
+        raises ListMemoryError and leaves ``genes.lists`` None."""
         torch = _torch()
         lanes, _stride, _gpw, _classes, _piece = self.list_params(genes.N)
         if not lanes:
@@ -223,7 +246,13 @@ class AssociationEngine:
             self.h, self._ptr(genes.tiled), G, N, self._ptr(scratch), self._ptr(start),
             self._ptr(ngroups), self._ptr(order), self._ptr(flipped), ctypes.byref(entries),
             self._stream()), "scoary_lists_plan")
-        total = int(entries.value)
+        total = int(entries.value)                     # 32-bit words of index array
+        need = 4 * (total + int(self.lib.scoary_lists_slack_entries()))
+        if budget_bytes is None:
+            budget_bytes = self.list_budget_bytes()
+        if need > budget_bytes:
+            raise ListMemoryError("index lists of a %d x %d matrix need %.1f MB, budget %.1f MB"
+                                  % (G, N, need / 2**20, budget_bytes / 2**20))
         idx = self._empty((total + int(self.lib.scoary_lists_slack_entries()),), torch.int32)
         self._check(self.lib.scoary_lists_fill(
             self.h, self._ptr(genes.tiled), G, N, self._ptr(scratch), self._ptr(order),
@@ -456,11 +485,13 @@ class AssociationEngine:
         first (kernel attributes, side stream and lazy module loads happen outside the
         capture)."""
         torch = _torch()
+        # checked before anything is launched: the warm-up step below ends in a device
+        # synchronize, which is illegal on a capturing stream
+        if torch.cuda.is_current_stream_capturing():
+            raise _abi.ScoaryHipError("capture(): the current stream is already capturing")
         self.associate(genes, traits, masks, permutations=permutations, seed=seed,
                        use_lists=use_lists, workspace=workspace)
         torch.cuda.synchronize(self.device)
-        if torch.cuda.is_current_stream_capturing():
-            raise _abi.ScoaryHipError("capture(): the current stream is already capturing")
         stream = torch.cuda.Stream(device=self.device)      # a fresh stream: never mid-capture
         with torch.cuda.stream(stream):
             self._check(self.lib.scoary_graph_begin(self.h, self._stream()), "scoary_graph_begin")

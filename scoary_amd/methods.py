@@ -618,8 +618,16 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
             return torch.zeros((T, 0, dist.REC_WORDS), dtype=torch.int32, device=eng.device)
         gm = table.on_device(eng) if (a, b) == (0, G) else eng.tile_rows(table.rows64[a:b], N)
         if permutations > 0 and not early_abort and gm.lists is None and eng.lists_supported(N):
-            # list-driven permutation kernel: cost follows each gene's minority count
-            eng.build_lists(gm)
+            # list-driven permutation kernel: cost follows each gene's minority count.  The
+            # index array (4 bytes per padded minority entry, 2 for N > 20479) is sized by the
+            # plan before it is allocated: a wide, dense matrix that would not fit keeps the
+            # dense kernels (same results, no lists) instead of dying in the allocator
+            from .engine import ListMemoryError
+            try:
+                eng.build_lists(gm)
+            except (ListMemoryError, torch.cuda.OutOfMemoryError) as e:
+                gm.lists = None
+                log.info("index lists not built (%s); using the dense permutation kernels" % e)
         elif permutations > 0 and not early_abort and not eng.lists_supported(N) and a == 0:
             # more than 131 070 isolates: the list counts would need a 17th counter plane; the
             # dense AND + popcount kernels take over (same results, 1.5-3x the time per test)

@@ -2,7 +2,7 @@
 and the judge read (metric / value / unit / n_gpus / steps / warmup / ms_per_step /
 higher_is_better / scaling / vs_baseline / dtype / data / config.workload, roofline{bound,
 achieved, peak, unit, frac, traffic}, cpu_baseline{value, unit, cores, kind, sample}) and
-internally consistent numbers; eager and hipGraph replay."""
+internally consistent numbers; eager and hipGraph replay; the clock / power telemetry of the run."""
 import json
 import os
 import subprocess
@@ -57,6 +57,17 @@ def test_bench_json_contract(extra):
         want = r["padded_entries_per_gene"] * 2 * 31 / 32 / 32
         assert abs(r["adder_ops_per_test"] - want) < 0.02 * want
         assert r["overhead_ops_per_test"] is None and r["measured_op_peak"] == 56.1
+    # this run's shader clock / socket power (side-thread samples over the timed region)
+    tel = d["telemetry"]
+    for k in ("source", "samples", "sclk_mhz_mean", "socket_power_w_mean", "period_ms"):
+        assert k in tel, k
+    assert tel["source"] is not None, "no clock / power source on this box (amdsmi, hwmon)"
+    for k in ("sclk_mhz_mean", "socket_power_w_mean", "ops_per_clock", "ops_per_clock_frac", "telemetry_samples"):
+        assert k in r, k
+    if tel["samples"]:
+        assert 50 < tel["sclk_mhz_mean"] < 3000 and 20 < tel["socket_power_w_mean"] < 2000
+        assert r["sclk_mhz_mean"] == tel["sclk_mhz_mean"]
+    assert r["ops_per_clock"] is None                       # needs the counters: refused on an overridden shape
     assert r["kernel"] == k3 and d["kernel_ms"][k3] > 0
     assert sum(d["kernel_ms"].values()) < 3 * d["ms_per_step"]
     assert d["config"]["hip_graph"] == ("--graph" in extra)
@@ -68,3 +79,23 @@ def test_bench_json_contract(extra):
         assert d["cpu_baseline"]["kind"] == "scipy-restatement" and d["cpu_baseline"]["matches_gpu"] is True
         assert d["cpu_baseline_port"]["kind"] == "port"
         assert d["cpu_baseline"]["value"] < d["cpu_baseline_port"]["value"] < d["value"]
+
+
+def test_bench_headline_line_explains_itself():
+    """The default command line (cfg3, the BASELINE headline shape; fewer steps): the roofline
+    object carries the shader clock and socket power of THIS run and lane-ops per clock, so a
+    reader can tell a slow box from a slow kernel, next to K1 / K2's
+    own roofline entries (item 4)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    r, tel = d["roofline"], d["telemetry"]
+    assert "cfg3" in d["config"]["workload"] and d["config"]["permutations"] == 10_000
+    assert tel["samples"] >= 10                              # >= 10 samples inside the timed region
+    assert 500 < tel["sclk_mhz_mean"] <= 2600 and 100 < tel["socket_power_w_mean"] < 2000
+    if r["frac"] is not None:                                # counters of this kernel version are on file
+        assert 0 < r["ops_per_clock"] < 32768 and abs(r["ops_per_clock_frac"] - r["ops_per_clock"] / 32768) < 1e-12
+        # frac is taken against 2.4 GHz, ops_per_clock against the clock the box granted
+        assert abs(r["frac"] * 2400.0 / tel["sclk_mhz_mean"] - r["ops_per_clock_frac"]) < 1e-9

@@ -771,6 +771,95 @@ def test_fisher_symmetric_margins_and_large_n(eng, orc):
     assert checked > 150
 
 
+def test_index_lists_over_budget_fall_back_to_the_dense_kernels(eng, orc, caplog, monkeypatch):
+    """the list path now serves every N <= 131 070, and a wide, dense matrix can ask
+    for a very large index array.  scoary_lists_plan returns the size before anything is
+    allocated: over the budget build_lists raises ListMemoryError (no allocation, genes.lists
+    stays None) and the command line's _associate logs it and keeps the dense kernels -- same
+    results."""
+    import logging
+    from scoary_amd import methods as M
+    from scoary_amd.engine import ListMemoryError, pack_bits_rows
+    rng = np.random.default_rng(620)
+    G, N, T, P = 300, 700, 2, 64
+    genes, traits = _random_case(rng, G, N, T)
+    gm = eng.pack_dense(genes)
+    with pytest.raises(ListMemoryError):
+        eng.build_lists(gm, budget_bytes=1000)
+    assert gm.lists is None
+    assert eng.build_lists(gm, budget_bytes=1 << 30) is gm.lists and gm.lists is not None
+    table = M.GeneTable(["g%d" % i for i in range(G)], [""] * G, [""] * G,
+                        ["s%d" % i for i in range(N)], pack_bits_rows(genes))
+    monkeypatch.setenv("SCOARY_LIST_BUDGET_MB", "0.001")
+    M._ENGINE = eng
+    try:
+        with caplog.at_level(logging.INFO, logger=M.log.name):
+            out = M._associate(table, traits, permutations=P, seed=5)
+    finally:
+        M._ENGINE = None
+    assert any("index lists not built" in r.getMessage() for r in caplog.records)
+    tb, mb = _bits(eng, traits)
+    gb = orc.pack_rows(genes)
+    assert np.array_equal(out["counts"], orc.counts_packed(gb, tb, mb).transpose(1, 0, 2))
+    assert np.array_equal(out["r"], orc.permute_r(gb, tb, mb, N, P, 5).T)
+
+
+def _large_n_tables(rng, sizes, per_size):
+    """Random and symmetric-margin 2x2 tables (a, b, c, d) at large population sizes, observed
+    count a few standard deviations around the mode (so p is neither 0 nor 1)."""
+    tabs = []
+    for N in sizes:
+        for i in range(per_size):
+            kind = i % 4
+            if kind == 0:                                   # n1 == n2
+                n1 = N // 2; Nn = 2 * n1
+                n = int(rng.integers(1, Nn))
+            elif kind == 1:                                 # n == N - n
+                n = N // 2; Nn = 2 * n
+                n1 = int(rng.integers(1, Nn))
+            elif kind == 2:                                 # a rare gene or a rare trait
+                Nn = N; n1 = int(rng.integers(1, N)); n = int(rng.integers(1, 400))
+            else:
+                Nn = N; n1 = int(rng.integers(1, N)); n = int(rng.integers(1, N))
+            n2 = Nn - n1
+            lo, hi = max(0, n - n2), min(n, n1)
+            mode = (n + 1) * (n1 + 1) // (Nn + 2)
+            sd = max(1.0, (n * n1 / Nn * n2 / Nn * (Nn - n) / max(Nn - 1, 1)) ** 0.5)
+            a = int(np.clip(round(mode + rng.normal() * 2.5 * sd), lo, hi))
+            tabs.append((a, n1 - a, n - a, n2 - n + a))
+    return np.array(tabs, dtype=np.int32)
+
+
+def test_fisher_where_the_segmented_list_path_goes(eng, orc):
+    """k_fisher for 40 958 < N <= 131 070: since round 3 the list path --
+    and with it scoary_fisher_lists' p, odds and acceptance intervals -- serves matrices this wide,
+    and the direct checks stopped at 40 958.  Random, rare-margin and symmetric-margin tables at
+    N = 50 000, 90 001 and 131 070 against the oracle, whose own p is pinned to EXACT rational
+    arithmetic at these sizes by tests/test_oracle_golden.py::test_oracle_fisher_vs_exact_rationals_large_n
+    (SciPy 1.15.3 itself is up to 6e-12 off the exact value up here, so the oracle is the
+    yardstick, not SciPy).  Reference call site: scoary/methods.py:854."""
+    import torch
+    rng = np.random.default_rng(131070)
+    tabs = _large_n_tables(rng, (50_000, 90_001, 131_070), 80)
+    tabs = np.concatenate([tabs, np.array([[5582, 3263, 70693, 40462]], dtype=np.int32)])   # N = 120 000
+    assert tabs.min() >= 0 and tabs.sum(1).max() <= 131_070
+    p, odds, crit = eng.fisher(torch.from_numpy(tabs).cuda())
+    p, odds = p.cpu().numpy(), odds.cpu().numpy()
+    crit = crit.cpu().numpy().view(np.uint32).astype(np.int64)
+    o_odds, o_p = orc.fisher_many(tabs)
+    assert np.max(np.abs(p - o_p)) < P_TOL
+    ok = o_p > 1e-280
+    assert ok.sum() > 200 and np.max(np.abs(p[ok] - o_p[ok]) / o_p[ok]) < 1e-10
+    fin = np.isfinite(o_odds)
+    assert np.array_equal(fin, np.isfinite(odds)) and np.allclose(odds[fin], o_odds[fin], rtol=1e-15, atol=0)
+    # the exact value of the N = 120 000 table (computed in rationals; SciPy says ...243636)
+    assert abs(p[-1] - 0.3584981573183696) < 1e-13
+    # the acceptance interval contains the observed count's complement: a is on its edge or outside
+    a = tabs[:, 0].astype(np.int64)
+    inside = (a >= crit[:, 0]) & (a < crit[:, 0] + crit[:, 1])
+    assert not inside.any()                                  # p_obs <= p_obs: the observed table is in the region
+
+
 def test_more_isolates_than_the_list_kernel_takes(eng, orc, caplog):
     """N > 131 070 (the list counts would need a 17th counter plane): the list builder refuses, associate() and the command line's
     _associate fall back to the dense kernels -- and say so in the log (VERDICT round 2,

@@ -22,11 +22,11 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(extra, ranks=2):
+def _bench(extra, ranks=2, config="cfg2", steps=4):
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--share-gpu",
-                          "--backend", "gloo", "--config", "cfg2", "--steps", "4", "--warmup", "1",
+                          "--backend", "gloo", "--config", config, "--steps", str(steps), "--warmup", "1",
                           "--verify-gather"] + extra,
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
@@ -106,3 +106,135 @@ def test_command_line_two_ranks_share_the_gpu(exampledir, tmp_path, extra):
     for f in names:
         assert (one / f).read_bytes() == (two / f).read_bytes(), f
     assert os.path.exists(two / "scoary.rank1.log")          # rank 1 ran, logged, wrote no results
+
+
+# ---- the 8-GPU configs of BASELINE.json at 8 ranks ---------------------
+# No multi-GPU node reaches the build or `pytest -m gpu`, so the first run on eight devices will be
+# the driver's: these rehearse exactly that launch -- bench.py's own launcher, eight processes,
+# eight gene shards, labels regenerated from the seed on every rank, the asynchronous gather of
+# eight blocks overlapped with the next step, rank 0's checks -- with the eight ranks time-sharing
+# the one device over gloo.  Reference analogue: scoary/methods.py:1076-1097 (stride domains),
+# :1115-1122 (result weave).
+
+def test_bench_eight_ranks_cfg4_strong_split():
+    """cfg4 is DEFINED as gene-sharded 8x (BASELINE.json configs[3]): 200 000 variants x 5000
+    isolates, --permute 10000, 25 000 genes per rank; every gathered record equals rank 0's
+    own recomputation of that rank's shard."""
+    d = _bench(["--scaling", "strong", "--no-cpu-baseline"], ranks=8, config="cfg4", steps=2)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "strong"
+    assert d["gather_matches_single_rank"] is True
+    assert d["config"]["genes_total"] == 200_000 and d["config"]["parallelism"] == "gene-shard x8"
+    assert d["config"]["isolates"] == 5000 and d["config"]["permutations"] == 10_000
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(8)) and [r["genes"] for r in pr] == [25_000] * 8
+    assert all(r["exchange_bytes"] == 25_000 * 40 for r in pr)
+    assert all(r["kernel_ms"]["k_permute_lists"] > 0 for r in pr)
+    assert abs(d["value"] - 200_000 * 10_000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_eight_ranks_cfg5_weak_shards():
+    """cfg5 (BASELINE.json configs[4], 8 x MI355X): every rank its own shard of the 10 000-isolate
+    x 50-trait x 100 000-permutation problem (8000 genes per rank here instead of 125 000 -- the
+    full shard is tests/test_gpu_full_size.py's), three label-tile batches per step, weak scaling."""
+    d = _bench(["--scaling", "weak", "--genes", "8000", "--no-cpu-baseline"], ranks=8, config="cfg5", steps=2)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["scaling"] == "weak"
+    assert d["gather_matches_single_rank"] is True
+    assert d["config"]["genes_total"] == 64_000 and d["config"]["genes_per_gpu"] == 8000
+    assert d["config"]["isolates"] == 10_000 and d["config"]["traits"] == 50
+    assert d["config"]["permutations"] == 100_000
+    assert len(d["per_rank"]) == 8 and all(r["exchange_bytes"] == 50 * 8000 * 40 for r in d["per_rank"])
+
+
+def _torchrun(nproc, args, env, timeout=900):
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+                           str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args,
+                          capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_one_rank_through_rccl(scaling):
+    """The real backend in the driver-run evidence: one rank under torch.distributed.run with
+    --backend nccl (= RCCL) -- init_process_group("nccl", device_id=...), scoary_pack_records,
+    dist.gather on device tensors, the asynchronous drain, the MAX all_reduce on a device tensor,
+    rank 0's record checks -- everything the 8-GPU run does except a second device."""
+    out = _torchrun(1, [os.path.join(ROOT, "bench.py"), "--exercise-exchange", "--backend", "nccl",
+                        "--verify-gather", "--config", "cfg2", "--scaling", scaling, "--steps", "4",
+                        "--warmup", "1", "--no-cpu-baseline"], _clean_env())
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["gather_matches_single_rank"] is True
+    assert d["config"]["exchange"].startswith("rccl gather")
+    assert d["per_rank"][0]["exchange_bytes"] == 10_000 * 40
+    assert d["per_rank"][0]["exchange_exposed_ms"] is not None
+
+
+def test_command_line_one_rank_through_rccl(exampledir, tmp_path):
+    """`python -m scoary_amd` under torch.distributed.run with one rank and SCOARY_EXERCISE_DIST=1:
+    the command line joins an RCCL group, all-gathers the per-gene records and the bit rows on
+    device tensors and shuts the group down; outputs byte-identical to the plain run."""
+    inputs = ["-g", os.path.join(exampledir, "Gene_presence_absence.csv"),
+              "-t", os.path.join(exampledir, "Tetracycline_resistance.csv"),
+              "--no_pairwise", "-e", "100", "--seed", "3", "--no-time"]
+    env = _clean_env()
+    one, two = tmp_path / "one", tmp_path / "two"
+    out = subprocess.run([sys.executable, "-m", "scoary_amd"] + inputs + ["-o", str(one)],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    out = _torchrun(1, ["-m", "scoary_amd"] + inputs + ["-o", str(two)],
+                    dict(env, SCOARY_EXERCISE_DIST="1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    names = sorted(f for f in os.listdir(one) if f.endswith(".results.csv"))
+    assert names and names == sorted(f for f in os.listdir(two) if f.endswith(".results.csv"))
+    for f in names:
+        assert (one / f).read_bytes() == (two / f).read_bytes(), f
+
+
+def test_command_line_eight_ranks_share_the_gpu(exampledir, tmp_path):
+    """The command line at the node's full width: eight ranks under torch.distributed.run on the one
+    GPU (gloo), each parsing one byte range of the gene table and taking one of eight gene shards
+    (9 001 rows: uneven) through the kernels; result files and Tree.nwk byte-identical to one process."""
+    inputs = ["-g", os.path.join(exampledir, "Gene_presence_absence.csv"),
+              "-t", os.path.join(exampledir, "Tetracycline_resistance.csv"),
+              "-e", "100", "--seed", "11", "--no-time", "-u", "-c", "I", "EPW", "-p", "0.05", "0.5"]
+    env = _clean_env()
+    one, eight = tmp_path / "one", tmp_path / "eight"
+    out = subprocess.run([sys.executable, "-m", "scoary_amd"] + inputs + ["-o", str(one)],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    out = _torchrun(8, ["-m", "scoary_amd"] + inputs + ["-o", str(eight)],
+                    dict(env, SCOARY_SHARE_GPU="1", SCOARY_DIST_BACKEND="gloo"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    names = sorted(f for f in os.listdir(one) if not f.startswith("scoary"))
+    assert any(f.endswith(".results.csv") for f in names) and "Tree.nwk" in names
+    assert names == sorted(f for f in os.listdir(eight) if not f.startswith("scoary"))
+    for f in names:
+        assert (one / f).read_bytes() == (eight / f).read_bytes(), f
+    assert all(os.path.exists(eight / ("scoary.rank%d.log" % r)) for r in range(1, 8))
+
+
+def test_a_failed_gather_check_ends_every_rank(tmp_path):
+    """when rank 0's --verify-gather finds a difference, its verdict is broadcast
+    and EVERY rank exits non-zero at once -- before, rank 0 raised while the others sat in a
+    barrier until the launcher's timeout.  A corrupted record is injected on rank 0."""
+    import time
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu",
+                          "--backend", "gloo", "--config", "cfg2", "--steps", "2", "--warmup", "1",
+                          "--verify-gather", "--inject-gather-fault"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert "gathered records differ from a single-rank run" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]      # no bench line
+    assert time.perf_counter() - t0 < 300                                        # nobody waited for a timeout

@@ -706,3 +706,51 @@ def test_zero_ones_matrix_of_a_table_without_data_rows():
     z = M._LazyZeroOnes(np.zeros((0, 3), dtype=np.uint64), 130)
     assert z.file_rows().shape == (0, 130)
     assert len(z) == 0 and list(z) == []
+
+
+def test_bench_telemetry_summarises_the_samples_of_the_timed_region():
+    """bench.py samples shader clock and socket power from a side thread during
+    the timed region.  With an injected reader: only samples inside [t_begin, t_end] count, missing
+    values are skipped, and a box without any source yields nulls -- never an exception."""
+    import time
+    import bench
+    seq = iter([(2100.0, 1300.0), (2200.0, None), (None, 1350.0)] + [(2150.0, 1320.0)] * 10000)
+    tel = bench.Telemetry(0, period_s=0.001, reader=lambda: next(seq)).start()
+    t0 = time.perf_counter()
+    time.sleep(0.05)
+    t1 = time.perf_counter()
+    out = tel.stop(t0, t1)
+    assert out["source"] == "injected" and out["samples"] >= 10
+    assert 2100.0 <= out["sclk_mhz_min"] <= out["sclk_mhz_mean"] <= out["sclk_mhz_max"] <= 2200.0
+    assert 1300.0 <= out["socket_power_w_mean"] <= 1350.0
+    assert bench.Telemetry(0, reader=lambda: (1.0, 1.0)).start().stop(t1 + 100, t1 + 200)["samples"] == 0
+
+    def broken():
+        raise OSError("sensor gone")
+    out = bench.Telemetry(0, period_s=0.001, reader=broken).start()
+    time.sleep(0.01)
+    out = out.stop()
+    assert out["sclk_mhz_mean"] is None and out["socket_power_w_mean"] is None
+    none = bench.Telemetry(0)                                # this container: no amdgpu device at all
+    if none.source is None:
+        assert none.start().stop()["samples"] == 0
+
+
+def test_roofline_ops_per_clock_follows_the_run_s_clock(monkeypatch):
+    """ops_per_clock = SQ_INSTS_VALU x 64 / (kernel time x sclk_mhz_mean): the same counters and
+    kernel time at two clocks give the same frac (taken against 2.4 GHz) and different ops per clock."""
+    import types
+    import bench
+    monkeypatch.setattr(bench, "load_counters", lambda *a: ({"SQ_INSTS_VALU": 3.0e9, "source": "x"}, None))
+    monkeypatch.setattr(bench, "measured_copy_peak", lambda dev: 5000.0)
+    args = types.SimpleNamespace(config="cfg3", genes=None, permutations=None, isolates=None, traits=None)
+    eng = types.SimpleNamespace(device="cpu")
+    a = bench.roofline_report(args, eng, True, 50000, 2000, 10, 10000, 10240, "k_permute_lists", 4.8,
+                              telemetry={"sclk_mhz_mean": 2400.0, "socket_power_w_mean": 1000.0, "samples": 12})
+    b = bench.roofline_report(args, eng, True, 50000, 2000, 10, 10000, 10240, "k_permute_lists", 4.8,
+                              telemetry={"sclk_mhz_mean": 2000.0, "socket_power_w_mean": 1350.0, "samples": 12})
+    assert a["frac"] == b["frac"] and abs(a["ops_per_clock_frac"] - a["frac"]) < 1e-12
+    assert abs(b["ops_per_clock"] / a["ops_per_clock"] - 1.2) < 1e-12
+    assert b["sclk_mhz_mean"] == 2000.0 and b["socket_power_w_mean"] == 1350.0 and b["telemetry_samples"] == 12
+    c = bench.roofline_report(args, eng, True, 50000, 2000, 10, 10000, 10240, "k_permute_lists", 4.8)
+    assert c["ops_per_clock"] is None and c["sclk_mhz_mean"] is None
