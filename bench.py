@@ -69,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--permutations", type=int, default=None, help="override P")
     ap.add_argument("--isolates", type=int, default=None, help="override N (shape experiments)")
     ap.add_argument("--traits", type=int, default=None, help="override T (shape experiments)")
+    ap.add_argument("--gene-kind", default=None, choices=["uniform", "rare", "ushaped"],
+                    help="gene-frequency spectrum instead of the config's own (evidence lines next to the "
+                         "BASELINE configs: ushaped = Beta(0.15, 0.15), a pan-genome-like spectrum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="run the RCCL exchange step even at world size 1 (launched under "
@@ -76,8 +79,11 @@ def parse(argv=None):
     ap.add_argument("--kernel", default="auto", choices=["auto", "dense", "lists"],
                     help="permutation kernel: dense (k_permute_reg/chunked) or list-driven")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the step into a hipGraph and replay it (launch-bound configs); "
-                         "per-kernel times then come from extra eager steps after the timed region")
+                    help="capture the step into a hipGraph and replay it; per-kernel times then come from "
+                         "extra eager steps after the timed region.  Launch-bound workloads (fewer than 5e8 "
+                         "tests per step: cfg2) do this by default, as the engine itself does "
+                         "(AssociationEngine.auto_graph_eligible)")
+    ap.add_argument("--no-graph", action="store_true", help="never replay a hipGraph (eager launches)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0,
                     help="target wall time of each cpu_baseline sample")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -536,8 +542,8 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms, ad
     launches_per_step = -(-P // pbatch)                # label tiles / label rows come in batches
     tests_per_launch = G * T * P / launches_per_step   # average over the launches of a step
     operand_bytes = 16.0 * W64 * tests_per_launch        # 16*W bytes / test
-    default_sizes = (args.genes is None and args.permutations is None
-                     and args.isolates is None and args.traits is None)
+    default_sizes = (args.genes is None and args.permutations is None and args.isolates is None
+                     and args.traits is None and getattr(args, "gene_kind", None) is None)
     ctr, why = load_counters(args.config, default_sizes, k3_name)
     sec = k3_ms * 1e-3
     valu = traffic = None
@@ -604,6 +610,54 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms, ad
                          "kernel sits at the socket power cap (1.31-1.38 kW, 2.14-2.22 of 2.4 GHz: "
                          "profiles/r03_clock_power.txt), a 0.1 s timed region may not have reached it") \
         if use_lists else None
+    return out
+
+
+def small_kernel_rooflines(args, G, N, T, n_mask_classes, kernel_ms):
+    """`roofline_k1` / `roofline_k2`: K1 (k_counts) is the path's genuine HBM
+    stream -- SURVEY 8d's B1 = 8 W G + 16 W T + 16 G T bytes, each gene word read once -- with an
+    integer-VALU floor next to it (2 ops, AND + popcount-accumulate, per 32 isolates and (gene,
+    vector); vectors = T label rows + one validity row per mask class); whichever floor is
+    higher is its bound.  K2 (k_fisher) moves B2 = 32 G T bytes and is bound by its fp64
+    divide chains (trip count = half the support of every table), so it is reported as a rate.
+    Counter traffic comes from the committed PMC summary when it matches these sources."""
+    W64 = (N + 63) // 64
+    default_sizes = (args.genes is None and args.permutations is None and args.isolates is None
+                     and args.traits is None and getattr(args, "gene_kind", None) is None)
+    out = {}
+    t1 = kernel_ms.get("k_counts")
+    if t1:
+        sec = t1 * 1e-3
+        b1 = 8.0 * W64 * G + 16.0 * W64 * T + 16.0 * G * T
+        vectors = T + n_mask_classes
+        ops = 2.0 * ((N + 31) // 32) * G * vectors                     # lane-ops
+        ctr, _why = load_counters(args.config, default_sizes, "k_counts")
+        traffic = ctr.get("hbm_traffic_bytes_per_launch") if ctr else None
+        hbm_floor, valu_floor = b1 / (HBM_PEAK_GBS * 1e9), ops / VALU_PEAK_AND_BCNT
+        out["roofline_k1"] = {
+            "kernel": "k_counts", "bound": "hbm" if hbm_floor >= valu_floor else "valu",
+            "bytes": b1, "bytes_formula": "8*W*G + 16*W*T + 16*G*T (SURVEY 8d B1), W = ceil(N/64)",
+            "kernel_ms": t1, "gbs": b1 / sec / 1e9, "hbm_frac": b1 / sec / 1e9 / HBM_PEAK_GBS,
+            "passes_over_matrix": -(-T // 32), "vectors": vectors, "mask_classes_over_passes": n_mask_classes,
+            "valu_lane_ops": ops, "valu_frac": ops / sec / VALU_NOMINAL_LANE_OPS,
+            "valu_frac_of_measured_and_bcnt_peak": ops / sec / VALU_PEAK_AND_BCNT,
+            "hbm_floor_ms": hbm_floor * 1e3, "valu_floor_ms": valu_floor * 1e3,
+            "frac_of_bound": max(hbm_floor, valu_floor) / sec,
+            "traffic": traffic, "traffic_over_bytes": None if not traffic else traffic / b1,
+            "counters_source": ctr["source"] if ctr else None}
+    t2 = kernel_ms.get("k_fisher")
+    if t2:
+        sec = t2 * 1e-3
+        b2 = 32.0 * G * T
+        ctr, _why = load_counters(args.config, default_sizes, "k_fisher")
+        out["roofline_k2"] = {
+            "kernel": "k_fisher", "bound": "fp64 valu latency (divide chains, trip count = half the support)",
+            "tables": G * T, "tables_per_s": G * T / sec, "kernel_ms": t2,
+            "bytes": b2, "bytes_formula": "32*G*T (SURVEY 8d B2)", "gbs": b2 / sec / 1e9,
+            "hbm_frac": b2 / sec / 1e9 / HBM_PEAK_GBS,
+            "valu_insts_per_table": None if not ctr else ctr["SQ_INSTS_VALU"] * 64.0 / (G * T),
+            "overlapped": "runs on the main stream under the label-tile generator (side stream)",
+            "counters_source": ctr["source"] if ctr else None}
     return out
 
 
@@ -677,7 +731,8 @@ def main():
     c = synth.CONFIGS[args.config]
     G_cfg = args.genes or (c["G"] // 8 if args.config == "cfg5" else c["G"])   # cfg5: the per-GPU shard
     bounds = sdist.shard_bounds(G_cfg, world) if (args.scaling == "strong" and world > 1) else None
-    base_genes, traits, P, seed = synth.make_config(args.config, G=G_cfg, N=args.isolates, T=args.traits)
+    base_genes, traits, P, seed = synth.make_config(args.config, G=G_cfg, N=args.isolates, T=args.traits,
+                                                    gene_kind=args.gene_kind)
 
     def shard_of(rk):
         """The gene rows rank rk works on.  strong: the config's genes, split -- every rank
@@ -690,7 +745,7 @@ def main():
             return base_genes
         rng = np.random.default_rng(seed + 1000 * rk)
         return synth.make_genes(base_genes.shape[0], base_genes.shape[1], rng,
-                                kind="rare" if args.config == "cfg4" else "uniform",
+                                kind=args.gene_kind or ("rare" if args.config == "cfg4" else "uniform"),
                                 core_frac=0.05 if args.config in ("cfg3", "cfg5") else 0.0)
     genes = shard_of(rank)
     if args.permutations:
@@ -708,23 +763,28 @@ def main():
     def setup():
         gm_ = eng.tile_rows(rows64, N)             # H2D of the packed bits + device tiling
         trv_, mkv_ = eng.vecrows(tbits, N), eng.vecrows(mbits, N)
+        plan_ = eng.trait_plan(trv_, mkv_, N)      # trait margins + mask classes: once per trait set
         ul = args.kernel == "lists" or (args.kernel == "auto" and LISTS_DEFAULT
                                         and eng.lists_supported(N))
         if ul:
             eng.build_lists(gm_)                   # on the device, from the tiled matrix
         torch.cuda.synchronize()
-        return gm_, trv_, mkv_, ul
+        return gm_, trv_, mkv_, ul, plan_
     setup()                                        # first call pays module loads; time the second
     t0 = time.perf_counter()
-    gm, trv, mkv, use_lists = setup()
+    gm, trv, mkv, use_lists, plan = setup()
     setup_ms = (time.perf_counter() - t0) * 1e3
 
     pbatch = eng.perm_batch(T, N, P)
     ws = eng.workspace(gm, T, P, use_lists=use_lists)
     exchange = Exchange(torch, eng, world, rank, T, G, bounds=bounds) if sharded else None
     graph = graph_res = None
-    if args.graph:
-        graph, graph_res = eng.capture(gm, trv, mkv, P, seed, ws, use_lists=use_lists)
+    auto_graph = (not args.graph and not args.no_graph and not sharded
+                  and eng.auto_graph_eligible(gm, T, P))
+    if args.graph or auto_graph:
+        # recorded here, outside the warm-up count: what engine.associate does by itself on the
+        # second call of a launch-bound step
+        graph, graph_res = eng.capture(gm, trv, mkv, P, seed, ws, use_lists=use_lists, plan=plan)
 
     def step():
         if graph is not None:
@@ -732,7 +792,7 @@ def main():
             res = graph_res
         else:
             res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=use_lists,
-                                workspace=ws)
+                                workspace=ws, plan=plan, graph=False)
         if exchange:
             exchange.submit(res)
         return res
@@ -774,7 +834,8 @@ def main():
     if graph is not None:                           # per-kernel times: a few eager steps afterwards
         eng.set_timing(True)
         for _ in range(5):
-            eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=use_lists, workspace=ws)
+            eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=use_lists, workspace=ws, plan=plan,
+                          graph=False)
         torch.cuda.synchronize()
     k3_name = eng.list_kernel_name(N) if use_lists else "k_permute"
     k3_ms = eng.kernel_ms(k3_name)
@@ -819,7 +880,7 @@ def main():
             if use_lists:
                 eng.build_lists(g_rk)
             alone = eng.pack_records(eng.associate(g_rk, trv, mkv, permutations=P, seed=seed,
-                                                   use_lists=use_lists))
+                                                   use_lists=use_lists, plan=plan))
             gather_ok = gather_ok and bool(torch.equal(last[rk, :, :b - a], alone))
         if not gather_ok:
             failure = "bench.py: the gathered records differ from a single-rank run"
@@ -851,13 +912,15 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 bit-words (bit-sliced adders / AND + popcount), f64 for Fisher p",
             "data": "synthetic",
-            "config": {"workload": "%s: %d genes x %d isolates x %d traits, --permute %d %s; "
+            "config": {"workload": "%s%s: %d genes x %d isolates x %d traits, --permute %d %s; "
                                    "counts + Fisher + label permutations + exceedance counts"
-                                   % (args.config, G_total if bounds is not None else G, N, T, P,
+                                   % (args.config, "" if not args.gene_kind else " shape, %s gene frequencies"
+                                      % args.gene_kind, G_total if bounds is not None else G, N, T, P,
                                       "in all (split across the GPUs)" if bounds is not None else "per GPU"),
+                       "gene_kind": args.gene_kind or "config",
                        "genes_per_gpu": G, "genes_total": G_total, "isolates": N, "traits": T,
                        "permutations": P, "parallelism": "gene-shard x%d" % world,
-                       "hip_graph": bool(graph),
+                       "hip_graph": bool(graph), "hip_graph_auto": bool(auto_graph),
                        "exchange": ("%s %s of per-gene records" % (
                            "rccl" if args.backend == "nccl" else "gloo (shared-GPU functional check)",
                            exchange.kind)) if exchange
@@ -866,7 +929,8 @@ def main():
             "gather_matches_single_rank": gather_ok,
             "per_rank": per_rank,
             # once per data set, outside the timed region: H2D of the packed bits + device tiling +
-            # device list build + trait vectors (host bit-packing and parsing excluded)
+            # device list build + trait vectors and their plan (margins, mask classes); host
+            # bit-packing and parsing excluded
             "setup_ms": setup_ms,
             "value_incl_setup": tests_per_step * args.steps / (dt + setup_ms * 1e-3),
             "value_single_step_incl_setup": tests_per_step / (dt / args.steps + setup_ms * 1e-3),
@@ -879,6 +943,10 @@ def main():
             "telemetry": telemetry,
             "kernel_ms": kernel_ms,
         }
+        cls = plan.mask_class.cpu().numpy()
+        tpp = int(eng.lib.scoary_counts_traits_per_pass(T))       # classes are counted once per PASS
+        out.update(small_kernel_rooflines(
+            args, G, N, T, sum(len(np.unique(cls[a:a + tpp])) for a in range(0, T, tpp)), kernel_ms))
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline_port(genes, traits, N, seed, args.cpu_seconds)
             try:

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SCOARY_ABI_VERSION 6
+#define SCOARY_ABI_VERSION 7
 
 /* error codes */
 #define SCOARY_OK 0
@@ -89,6 +89,30 @@ int scoary_counts(scoary_handle h, const uint32_t *d_tiled,
                   const uint32_t *d_traits, const uint32_t *d_masks, int64_t G,
                   int64_t T, int64_t N, int32_t *d_counts, int32_t *d_margins,
                   scoary_stream_t stream);
+/* The same in two parts (ABI 7), for callers that run more than one step per trait set: the
+ * trait PLAN -- everything the counts need that depends on the traits alone -- is built once
+ * (as the index lists are built once per gene matrix), and the per-step call is one kernel
+ * that streams the gene matrix once per pass of up to 32 traits.
+ *   scoary_trait_plan : d_margins int32 [T][2] = (npos, nval) per trait (the isolate loop of
+ *       scoary/methods.py:940-965 sees exactly the valid isolates: :591-598); d_mask_class
+ *       int32 [T] (may be NULL) = the smallest t' <= t whose validity row equals trait t's --
+ *       traits of one class share popc(gene & valid), counted once per class and pass (most
+ *       traits of a real file have no missing values: a single class); d_plan = an opaque
+ *       buffer of scoary_trait_plan_bytes(T, N) bytes: the classes as dense slots per pass and
+ *       the label / validity rows gathered quad-major, one contiguous operand row per gene
+ *       quad and pass (what k_counts reads with wide scalar loads).
+ *   scoary_counts_planned : d_counts as scoary_counts; d_plan / d_margins from
+ *       scoary_trait_plan of the same traits, masks, T and N.
+ * scoary_counts(...) == scoary_trait_plan into stream-ordered temporary memory +
+ * scoary_counts_planned. */
+int64_t scoary_counts_traits_per_pass(int64_t T);   /* traits one pass over the matrix takes (<= 32) */
+int64_t scoary_trait_plan_bytes(int64_t T, int64_t N);
+int scoary_trait_plan(scoary_handle h, const uint32_t *d_traits, const uint32_t *d_masks,
+                      int64_t T, int64_t N, int32_t *d_margins, int32_t *d_mask_class,
+                      void *d_plan, scoary_stream_t stream);
+int scoary_counts_planned(scoary_handle h, const uint32_t *d_tiled, const void *d_plan,
+                          const int32_t *d_margins, int64_t G, int64_t T, int64_t N,
+                          int32_t *d_counts, scoary_stream_t stream);
 
 /* ---- a5: scipy.stats.fisher_exact(obs_table) at scoary/methods.py:854 ---
  * Two-sided Fisher exact p and sample odds ratio for M 2x2 tables
@@ -223,12 +247,16 @@ int scoary_permute_lists(scoary_handle h, const uint32_t *d_tiles, const uint32_
  *       and group bases (prefix sum).  Writes d_order (int32 [G], per list slot),
  *       d_start / d_ngroups (int32 [scoary_list_segments(N)][G]: per segment and list
  *       slot -- plain [G] for N <= 20479) and d_flipped (uint8 [G], per gene); *entries_out (HOST)
- *       = total number of entries.  Synchronises `stream` (the caller needs the
+ *       = total number of 32-bit words of index array (= entries for N <= 20479).  Synchronises `stream` (the caller needs the
  *       count to allocate d_idx).
  *   scoary_lists_fill : d_idx = uint32 [entries + scoary_lists_slack_entries()],
  *       entry = position * row stride (the LDS byte offset of that isolate's label
- *       row), padding = N * row stride (the all-zero row).  Segmented lists (N > 20479):
- *       entry = (position - segment start) * 8, padding = the segment's own zero row.
+ *       row), padding = N * row stride (the all-zero row).  Segmented lists (N > 20479,
+ *       round 4): 16-BIT entries, two per word of d_idx -- entry = position - segment start
+ *       (the kernel scales it to the LDS address), padding = the segment's own zero row (=
+ *       the segment's row count); *entries_out then counts 32-bit WORDS of d_idx (half the
+ *       number of entries), eight entries per lane and 16-byte index vector, the entries of a
+ *       sub-list in grid-compaction order (scoary_listbuild.hip).
  *   d_scratch : scoary_lists_scratch_bytes(G, N) bytes, the SAME buffer in both calls
  *       (plan leaves the lengths and group bases in it). */
 int64_t scoary_lists_scratch_bytes(int64_t G, int64_t N);

@@ -66,61 +66,222 @@ __device__ __forceinline__ int popc4(const uint4 a) {
   return __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w);
 }
 
-// Lane = gene; blockIdx.y = group of TB traits.  Gene quads stream once per
-// trait group (coalesced 16 B / lane); trait and mask quads are wave-uniform
-// (scalar loads).  The trait margins (positives, valid isolates) are popcounts of the
-// same wave-uniform words, so every block counts them on the scalar unit as it goes
-// and block x = 0 publishes them (a separate k_margins launch before round 2: one
-// launch less on the critical path of launch-bound workloads).
-template <int TB>
-__global__ __launch_bounds__(256) void k_counts(const uint4* __restrict__ tiled,
-                                                const uint32_t* __restrict__ traits,
-                                                const uint32_t* __restrict__ masks,
-                                                int32_t* __restrict__ margins, int G,
-                                                int Gp, int Qp, int T, int4* __restrict__ counts) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  const int t0 = blockIdx.y * TB;
-  const int Wp = Qp * 4;
-  int a[TB], m[TB], npos_[TB], nval_[TB];
-  const uint4* trow[TB];
-  const uint4* mrow[TB];
-#pragma unroll
-  for (int j = 0; j < TB; ++j) {
-    a[j] = 0;
-    m[j] = 0;
-    npos_[j] = nval_[j] = 0;
-    const int t = min(t0 + j, T - 1);
-    trow[j] = reinterpret_cast<const uint4*>(traits + (int64_t)t * Wp);
-    mrow[j] = reinterpret_cast<const uint4*>(masks + (int64_t)t * Wp);
+// Trait plan: everything the counts need that depends on the traits alone -- built once per trait
+// set (like the index lists once per gene matrix), not once per step.
+//   margins[t] = (positives, valid isolates) = popcounts of the label / validity rows;
+//   cls[t]     = the smallest t' <= t whose validity row equals trait t's: traits of one class
+//                share popc(gene & valid), which k_counts computes once per class and pass (most
+//                traits of a real file have no missing values at all: one class);
+//   per pass of TB traits (counts_traits_per_pass): the classes of the pass as dense slots, and
+//   the pass's label and validity rows GATHERED quad-major -- vecq[pass][q][2 TB] 16-byte quads,
+//   slots 0 .. TB - 1 the label rows (the last one repeated past the pass's traits), TB .. the
+//   validity rows of the pass's classes (the last one repeated) -- so that k_counts fetches the
+//   operands of one gene quad with a few wide scalar loads from one contiguous 32 TB-byte row.
+// Plan buffer (int32 words): header {T, TB, passes, Qp}, cls[T], slot[T], nM[passes],
+// mrow[passes][TB], padding to 64 bytes, vecq.
+struct PlanLayout {
+  int64_t cls, slot, nm, mrow, vecq_words, words;
+  int tb, passes;
+};
+constexpr int kPlanHdr = 4;
+__host__ __device__ inline int plan_traits_per_pass(int64_t T) {
+  const int64_t passes = (T + 31) / 32;
+  const int64_t tpp = (T + passes - 1) / passes;
+  return tpp <= 2 ? (int)tpp : (int)((tpp + 3) / 4 * 4);    // kernel instances: 1, 2, 4, 8, ... 32
+}
+__host__ __device__ inline PlanLayout plan_layout(int64_t T, int64_t Qp) {
+  PlanLayout L{};
+  L.tb = plan_traits_per_pass(T);
+  L.passes = (int)((T + L.tb - 1) / L.tb);
+  L.cls = kPlanHdr;
+  L.slot = L.cls + T;
+  L.nm = L.slot + T;
+  L.mrow = L.nm + L.passes;
+  L.vecq_words = (L.mrow + (int64_t)L.passes * L.tb + 15) / 16 * 16;
+  L.words = L.vecq_words + (int64_t)L.passes * Qp * 2 * L.tb * 4;
+  return L;
+}
+// One wavefront per trait; the class search compares rows front to back with an early exit
+// (different masks differ within the first words, identical ones are found at t' = cls).
+__global__ __launch_bounds__(64) void k_trait_plan(const uint32_t* __restrict__ traits,
+                                                   const uint32_t* __restrict__ masks, int Wp, int T,
+                                                   int32_t* __restrict__ margins,
+                                                   int32_t* __restrict__ cls,
+                                                   int32_t* __restrict__ cls_user) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const uint32_t* trow = traits + (int64_t)t * Wp;
+  const uint32_t* mrow = masks + (int64_t)t * Wp;
+  int npos = 0, nval = 0;
+  for (int w = lane; w < Wp; w += 64) {
+    npos += __popc(trow[w]);
+    nval += __popc(mrow[w]);
   }
-  for (int q = 0; q < Qp; ++q) {
-    const uint4 gw = tiled[(int64_t)q * Gp + g];
 #pragma unroll
-    for (int j = 0; j < TB; ++j) {
-      const uint4 tw = trow[j][q], mw = mrow[j][q];       // wave-uniform
-      a[j] += popc4(gw, tw);
-      m[j] += popc4(gw, mw);
-      npos_[j] += popc4(tw);
-      nval_[j] += popc4(mw);
+  for (int off = 32; off > 0; off >>= 1) {
+    npos += __shfl_xor(npos, off);
+    nval += __shfl_xor(nval, off);
+  }
+  if (lane == 0) {
+    margins[2 * t] = npos;
+    margins[2 * t + 1] = nval;
+  }
+  int found = t;
+  for (int u = 0; u < t; ++u) {
+    const uint32_t* urow = masks + (int64_t)u * Wp;
+    bool same = true;
+    for (int w0 = 0; w0 < Wp && same; w0 += 64) {
+      const int w = w0 + lane;
+      const bool eq = w >= Wp || urow[w] == mrow[w];
+      same = __all(eq);
+    }
+    if (same) {
+      found = u;
+      break;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-#pragma unroll
-    for (int j = 0; j < TB; ++j)
-      if (t0 + j < T) {
-        margins[2 * (t0 + j)] = npos_[j];
-        margins[2 * (t0 + j) + 1] = nval_[j];
+  if (lane == 0) {
+    cls[t] = found;
+    if (cls_user) cls_user[t] = found;
+  }
+}
+// One wavefront per pass: the classes of the pass's traits -> dense slots 0 .. nM - 1
+__global__ __launch_bounds__(64) void k_trait_slots(int32_t* __restrict__ plan, int T, int Qp) {
+  const PlanLayout L = plan_layout(T, Qp);
+  const int pass = blockIdx.x, lane = threadIdx.x, t0 = pass * L.tb;
+  const int nT = min(L.tb, T - t0);
+  const int32_t* cls = plan + L.cls;
+  int rep = lane;                                         // first trait of the pass with this trait's class
+  if (lane < nT)
+    for (int u = 0; u < lane; ++u)
+      if (cls[t0 + u] == cls[t0 + lane]) {
+        rep = u;
+        break;
       }
-  }
-  if (g >= G) return;
-#pragma unroll
-  for (int j = 0; j < TB; ++j) {
-    const int t = t0 + j;
-    if (t < T) {
-      const int npos = npos_[j], nval = nval_[j];
-      counts[(int64_t)t * G + g] =
-          make_int4(a[j], npos - a[j], m[j] - a[j], nval - npos - m[j] + a[j]);
+  const uint64_t owners = __ballot(lane < nT && rep == lane);
+  if (lane < nT) plan[L.slot + t0 + lane] = __popcll(owners & (((uint64_t)1 << rep) - 1));
+  if (lane < nT && rep == lane)
+    plan[L.mrow + (int64_t)pass * L.tb + __popcll(owners & (((uint64_t)1 << lane) - 1))] = lane;
+  if (lane == 0) {
+    plan[L.nm + pass] = __popcll(owners);
+    if (pass == 0) {
+      plan[0] = T;
+      plan[1] = L.tb;
+      plan[2] = L.passes;
+      plan[3] = Qp;
     }
+  }
+}
+// block (q, pass), thread = slot: gather the pass's rows quad-major
+__global__ __launch_bounds__(64) void k_trait_vecq(const uint4* __restrict__ traits,
+                                                   const uint4* __restrict__ masks,
+                                                   int32_t* __restrict__ plan, int T, int Qp) {
+  const PlanLayout L = plan_layout(T, Qp);
+  const int q = blockIdx.x, pass = blockIdx.y, sl = threadIdx.x, t0 = pass * L.tb;
+  if (sl >= 2 * L.tb) return;
+  const int nT = min(L.tb, T - t0), nM = plan[L.nm + pass];
+  uint4 v;
+  if (sl < L.tb) {
+    v = traits[(int64_t)(t0 + min(sl, nT - 1)) * Qp + q];
+  } else {
+    const int row = plan[L.mrow + (int64_t)pass * L.tb + min(sl - L.tb, nM - 1)];
+    v = masks[(int64_t)(t0 + row) * Qp + q];
+  }
+  reinterpret_cast<uint4*>(plan + L.vecq_words)[((int64_t)pass * Qp + q) * (2 * L.tb) + sl] = v;
+}
+
+// K1.  Block = 64 genes x QS wavefronts; lane = gene, wavefront w = the quads q = w, w + QS, ... of
+// the rows: the matrix is streamed ONCE per pass, 1 KiB per wavefront load, and QS (1 ... 16, chosen by
+// the host) makes enough wavefronts to hide the latency of a stream that has little arithmetic per
+// byte (round 3's lane-per-gene kernel took 4 traits per pass: ceil(T / 4) passes over the matrix,
+// 13 at cfg5, 8.5x the algorithmic bytes).  A pass takes TB traits (instances 1, 2, 4, 8, ... 32;
+// grid.y passes; TB <= 32 keeps 2 TB accumulators in VGPRs):
+//   a[j] += popc(gene & label_j)      for every trait slot j of the pass
+//   m[i] += popc(gene & valid_i)      for the i-th CLASS of identical validity rows of the pass,
+//                                     four classes per (wave-uniform) branch
+// The operands of a gene quad are one contiguous row of the plan's vecq (scalar loads of 64 bytes,
+// the next group requested before the current one is used; SGPR operands of the AND).  The partial
+// sums of a gene's quad slices meet in LDS (ds_add), where the tables are put together (a of trait
+// j, m of its class, the margins from the plan) and leave as one 16-byte store per (trait, gene).
+template <int TB>
+__global__ __launch_bounds__(1024) void k_counts(const uint4* __restrict__ tiled,
+                                                 const int32_t* __restrict__ plan,
+                                                 const int32_t* __restrict__ margins, int G, int Gp,
+                                                 int Qp, int T, int4* __restrict__ counts) {
+  constexpr int GS = TB < 4 ? TB : 4;                     // vectors per scalar load / mask branch
+  constexpr int NGR = TB / GS;                            // groups of trait slots
+  __shared__ int32_t s_tot[2 * TB][kWave];               // 512 B per accumulator: 16 KB at TB = 32
+  const PlanLayout L = plan_layout(T, Qp);
+  const int tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x * kWave + lane;               // < Gp: the tiled matrix is padded
+  const int pass = blockIdx.y, t0 = pass * TB;
+  const int nT = min(TB, T - t0);                         // traits of this pass, 1 ... TB
+  const int nM = __builtin_amdgcn_readfirstlane(plan[L.nm + pass]);     // classes of the pass, >= 1
+  for (int i = tid; i < 2 * TB * kWave; i += blockDim.x) (&s_tot[0][0])[i] = 0;
+  __syncthreads();
+  uint32_t a[TB], m[TB];
+#pragma unroll
+  for (int j = 0; j < TB; ++j) a[j] = m[j] = 0u;
+  const uint4* vecq = reinterpret_cast<const uint4*>(plan + L.vecq_words) + (int64_t)pass * Qp * (2 * TB);
+  auto load_group = [&](const uint4* row, int gi, uint4 (&dst)[GS]) {
+#pragma unroll
+    for (int k = 0; k < GS; ++k) dst[k] = row[gi * GS + k];          // wave-uniform: one s_load_dwordx(4 GS)
+  };
+  auto add_group = [&](const uint4& gw, const uint4 (&src)[GS], uint32_t* acc) {
+#pragma unroll
+    for (int k = 0; k < GS; ++k) {
+      bcnt_acc(acc[k], gw.x & src[k].x);
+      bcnt_acc(acc[k], gw.y & src[k].y);
+      bcnt_acc(acc[k], gw.z & src[k].z);
+      bcnt_acc(acc[k], gw.w & src[k].w);
+    }
+  };
+  // U gene quads are requested before any of them is used: with few traits per pass there is
+  // little arithmetic per load and the stream lives on loads in flight (cfg4: T = 1)
+  constexpr int U = TB <= 4 ? 4 : (TB <= 16 ? 2 : 1);
+  for (int q0 = wave; q0 < Qp; q0 += nw * U) {
+    uint4 gws[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + nw * u;                          // wave-uniform
+      gws[u] = q < Qp ? tiled[(int64_t)q * Gp + g] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = min(q0 + nw * u, Qp - 1);             // past the end: a zero gene quad adds nothing
+      const uint4 gw = gws[u];
+      const uint4* row = vecq + (int64_t)q * (2 * TB);
+      uint4 cur[GS], nxt[GS];
+      load_group(row, 0, cur);
+#pragma unroll
+      for (int gi = 0; gi < NGR; ++gi) {                  // label rows; then the first group of classes
+        load_group(row, gi + 1, nxt);                     // gi + 1 == NGR: slots TB .. = validity rows
+        add_group(gw, cur, a + gi * GS);
+#pragma unroll
+        for (int k = 0; k < GS; ++k) cur[k] = nxt[k];
+      }
+      add_group(gw, cur, m);                              // classes 0 .. GS - 1 (nM >= 1; repeats are not read)
+#pragma unroll
+      for (int gi = 1; gi < NGR; ++gi) {                  // further classes: rare (many distinct masks)
+        if (gi * GS < nM) {                               // wave-uniform
+          load_group(row, NGR + gi, cur);
+          add_group(gw, cur, m + gi * GS);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TB; ++j) {                          // the quad slices of a gene meet in LDS
+    if (j < nT) atomicAdd(&s_tot[j][lane], (int32_t)a[j]);
+    if (j < nM) atomicAdd(&s_tot[TB + j][lane], (int32_t)m[j]);
+  }
+  __syncthreads();
+  if (g >= G) return;
+  for (int j = wave; j < nT; j += nw) {                   // wavefront w puts together traits w, w + nw, ...
+    const int aa = s_tot[j][lane];
+    const int mm = s_tot[TB + plan[L.slot + t0 + j]][lane];
+    const int npos = margins[2 * (t0 + j)], nval = margins[2 * (t0 + j) + 1];
+    counts[(int64_t)(t0 + j) * G + g] = make_int4(aa, npos - aa, mm - aa, nval - npos - mm + aa);
   }
 }
 
@@ -574,6 +735,82 @@ int scoary_tile_rows(scoary_handle h, const uint64_t* d_rows64, int64_t G, int64
   return SCOARY_OK;
 }
 
+extern "C++" {
+static int launch_trait_plan(scoary_handle h, hipStream_t s, const uint32_t* d_traits, const uint32_t* d_masks,
+                             int64_t T, int64_t N, int32_t* d_margins, int32_t* d_mask_class, int32_t* d_plan) {
+  const int64_t Qp = scoary_tiled_quads(N);
+  const PlanLayout L = plan_layout(T, Qp);
+  KernelTimer kt(h, s, "k_trait_plan");
+  hipLaunchKernelGGL(k_trait_plan, dim3((unsigned)T), dim3(64), 0, s, d_traits, d_masks,
+                     (int)scoary_row_words(N), (int)T, d_margins, d_plan + L.cls, d_mask_class);
+  hipLaunchKernelGGL(k_trait_slots, dim3((unsigned)L.passes), dim3(64), 0, s, d_plan, (int)T, (int)Qp);
+  hipLaunchKernelGGL(k_trait_vecq, dim3((unsigned)Qp, (unsigned)L.passes), dim3(64), 0, s,
+                     reinterpret_cast<const uint4*>(d_traits), reinterpret_cast<const uint4*>(d_masks),
+                     d_plan, (int)T, (int)Qp);
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+static int launch_counts(scoary_handle h, hipStream_t s, const uint32_t* d_tiled, const int32_t* d_plan,
+                         const int32_t* d_margins, int64_t G, int64_t T, int64_t N, int32_t* d_counts) {
+  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
+  const PlanLayout L = plan_layout(T, Qp);
+  // wavefronts per 64 genes: enough of them for ~8 per SIMD over the chip, at least two quads each
+  const int64_t base = Gp / kWave * L.passes, want = (int64_t)h->num_cu * 4 * 8;
+  int qs = 1;
+  while (qs < 16 && base * qs < want && 4 * qs <= Qp) qs *= 2;
+  const dim3 grid((unsigned)(Gp / kWave), (unsigned)L.passes), block((unsigned)(kWave * qs));
+  KernelTimer kt(h, s, "k_counts");
+#define COUNTS(TBV)                                                                                   \
+  hipLaunchKernelGGL((k_counts<TBV>), grid, block, 0, s, reinterpret_cast<const uint4*>(d_tiled),     \
+                     d_plan, d_margins, (int)G, (int)Gp, (int)Qp, (int)T, reinterpret_cast<int4*>(d_counts))
+  switch (L.tb) {
+    case 1: COUNTS(1); break;
+    case 2: COUNTS(2); break;
+    case 4: COUNTS(4); break;
+    case 8: COUNTS(8); break;
+    case 12: COUNTS(12); break;
+    case 16: COUNTS(16); break;
+    case 20: COUNTS(20); break;
+    case 24: COUNTS(24); break;
+    case 28: COUNTS(28); break;
+    default: COUNTS(32); break;
+  }
+#undef COUNTS
+  HIP_TRY(h, hipGetLastError());
+  return SCOARY_OK;
+}
+}  // extern "C++"
+
+int64_t scoary_counts_traits_per_pass(int64_t T) { return T < 1 ? 0 : plan_traits_per_pass(T); }
+int64_t scoary_trait_plan_bytes(int64_t T, int64_t N) {
+  return (T < 1 || N < 1) ? 0 : plan_layout(T, scoary_tiled_quads(N)).words * (int64_t)sizeof(int32_t);
+}
+
+int scoary_trait_plan(scoary_handle h, const uint32_t* d_traits, const uint32_t* d_masks, int64_t T,
+                      int64_t N, int32_t* d_margins, int32_t* d_mask_class, void* d_plan,
+                      scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_traits || !d_masks || !d_margins || !d_plan || T < 1 || N < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_trait_plan: bad argument");
+  if (T > 65535 * 8) return fail(h, SCOARY_ERR_SIZE, "scoary_trait_plan: T too large");
+  DeviceGuard guard(h->device);
+  return launch_trait_plan(h, static_cast<hipStream_t>(stream), d_traits, d_masks, T, N, d_margins,
+                           d_mask_class, static_cast<int32_t*>(d_plan));
+}
+
+int scoary_counts_planned(scoary_handle h, const uint32_t* d_tiled, const void* d_plan,
+                          const int32_t* d_margins, int64_t G, int64_t T, int64_t N,
+                          int32_t* d_counts, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!d_tiled || !d_plan || !d_margins || !d_counts || G < 1 || T < 1 || N < 1)
+    return fail(h, SCOARY_ERR_ARG, "scoary_counts_planned: bad argument");
+  if (G > (int64_t)1 << 30 || T > 65535 * 8)
+    return fail(h, SCOARY_ERR_SIZE, "scoary_counts_planned: G or T too large");
+  DeviceGuard guard(h->device);
+  return launch_counts(h, static_cast<hipStream_t>(stream), d_tiled, static_cast<const int32_t*>(d_plan),
+                       d_margins, G, T, N, d_counts);
+}
+
 int scoary_counts(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_traits,
                   const uint32_t* d_masks, int64_t G, int64_t T, int64_t N, int32_t* d_counts,
                   int32_t* d_margins, scoary_stream_t stream) {
@@ -582,17 +819,16 @@ int scoary_counts(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_tr
     return fail(h, SCOARY_ERR_ARG, "scoary_counts: bad argument");
   if (G > (int64_t)1 << 30 || T > 65535 * 8) return fail(h, SCOARY_ERR_SIZE, "scoary_counts: G or T too large");
   DeviceGuard guard(h->device);
-  const int64_t Gp = scoary_tiled_genes(G), Qp = scoary_tiled_quads(N);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  constexpr int TB = 4;
-  {
-    KernelTimer kt(h, s, "k_counts");
-    hipLaunchKernelGGL((k_counts<TB>), dim3((unsigned)(Gp / 256), (unsigned)((T + TB - 1) / TB)),
-                       dim3(256), 0, s, reinterpret_cast<const uint4*>(d_tiled), d_traits, d_masks,
-                       d_margins, (int)G, (int)Gp, (int)Qp, (int)T, reinterpret_cast<int4*>(d_counts));
-  }
-  HIP_TRY(h, hipGetLastError());
-  return SCOARY_OK;
+  // the one-call form: a plan in stream-ordered temporary memory, then the tables.  Callers with more
+  // than one step per trait set build the plan once (scoary_trait_plan + scoary_counts_planned).
+  void* tmp = nullptr;
+  HIP_TRY(h, hipMallocAsync(&tmp, (size_t)scoary_trait_plan_bytes(T, N), s));
+  int rc = launch_trait_plan(h, s, d_traits, d_masks, T, N, d_margins, nullptr, static_cast<int32_t*>(tmp));
+  if (rc == SCOARY_OK)
+    rc = launch_counts(h, s, d_tiled, static_cast<const int32_t*>(tmp), d_margins, G, T, N, d_counts);
+  (void)hipFreeAsync(tmp, s);
+  return rc;
 }
 
 int scoary_fisher(scoary_handle h, const int32_t* d_tables, int64_t M, double* d_p, double* d_or,

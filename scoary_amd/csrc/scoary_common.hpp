@@ -65,6 +65,7 @@ inline int64_t tiled_quads(int64_t N) {
 constexpr int kSegRows = 20352;                      // 159 * 128: whole word quads; (rows + 1) * 8 B fit 160 KB
 constexpr int kSegTW = 2;                            // dwords per row of a segmented tile
 constexpr int kSegStride = ((kSegRows + 1) * kSegTW + 3) / 4 * 4;   // dwords from one segment of a tile to the next
+constexpr int kSegPiece = 8;                         // 16-bit entries per lane and index vector (16 bytes) of a segmented sub-list
 constexpr int kMaxListIsolates = 131070;             // N / 2 < 2^16: sixteen counter planes; at most 7 segments
 __host__ __device__ constexpr int list_segments(int64_t N) {
   return N <= 20479 ? 1 : (N <= kMaxListIsolates ? (int)((N + kSegRows - 1) / kSegRows) : 0);

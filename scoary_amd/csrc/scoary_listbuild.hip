@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void k_lists_fill(const uint4* __restrict__ ti
 
 // ---- segmented lists (N > 20479, scoary_common.hpp): one sub-list per gene and segment ----
 // Order and flip are the whole row's (k_lists_len + sort); the sub-lists of a wave group are
-// padded to the longest of the group in that segment; entries are byte addresses inside the
-// segment's tile (row - segment start) * 8, padding points at the segment's own zero row.
+// padded to the longest of the group in that segment; entries are 16-bit row indices inside the
+// segment (row - segment start), padding points at the segment's own zero row.
 // Segments start on multiples of 128 isolates, so a position's residue class mod 32 is the
 // same inside the segment as in the row.
 
@@ -369,13 +369,28 @@ __global__ __launch_bounds__(256) void k_lists_segslots(const int32_t* __restric
   if (k >= G) return;
   const int64_t q = k / gpw;
   for (int sgm = 0; sgm < nseg; ++sgm) {
-    start[(int64_t)sgm * G + k] = (int32_t)(base[q * nseg + sgm] / kListStartUnit);
+    start[(int64_t)sgm * G + k] = (int32_t)(base[q * nseg + sgm] / (2 * kListStartUnit));   // 16-bit entries: 128 bytes = 64
     ngroups[(int64_t)sgm * G + k] = padded[q * nseg + sgm] / kListPad;
   }
 }
-// The entry order of spec S6 inside every segment (k_lists_fill with a segment loop): C lanes
-// per slot (lane = residue class), 64 / C slots per wavefront; C = 32 for the two-dword tiles.
-template <int C>
+// Segmented sub-lists, round 4: 16-BIT entries (the row index inside the segment, <= kSegRows = the
+// segment's zero row; the kernel shifts it to an LDS address), eight per 16-byte index vector.
+// Entry order: spec S6's alignment property with a cheaper hole assignment.  Class c = position
+// mod 32 -- one bit of every 32-bit word, so a lane tests exactly one bit per word, no per-lane bit
+// loops -- rank rho inside the class, grid slot rho * 32 + d, d = (c - k) mod 32.  With
+// R = total / 32 complete grid rows:
+//   * (c, rho), rho < R: ALIGNED, entry rho * 32 + d -- entry e then comes from class (k + e) mod 32 and
+//     the 32 genes of an LDS service group read 32 distinct bank slots;
+//   * (c, rho), rho >= R ("overflow" of the classes above the average, ~3 % of a random list): overflow
+//     rank r = sum_{c' < c} max(0, cnt[c'] - R) + rho - R; the holes below row R are ranked class by
+//     class (class c' has max(0, R - cnt[c']) of them, rows cnt[c'] .. R - 1): overflow r goes to hole r,
+//     and the overflow beyond the holes to the partial last row R * 32 + (r - holes).
+// Two 32-term prefix sums per (slot, segment) and a 5-step search per overflow entry replace round 3's
+// binary search over a 32-term sum per overflow entry (k_lists_fill's closed form, 13.7 ms of a 16.7 ms
+// set-up at 20 000 x 50 000).  (A plain compaction of the grid -- no holes to assign -- was tried first:
+// its last ~25 % of rows are misaligned, LDS bank conflicts of k_permute_seglists 16 % -> 29 % of the
+// LDS cycles, profiles/r04_wide50000_*.)  32 lanes per slot (lane = residue class), 2 slots per
+// wavefront, 8 per block.
 __global__ __launch_bounds__(256) void k_lists_fill_seg(const uint4* __restrict__ tiled, int64_t Gp,
                                                         int G, int N, int nseg,
                                                         const int32_t* __restrict__ seglen,
@@ -383,57 +398,59 @@ __global__ __launch_bounds__(256) void k_lists_fill_seg(const uint4* __restrict_
                                                         const uint8_t* __restrict__ flipped,
                                                         const int64_t* __restrict__ base,
                                                         const int32_t* __restrict__ padded,
-                                                        int64_t nslots, uint32_t* __restrict__ idx) {
-  __shared__ int32_t s_cnt[256];
-  static_assert(C <= 32, "a class is a set of bits of every 32-bit word");
-  constexpr int SPW = 64 / C, gpw = 64, piece = 4;
-  constexpr uint32_t row_stride = 4u * kSegTW;
+                                                        int64_t nslots, uint16_t* __restrict__ idx) {
+  __shared__ int32_t s_cnt[256], s_hlp[256];
+  constexpr int C = 32, gpw = 64, piece = kSegPiece;
+  static_assert(64 / kSegTW == C, "residue classes of the two-dword tiles");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane % C;
-  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * SPW + lane / C;
+  const int64_t k = ((int64_t)blockIdx.x * 4 + wave) * (64 / C) + lane / C;
   const bool exists = k < nslots, live = k < G;
   const int64_t q = exists ? k / gpw : 0;
   const int j = (int)(k - q * gpw);
   const int g = live ? order[k] : 0;
   const uint32_t inv = (live && flipped[g]) ? 0xffffffffu : 0u;
-  uint32_t cmask = 0u;                         // bits of a 32-bit word that belong to class c
-  for (int b = c; b < 32; b += C) cmask |= 1u << b;
-  auto class_bits = [&](uint32_t word, int w) -> uint32_t {
-    const int first = 32 * w;
-    uint32_t bits = word ^ inv;
-    if (first + 32 > N) bits &= first < N ? ((1u << (N - first)) - 1u) : 0u;
-    return bits & cmask;
+  // bit c of word w (position 32 w + c) of the minority pattern, 0 beyond N
+  auto class_bit = [&](uint32_t word, int w) -> uint32_t {
+    return (32 * w + c < N) ? (((word ^ inv) >> c) & 1u) : 0u;
   };
-  const int32_t* cnt = s_cnt + (tid - c);      // the C class counts of this slot
+  const int32_t* cnt = s_cnt + (tid - c);      // the 32 class counts of this slot
   const int dk = (int)((c - k) & (C - 1));
   for (int sgm = 0; sgm < nseg; ++sgm) {
     const int row0 = sgm * kSegRows, rows = (int)list_seg_rows(N, sgm);
     const int qd0 = row0 / 128, qd1 = (row0 + rows + 127) / 128;
     const int L = exists ? padded[q * nseg + sgm] : 0;
-    const int64_t b0 = exists ? base[q * nseg + sgm] : 0;
+    const int64_t b0 = exists ? base[q * nseg + sgm] : 0;          // in 16-bit entries
     const int total = live ? seglen[(int64_t)sgm * G + g] : 0;
-    auto at = [&](int n) -> int64_t {
+    auto at = [&](int n) -> int64_t {          // interleaved position of entry n of this slot
       return b0 + ((int64_t)(n / piece) * gpw + j) * piece + n % piece;
     };
     int my_cnt = 0;
     if (live)
       for (int qd = qd0; qd < qd1; ++qd) {
         const uint4 v = tiled[(int64_t)qd * Gp + g];
-        my_cnt += __popc(class_bits(v.x, 4 * qd)) + __popc(class_bits(v.y, 4 * qd + 1)) +
-                  __popc(class_bits(v.z, 4 * qd + 2)) + __popc(class_bits(v.w, 4 * qd + 3));
+        my_cnt += (int)(class_bit(v.x, 4 * qd) + class_bit(v.y, 4 * qd + 1) + class_bit(v.z, 4 * qd + 2) +
+                        class_bit(v.w, 4 * qd + 3));
       }
     __syncthreads();                           // the previous segment's counts have been used
     s_cnt[tid] = my_cnt;
     __syncthreads();
-    auto filled = [&](int x) -> int {
-      int f = 0;
-      for (int xc = 0; xc < C; ++xc) {
-        const int dx = (int)((xc - k) & (C - 1));
-        f += min(cnt[xc], max(0, (x - dx + C - 1) / C));
+    const int R = total / C;                   // complete grid rows (total = the sum of the 32 counts)
+    const int ov = max(0, my_cnt - R), hl = max(0, R - my_cnt);
+    int ovp = ov, hlp = hl;                    // inclusive prefix sums over the slot's classes 0 .. c
+#pragma unroll
+    for (int off = 1; off < C; off <<= 1) {
+      const int o = __shfl_up(ovp, off, C), hh = __shfl_up(hlp, off, C);
+      if (c >= off) {
+        ovp += o;
+        hlp += hh;
       }
-      return f;
-    };
-    const int filled_total = filled(total);
+    }
+    const int holes = __shfl(hlp, C - 1, C);   // all holes of the slot
+    ovp -= ov;                                 // exclusive: overflow rank of this class's first overflow entry
+    s_hlp[tid] = hlp - hl;                     // exclusive: rank of this class's first hole
+    __syncthreads();
+    const int32_t* hbase = s_hlp + (tid - c);
     if (live) {
       int rho = 0;
       for (int qd = qd0; qd < qd1; ++qd) {
@@ -441,28 +458,26 @@ __global__ __launch_bounds__(256) void k_lists_fill_seg(const uint4* __restrict_
         const uint32_t words[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int w4 = 0; w4 < 4; ++w4) {
-          uint32_t bits = class_bits(words[w4], 4 * qd + w4);
-          while (bits) {
-            const int b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            int pos = rho * C + dk;
-            if (pos >= total) {
-              const int ov = filled(pos) - filled_total;
-              int lo = 0, hi = total - 1;
-              while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (mid + 1 - filled(mid + 1) >= ov + 1) hi = mid; else lo = mid + 1;
-              }
-              pos = lo;
+          if (!class_bit(words[w4], 4 * qd + w4)) continue;
+          int pos = rho * C + dk;              // the aligned grid slot
+          if (rho >= R) {                      // overflow: to the r-th hole, or into the partial last row
+            const int r = ovp + (rho - R);
+            if (r < holes) {
+              int xc = 0;                      // the last class whose first hole has rank <= r
+#pragma unroll
+              for (int step = C / 2; step > 0; step >>= 1)
+                if (hbase[xc + step] <= r) xc += step;
+              pos = (cnt[xc] + (r - hbase[xc])) * C + (int)((xc - k) & (C - 1));
+            } else {
+              pos = R * C + (r - holes);
             }
-            idx[at(pos)] = (uint32_t)(32 * (4 * qd + w4) + b - row0) * row_stride;
-            ++rho;
           }
+          idx[at(pos)] = (uint16_t)(32 * (4 * qd + w4) + c - row0);
+          ++rho;
         }
       }
     }
-    const uint32_t zero_row = (uint32_t)rows * row_stride;
-    for (int n = total + c; n < L; n += C) idx[at(n)] = zero_row;
+    for (int n = total + c; n < L; n += C) idx[at(n)] = (uint16_t)rows;     // the segment's zero row
   }
 }
 
@@ -538,6 +553,9 @@ int scoary_lists_plan(scoary_handle h, const uint32_t* d_tiled, int64_t G, int64
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(entries_out, base + L.nwg * L.nseg, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(h, hipStreamSynchronize(s));
+  // entries_out counts 32-bit words of index array; the segmented sub-lists hold two 16-bit
+  // entries per word (every sub-list is a multiple of 64 x 16 entries: the total is even)
+  if (L.nseg > 1) *entries_out /= 2;
   return SCOARY_OK;
 }
 
@@ -564,11 +582,10 @@ int scoary_lists_fill(scoary_handle h, const uint32_t* d_tiled, int64_t G, int64
   const dim3 grid((unsigned)((nslots + spb - 1) / spb));
   KernelTimer kt(h, s, "k_lists_fill");
   if (L.nseg > 1) {
-    static_assert(64 / kSegTW == 32, "residue classes of the segmented tiles");
-    hipLaunchKernelGGL((k_lists_fill_seg<32>), dim3((unsigned)((nslots + 7) / 8)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_lists_fill_seg, dim3((unsigned)((nslots + 7) / 8)), dim3(256), 0, s,
                        reinterpret_cast<const uint4*>(d_tiled), Gp, (int)G, (int)N, (int)L.nseg,
                        reinterpret_cast<const int32_t*>(sc + L.seglen), d_order, d_flipped, base,
-                       padded, nslots, d_idx);
+                       padded, nslots, reinterpret_cast<uint16_t*>(d_idx));
     hipLaunchKernelGGL(k_lists_slack, dim3(1), dim3(256), 0, s, d_idx, entries);
     HIP_TRY(h, hipGetLastError());
     return SCOARY_OK;

@@ -424,6 +424,25 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
   out[(int64_t)t * G + k] = o;
 }
 
+// Which (trait, tile) column and which chunk of wave groups a block of k_permute_seglists works on.
+// The dispatcher places block b on XCD b % 8 and every XCD has its own 4 MB L2: with a plain
+// (tile fastest, chunk) grid the eight XCDs walk the SAME chunk of index lists at the same time and
+// each L2 fetches its own copy from the Infinity Cache / HBM.  The segmented kernel lives on that
+// stream (round 3: 8.4 GB of fetches per 1.87 ms launch at 20 000 x 50 000), so its grid is
+// one-dimensional, nx * 8 * ceil(ny / 8) blocks, and every XCD takes ONE chunk of each row of eight
+// -- the nx (trait, tile) blocks of a chunk share one L2 -- rows alternately forwards and backwards
+// (chunks hold ever shorter lists: XCD 0 would get the longest of every row).  Blocks whose chunk
+// does not exist leave at once.  (k_permute_lists keeps the two-dimensional grid: it is VALU-bound,
+// and the static split cost it 2-3 % in balance, profiles/r03_ab_xcd_block_map.txt.)
+struct SegJob { int bx, by; bool exists; };
+__device__ __forceinline__ SegJob seg_block_job(int ngroups, int groups_per_block) {
+  const int ny = (ngroups + groups_per_block - 1) / groups_per_block;       // chunks
+  const uint32_t nx = gridDim.x / (8u * (uint32_t)((ny + 7) / 8));          // (trait, tile) columns
+  const uint32_t b = blockIdx.x, xcd = b & 7u, k = b >> 3;
+  const uint32_t row = k / nx;
+  const int by = (int)row * 8 + (int)((row & 1u) ? 7u - xcd : xcd);
+  return SegJob{(int)(k % nx), by, by < ny};
+}
 // lane id from v_mbcnt, opaque to the optimiser (see its use in k_permute_lists)
 __device__ __forceinline__ int fresh_lane() {
   int l;
@@ -483,6 +502,27 @@ __device__ __forceinline__ void read4x4(Rows4& x, const uint32_t (&e)[4], uint32
   }
 }
 #undef SCOARY_DPP4
+// k_permute_seglists: 16-bit entries (row index inside the isolate segment, <= 20352), eight per
+// 16-byte index vector; sub-step H takes dwords 2H, 2H + 1.  LDS address = index * 8 (two-dword
+// rows, the tile segment sits at LDS address 0): one SDWA shift per entry picks the half word and
+// scales it -- the price of halving the index stream (round 3: the kernel ran at 0.25 of the VALU
+// peak behind 4.5 TB/s of index fetches, profiles/r03_wide50000_pmc.json).
+template <int H>
+__device__ __forceinline__ void read4x4_half(Rows4& x, const uint32_t (&e)[4], uint32_t three) {
+  uint32_t a[4];
+  asm("v_lshlrev_b32_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+      "v_lshlrev_b32_sdwa %1, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+      "v_lshlrev_b32_sdwa %2, %4, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+      "v_lshlrev_b32_sdwa %3, %4, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+      : "s"(three), "v"(e[2 * H]), "v"(e[2 * H + 1]));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32x2 v = *(const __attribute__((address_space(3))) u32x2*)(uintptr_t)a[j];
+    x.w0[j] = v.x;
+    x.w1[j] = v.y;
+  }
+}
 // 4 row words -> counter planes 0..1 of word W, returns the carry of weight 4
 template <int W>
 __device__ __forceinline__ uint32_t sum4(uint32_t (&c)[16], const uint32_t (&x)[4]) {
@@ -600,7 +640,10 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
     uint32_t c0[16], c1[16], c2[16], c3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) c0[k] = c1[k] = c2[k] = c3[k] = 0u;
+    constexpr int kVecSub = LPG;       // lane h of a gene's group holds the four entries of sub-step h
+#define SCOARY_READ4(H, X, E) read4x4<LPG, H, NW>(X, E, colb)
 #include "scoary_list_walk.inc"
+#undef SCOARY_READ4
     // next group of this wavefront: open it and request its first index vectors now
     if (q + nwaves < q_hi) {
       cur = open_group(q + nwaves);
@@ -639,7 +682,8 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
 
 // N > 20479: one 64-permutation tile no longer fits the 160 KB of LDS, so the isolates are cut
 // into nseg segments of kSegRows rows (scoary_common.hpp).  A gene's index list is one sub-list
-// per segment (entries = LDS byte addresses inside the segment, lstart / lngroups are [nseg][G]);
+// per segment (16-bit entries = row indices inside the segment, two per dword -- round 4, the
+// 32-bit LDS addresses of round 3 made the kernel index-bandwidth-bound; lstart / lngroups are [nseg][G]);
 // the block walks its wave groups in ROUNDS of one group per wavefront and, inside a round,
 // loads the tile segment by segment: the counter planes stay in registers across the reloads
 // and the region test comes after the last segment.  One lane per gene, two permutation words
@@ -658,15 +702,16 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
   scoary_bank_defs();
   constexpr int LPG = 1, NW = kSegTW, TW = kSegTW, GPW = kWave;
   static_assert(kSegTW == 2, "two permutation words per lane");
-  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+  const int ngroups = (G + GPW - 1) / GPW;
+  const SegJob job = seg_block_job(ngroups, groups_per_block);
+  if (!job.exists) return;
+  const int t = job.bx / ntiles, tile = job.bx % ntiles;
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = 0;
-  const int ngroups = (G + GPW - 1) / GPW;
-  const int q_lo = blockIdx.y * groups_per_block;
+  const int q_lo = job.by * groups_per_block;
   const int q_hi = min(ngroups, q_lo + groups_per_block);
   const uint32_t lane_off = (uint32_t)lane * 16u;
-  uint16_t* out = partial + (int64_t)blockIdx.x * ((int64_t)ngroups * GPW);
+  uint16_t* out = partial + (int64_t)job.bx * ((int64_t)ngroups * GPW);
   struct alignas(16) Ent { uint32_t e[4]; };
   constexpr int kListLoadPolicy = SCOARY_LIST_LOAD_POLICY;
   struct Group { int nhalf, last; __amdgpu_buffer_rsrc_t rsrc; };
@@ -675,7 +720,8 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
     const int64_t start = (int64_t)__builtin_amdgcn_readfirstlane(lstart[slot]);
     const int nh = __builtin_amdgcn_readfirstlane(lngroups[slot]);
     const int64_t gbytes = lidx_bytes - start * 128;
-    return Group{nh, max(nh * (4 / LPG) - 1, 0),
+    // a half step (16 entries of 16 bits) is two 16-byte vectors per lane
+    return Group{nh, max(nh * 2 - 1, 0),
                  __builtin_amdgcn_make_buffer_rsrc(
                      const_cast<Ent*>(reinterpret_cast<const Ent*>(lidx) + start * 8), 0,
                      (int)min(gbytes, (int64_t)0x7fffffff), 0x00020000)};
@@ -686,7 +732,8 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
     return Ent{{v.x, v.y, v.z, v.w}};
   };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds;
-  const uint32_t* src = tiles + (int64_t)blockIdx.x * ((int64_t)nseg * kSegStride);
+  const uint32_t three = 3u;                             // SDWA shift amount (an SGPR operand)
+  const uint32_t* src = tiles + (int64_t)job.bx * ((int64_t)nseg * kSegStride);
   // rounds and segments are block-uniform: every wavefront meets every barrier, whether or not
   // it has a wave group in this round
   const int rounds = (q_hi - q_lo + nwaves - 1) / nwaves;
@@ -697,6 +744,11 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
 #pragma unroll
     for (int k = 0; k < 16; ++k) c0[k] = c1[k] = c2[k] = c3[k] = 0u;
     for (int sgm = 0; sgm < nseg; ++sgm) {
+      // the sub-list's first four index vectors are requested before the tile segment is
+      // (re)loaded, so the walk does not open with an exposed L2 round trip (inactive
+      // wavefronts read the block's last group: harmless)
+      const Group cur = open_group(min(q, q_hi - 1), sgm);
+      Ent ring[4] = {load_from(cur, 0), load_from(cur, 1), load_from(cur, 2), load_from(cur, 3)};
       __syncthreads();                       // the previous segment has been walked by everyone
       {
         const uint4* src4 = reinterpret_cast<const uint4*>(src + (int64_t)sgm * kSegStride);
@@ -714,12 +766,12 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
       }
       __syncthreads();
       if (active) {
-        const Group cur = open_group(q, sgm);
-        Ent ring[4] = {load_from(cur, 0), load_from(cur, 1), load_from(cur, 2), load_from(cur, 3)};
         const int nhalf = cur.nhalf;
         const int nsuper = (nhalf + 1) >> 1;
-        const uint32_t colb = lds0;                    // one lane per gene: column 0 (both words)
+        constexpr int kVecSub = 2;                     // eight 16-bit entries per index vector
+#define SCOARY_READ4(H, X, E) read4x4_half<H>(X, E, three)
 #include "scoary_list_walk.inc"
+#undef SCOARY_READ4
       }
     }
     if (active) {
@@ -739,7 +791,6 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
       out[(int64_t)q * GPW + lg] = (uint16_t)cnt;                  // cnt <= 64
     }
   }
-  (void)col;
 }
 
 // r[t][gene of slot k] (+)= sum over the tiles of partial[t][tile][k]
@@ -778,7 +829,7 @@ int scoary_list_params(int64_t N, int64_t* out5) {
   out5[1] = TW * 4;                 /* LDS / tile row stride in bytes */
   out5[2] = TW ? kWave / list_lpg(TW) : 0;   /* genes per wavefront: lists padded to equal length */
   out5[3] = TW ? 64 / TW : 0;       /* residue classes of the isolate index (256-byte bank row) */
-  out5[4] = TW ? 4 * list_lpg(TW) : 0;   /* interleave piece, entries */
+  out5[4] = TW ? (list_segments(N) > 1 ? kSegPiece : 4 * list_lpg(TW)) : 0;   /* interleave piece, entries (16-bit ones in segments) */
   return TW ? SCOARY_OK : SCOARY_ERR_SIZE;
 }
 
@@ -932,7 +983,7 @@ static int launch_permute_seglists(scoary_handle h, hipStream_t s, const uint32_
                        (int)G, reinterpret_cast<uint2*>(d_lcrit_sc));
   }
   const ListGeom g = list_geom(h->num_cu, G, T, N, P, entries);
-  if (T * g.ntiles > 0x7fffffffLL || g.chunks > 65535)
+  if (T * g.ntiles * 8 * ((g.chunks + 7) / 8) > 0x7fffffffLL)
     return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: grid too large");
   const size_t lds = (size_t)kSegStride * sizeof(uint32_t);
   const void* fn = reinterpret_cast<const void*>(&k_permute_seglists<KC>);
@@ -947,8 +998,9 @@ static int launch_permute_seglists(scoary_handle h, hipStream_t s, const uint32_
     h->lists_lds_optin |= kOptinBit;
   }
   {
-    KernelTimer kt(h, s, "k_permute_lists");
-    hipLaunchKernelGGL((k_permute_seglists<KC>), dim3((unsigned)(T * g.ntiles), (unsigned)g.chunks),
+    KernelTimer kt(h, s, "k_permute_seglists");
+    // one-dimensional, XCD-aware grid (seg_block_job)
+    hipLaunchKernelGGL((k_permute_seglists<KC>), dim3((unsigned)(T * g.ntiles * 8 * ((g.chunks + 7) / 8))),
                        dim3(1024), lds, s, d_tiles, d_lidx, d_lstart, d_lngroups,
                        reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P, (int)g.ntiles,
                        (int)g.gpb, (entries + kListSlack) * (int64_t)sizeof(uint32_t),

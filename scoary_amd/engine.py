@@ -52,6 +52,21 @@ class GeneLists:
         self.order, self.flipped, self.entries = order, flipped, entries
 
 
+class TraitPlan:
+    """What the counts need that depends on the traits alone (scoary_trait_plan): margins
+    int32 [T, 2] = (positives, valid isolates), mask_class int32 [T] = first trait with the same
+    validity row, buf = the opaque plan buffer (class slots per pass + the label / validity
+    rows gathered quad-major).  Built once per trait set; valid for exactly the traits / masks
+    tensors it was built from (a snapshot: later in-place changes of them are not seen)."""
+
+    def __init__(self, margins, mask_class, buf, traits, masks, N):
+        self.margins, self.mask_class, self.buf, self.N = margins, mask_class, buf, int(N)
+        self.key = (traits.data_ptr(), masks.data_ptr(), tuple(traits.shape))
+
+    def fits(self, traits, masks):
+        return self.key == (traits.data_ptr(), masks.data_ptr(), tuple(traits.shape))
+
+
 class Workspace:
     """Device buffers of one associate() step (engine.workspace)."""
 
@@ -63,11 +78,14 @@ class Workspace:
         self.key = (G, N, int(T), int(permutations), bool(use_lists and permutations > 0))
         self.counts = eng._empty((T, G, 4), torch.int32)
         self.margins = eng._empty((T, 2), torch.int32)
+        self.mask_class = eng._empty((T,), torch.int32)
+        self.plan_buf = eng._empty((int(eng.lib.scoary_trait_plan_bytes(int(T), N)) // 4,), torch.int32)
         self.p = eng._empty((T, G), torch.float64)
         self.odds = eng._empty((T, G), torch.float64)
         self.crit = eng._empty((T, G, 2), torch.int32) if permutations > 0 else None
         self.r = eng._empty((T, G), torch.int32) if permutations > 0 else None
         self.tiles = self.scratch = self.perms = self.lcrit = None
+        self.auto = None        # engine.associate's cached hipGraph of a launch-bound step
         self.batch = 0
         if permutations > 0 and use_lists:
             self.batch = eng.list_batch(T, N, permutations, G)
@@ -305,16 +323,35 @@ class AssociationEngine:
         return r
 
     # -- a3: counts -----------------------------------------------------------
-    def counts(self, genes, traits, masks, out=None):
+    def trait_plan(self, traits, masks, N, out=None):
+        """Margins, mask classes and the gathered operand rows of a trait set (scoary_trait_plan),
+        once per trait set.  ``out`` = (margins, mask_class, plan buffer) to fill."""
         torch = _torch()
         T = traits.shape[0]
-        counts, margins = out if out is not None else (
-            self._empty((T, genes.G, 4), torch.int32), self._empty((T, 2), torch.int32))
-        self._check(self.lib.scoary_counts(self.h, self._ptr(genes.tiled), self._ptr(traits),
-                                           self._ptr(masks), genes.G, T, genes.N,
-                                           self._ptr(counts), self._ptr(margins), self._stream()),
-                    "scoary_counts")
-        return counts, margins
+        margins, mask_class, buf = out if out is not None else (
+            self._empty((T, 2), torch.int32), self._empty((T,), torch.int32),
+            self._empty((int(self.lib.scoary_trait_plan_bytes(int(T), int(N))) // 4,), torch.int32))
+        self._check(self.lib.scoary_trait_plan(self.h, self._ptr(traits), self._ptr(masks), T, int(N),
+                                               self._ptr(margins), self._ptr(mask_class), self._ptr(buf),
+                                               self._stream()), "scoary_trait_plan")
+        return TraitPlan(margins, mask_class, buf, traits, masks, N)
+
+    def counts(self, genes, traits, masks, out=None, plan=None):
+        """-> (counts int32 [T, G, 4], margins int32 [T, 2]).  ``plan``: the TraitPlan of these
+        traits / masks (trait_plan); without one it is built here (three more small launches).
+        ``out`` = (counts[, margins, mask_class, plan buffer]): buffers to fill."""
+        torch = _torch()
+        T = traits.shape[0]
+        counts = out[0] if out is not None else self._empty((T, genes.G, 4), torch.int32)
+        if plan is None:
+            plan = self.trait_plan(traits, masks, genes.N,
+                                   out=None if out is None or len(out) < 4 else tuple(out[1:4]))
+        elif not plan.fits(traits, masks) or plan.N != genes.N:
+            raise ValueError("the trait plan was built from other trait / mask tensors")
+        self._check(self.lib.scoary_counts_planned(
+            self.h, self._ptr(genes.tiled), self._ptr(plan.buf), self._ptr(plan.margins),
+            genes.G, T, genes.N, self._ptr(counts), self._stream()), "scoary_counts_planned")
+        return counts, plan.margins
 
     # -- a5: Fisher -----------------------------------------------------------
     def fisher(self, tables, want_crit=True, out=None, lists=None, lcrit=None):
@@ -422,13 +459,53 @@ class AssociationEngine:
         small launch-bound workloads need anyway)."""
         return Workspace(self, genes, T, permutations, use_lists, perm_buffer)
 
+    # -- launch-bound steps: automatic hipGraph replay -----------------------------
+    AUTO_GRAPH_MAX_TESTS = 5e8      # ~0.5 ms of kernels at 1e12 tests/s: below it launches dominate
+
+    def auto_graph_eligible(self, genes, T, permutations):
+        """A step this small is bound by its five kernel launches (cfg2: 0.112 ms eager, 0.064 ms
+        as one graph launch, profiles/r03_bench_cfg2*.json): associate() then records it into a
+        hipGraph on its second call with the same buffers and replays it from the third on.
+        SCOARY_AUTO_GRAPH=0 switches it off."""
+        import os
+        if os.environ.get("SCOARY_AUTO_GRAPH", "1") == "0":
+            return False
+        return float(genes.G) * int(T) * max(int(permutations), 1) <= self.AUTO_GRAPH_MAX_TESTS
+
+    def _auto_graph(self, genes, traits, masks, permutations, seed, use_lists, ws, plan):
+        """The cached-graph path of associate(): returns the result dict, or None for 'run eagerly'."""
+        torch = _torch()
+        if getattr(self, "_timing", False) or torch.cuda.is_current_stream_capturing():
+            return None
+        L = genes.lists
+        key = (genes.tiled.data_ptr(), L.idx.data_ptr() if L is not None else 0, traits.data_ptr(),
+               masks.data_ptr(), plan.margins.data_ptr(), plan.mask_class.data_ptr(), genes.G, genes.N,
+               int(traits.shape[0]), int(permutations), int(seed), bool(use_lists))
+        st = ws.auto
+        if st is None or st["key"] != key:
+            if st is not None and st["graph"] is not None:
+                st["graph"].close()
+            ws.auto = {"key": key, "calls": 1, "graph": None, "res": None}
+            return None                                   # first call with these buffers: eager
+        if st["graph"] is None:                           # second call: record (runs the step as well)
+            st["graph"], st["res"] = self.capture(genes, traits, masks, permutations, seed, ws,
+                                                  use_lists=use_lists, plan=plan)
+            # the capture ran on its own stream: order the caller's stream behind it
+            torch.cuda.current_stream(self.device).wait_stream(st["graph"].stream)
+            return st["res"]
+        st["graph"].launch()
+        return st["res"]
+
     def associate(self, genes, traits, masks, permutations=0, seed=0, perm_buffer=None,
-                  use_lists=None, workspace=None):
+                  use_lists=None, workspace=None, plan=None, graph=None):
         """counts -> Fisher -> (optional) permutation exceedance counts.
         Returns dict of device tensors: counts [T,G,4], margins [T,2],
         p / odds [T,G], r [T,G] (uint32 bit pattern in int32) or None.  With
         ``workspace`` the result tensors are the workspace's (overwritten by the
-        next step that uses it)."""
+        next step that uses it).  ``plan``: the TraitPlan of these traits (trait_plan, once
+        per trait set); without one every step rebuilds it (one more small launch).  With a
+        workspace AND a plan, a launch-bound step (auto_graph_eligible) is recorded into a
+        hipGraph on its second call and replayed afterwards; ``graph=False`` keeps it eager."""
         torch = _torch()
         T = traits.shape[0]
         if use_lists is None:
@@ -441,7 +518,15 @@ class AssociationEngine:
             ws = Workspace(self, genes, T, permutations, use_lists, perm_buffer)
         elif not ws.fits(genes, T, permutations, use_lists):
             raise ValueError("workspace was made for another problem shape")
-        counts, margins = self.counts(genes, traits, masks, out=(ws.counts, ws.margins))
+        # launch-bound steps with persistent buffers (workspace + plan): replay a cached hipGraph
+        # (graph=None: automatic; False: never -- capture() itself, per-kernel timing)
+        if graph is None and workspace is not None and plan is not None and perm_buffer is None \
+                and self.auto_graph_eligible(genes, T, permutations):
+            res = self._auto_graph(genes, traits, masks, permutations, seed, use_lists, ws, plan)
+            if res is not None:
+                return res
+        counts, margins = self.counts(genes, traits, masks,
+                                      out=(ws.counts, ws.margins, ws.mask_class, ws.plan_buf), plan=plan)
         if permutations > 0 and use_lists:
             # The first batch of label tiles needs only the trait margins, not the
             # Fisher pass: generate it on a side stream while k_fisher runs.
@@ -478,7 +563,7 @@ class AssociationEngine:
                 done += nb
         return {"counts": counts, "margins": margins, "p": p, "odds": odds, "crit": crit, "r": r}
 
-    def capture(self, genes, traits, masks, permutations, seed, workspace, use_lists=None):
+    def capture(self, genes, traits, masks, permutations, seed, workspace, use_lists=None, plan=None):
         """Record one associate() step into a hipGraph (scoary_graph_*): returns
         (StepGraph, result dict).  The results live in ``workspace``; ``launch()``
         recomputes them with a single graph launch.  The step is run once eagerly
@@ -490,7 +575,7 @@ class AssociationEngine:
         if torch.cuda.is_current_stream_capturing():
             raise _abi.ScoaryHipError("capture(): the current stream is already capturing")
         self.associate(genes, traits, masks, permutations=permutations, seed=seed,
-                       use_lists=use_lists, workspace=workspace)
+                       use_lists=use_lists, workspace=workspace, plan=plan, graph=False)
         torch.cuda.synchronize(self.device)
         stream = torch.cuda.Stream(device=self.device)      # a fresh stream: never mid-capture
         with torch.cuda.stream(stream):
@@ -498,7 +583,7 @@ class AssociationEngine:
             failed = True
             try:
                 res = self.associate(genes, traits, masks, permutations=permutations, seed=seed,
-                                     use_lists=use_lists, workspace=workspace)
+                                     use_lists=use_lists, workspace=workspace, plan=plan, graph=False)
                 failed = False
             finally:
                 # the capture must be ended either way; a graph that came out of a failed step
@@ -610,6 +695,7 @@ class AssociationEngine:
     # -- timing (bench.py) ------------------------------------------------------
     def set_timing(self, on):
         self._check(self.lib.scoary_set_timing(self.h, 1 if on else 0), "scoary_set_timing")
+        self._timing = bool(on)          # per-kernel events: steps run eagerly (no graph replay)
 
     def kernel_ms(self, name):
         ms = ctypes.c_double()

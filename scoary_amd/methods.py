@@ -612,6 +612,7 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
     G, N, T = len(table), len(table.strains), tarr.shape[0]
     trv = eng.vecrows(pack_bits_rows(tarr == 1), N)
     mkv = eng.vecrows(pack_bits_rows(tarr != 2), N)
+    plan = eng.trait_plan(trv, mkv, N)            # margins + mask classes: once per trait set
 
     def local(a, b):
         if b <= a:
@@ -635,13 +636,13 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
                      "using the dense permutation kernels" % (N, eng.lib.scoary_list_max_isolates()))
         if early_abort and permutations > 0:
             from . import tree as T_
-            res = eng.associate(gm, trv, mkv, permutations=0)
+            res = eng.associate(gm, trv, mkv, permutations=0, plan=plan)
             crit = eng.fisher(res["counts"], want_crit=True)[2]
             r, nstop = eng.permute_sequential(gm, mkv, res["margins"], crit, permutations, seed,
                                               T_._abort_thresholds(permutations))
             res["r"] = r
             return eng.pack_records(res, nstop=nstop)
-        res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed)
+        res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed, plan=plan)
         return eng.pack_records(res)
 
     out = dist.numpy_records(dist.associate_sharded(local, G))

@@ -18,13 +18,18 @@ CONFIGS = {
 def make_genes(G, N, rng, kind="uniform", core_frac=0.0, block=4096):
     """(G, N) uint8 presence matrix.  kind="uniform": gene frequency
     f_g ~ U(0.02, 0.98); kind="rare": minor-allele frequency ~ Beta(0.3, 3)
-    (VCF-like).  core_frac of the genes are forced all-present / all-absent
+    (VCF-like); kind="ushaped": f_g ~ Beta(0.15, 0.15) (U-shaped pan-genome spectrum).  core_frac of the genes are forced all-present / all-absent
     (alternating) to exercise the skip rule (methods.py:804-814)."""
     out = np.empty((G, N), dtype=np.uint8)
     for g0 in range(0, G, block):
         g1 = min(G, g0 + block)
         if kind == "rare":
             f = rng.beta(0.3, 3.0, size=(g1 - g0, 1)).astype(np.float32)
+        elif kind == "ushaped":
+            # pan-genome-like gene-frequency spectrum: most genes rare (cloud / shell) or near-core,
+            # few at intermediate frequency -- Beta(0.15, 0.15); not a BASELINE config, an evidence
+            # line next to cfg3 (bench.py --gene-kind ushaped)
+            f = rng.beta(0.15, 0.15, size=(g1 - g0, 1)).astype(np.float32)
         else:
             f = rng.uniform(0.02, 0.98, size=(g1 - g0, 1)).astype(np.float32)
         out[g0:g1] = rng.random((g1 - g0, N), dtype=np.float32) < f
@@ -47,7 +52,7 @@ def make_traits(T, N, rng, prevalence=None, missing_traits=(), missing_frac=0.01
     return tr
 
 
-def make_config(name, G=None, N=None, T=None):
+def make_config(name, G=None, N=None, T=None, gene_kind=None):
     """Returns (genes[G,N] uint8, traits[T,N] uint8 (2 = missing), P, seed).
     G/N/T override the config's sizes (for small parity cases of the same
     distribution)."""
@@ -59,6 +64,12 @@ def make_config(name, G=None, N=None, T=None):
     if T is not None:
         c["T"] = T
     rng = np.random.default_rng(c["seed"])
+    if gene_kind is not None:       # the config's shape and traits over another gene-frequency spectrum
+        genes = make_genes(c["G"], c["N"], rng, kind=gene_kind,
+                           core_frac=0.05 if name in ("cfg3", "cfg5") else 0.0)
+        traits = make_traits(c["T"], c["N"], rng, prevalence={"cfg2": 0.35, "cfg4": 0.3}.get(name),
+                             missing_traits=(8, 9) if name in ("cfg3", "cfg5") else ())
+        return genes, traits, c["P"], c["seed"]
     if name == "cfg2":
         genes = make_genes(c["G"], c["N"], rng)
         traits = make_traits(c["T"], c["N"], rng, prevalence=0.35)

@@ -132,8 +132,9 @@ SEG_N = [20480, 20481, 31000, 40704, 40705, 61111, 100003, 131070]
 def seglists_case(eng, case, seed=57):
     """Segmented lists (N > 20479: one sub-list per gene and 20 352-isolate segment, no host
     builder to compare with): order / flip of the whole row, and every sub-list holds exactly the
-    gene's minority positions of its segment as LDS addresses ((row - segment start) * 8),
-    padded with the segment's zero row to the wave group's common length."""
+    gene's minority positions of its segment as 16-bit row indices (row - segment start), in
+    grid-compaction order (class-aligned while every residue class has positions left), padded
+    with the segment's zero row to the wave group's common length."""
     rng = np.random.default_rng([seed, case])
     N = int(rng.choice(SEG_N))
     G = int(rng.choice([1, 3, 63, 64, 65, 130, 300]))
@@ -146,8 +147,8 @@ def seglists_case(eng, case, seed=57):
     gm = eng.pack_dense(genes)
     L = eng.build_lists(gm)
     S, SEG = int(eng.lib.scoary_list_segments(N)), 20352
-    idx = L.idx.cpu().numpy().view(np.uint32)
-    start = L.start.cpu().numpy().astype(np.int64).reshape(S, G) * 32
+    idx = L.idx.cpu().numpy().view(np.uint16)                      # 16-bit entries: row index in the segment
+    start = L.start.cpu().numpy().astype(np.int64).reshape(S, G) * 64
     nhalf = L.ngroups.cpu().numpy().astype(np.int64).reshape(S, G)
     order, flipped = L.order.cpu().numpy(), L.flipped.cpu().numpy()
     ones = genes.sum(1, dtype=np.int64)
@@ -162,12 +163,14 @@ def seglists_case(eng, case, seed=57):
         for s in range(S):
             n_s = min(SEG, N - s * SEG)
             n = np.arange(nhalf[s, q * 64] * 16)
-            at = start[s, q * 64] + ((n // 4) * 64 + j) * 4 + n % 4
+            at = start[s, q * 64] + ((n // 8) * 64 + j) * 8 + n % 8
             vals = idx[at]
-            want = np.flatnonzero(minority[s * SEG:s * SEG + n_s]) * 8
+            want = np.flatnonzero(minority[s * SEG:s * SEG + n_s])
+            full = int(np.bincount(want % 32, minlength=32).min()) * 32     # grid rows no class has left yet
             ok = ok and len(want) <= len(vals) and np.array_equal(np.sort(vals[:len(want)]), want) \
-                and bool(np.all(vals[len(want):] == n_s * 8)) and (len(at) == 0 or at.max() < L.entries) \
-                and nhalf[s, k] == nhalf[s, q * 64]
+                and bool(np.all(vals[len(want):] == n_s)) and (len(at) == 0 or at.max() < 2 * L.entries) \
+                and nhalf[s, k] == nhalf[s, q * 64] \
+                and np.array_equal(vals[:full] % 32, (k + np.arange(full)) % 32)
     return bool(ok), "seglists G=%d N=%d %s" % (G, N, dens)
 
 

@@ -26,7 +26,7 @@ def _run(extra):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("extra", [["--cpu-seconds", "0.5"], ["--graph", "--no-cpu-baseline"],
+@pytest.mark.parametrize("extra", [["--cpu-seconds", "0.5"], ["--no-graph", "--no-cpu-baseline"],
                                    ["--kernel", "dense", "--no-cpu-baseline"]])
 def test_bench_json_contract(extra):
     d = _run(extra)
@@ -70,7 +70,10 @@ def test_bench_json_contract(extra):
     assert r["ops_per_clock"] is None                       # needs the counters: refused on an overridden shape
     assert r["kernel"] == k3 and d["kernel_ms"][k3] > 0
     assert sum(d["kernel_ms"].values()) < 3 * d["ms_per_step"]
-    assert d["config"]["hip_graph"] == ("--graph" in extra)
+    # 3000 x 10 x 1024 = 3e7 tests per step: launch-bound, so the step is replayed as a hipGraph by
+    # default (AssociationEngine.auto_graph_eligible) unless --no-graph asks for eager launches
+    assert d["config"]["hip_graph"] == ("--no-graph" not in extra)
+    assert d["config"]["hip_graph_auto"] == ("--no-graph" not in extra)
     if "--no-cpu-baseline" not in extra:
         for name in ("cpu_baseline", "cpu_baseline_port"):
             c = d[name]

@@ -96,6 +96,55 @@ def test_counts_bit_exact(eng, orc, G, N, T):
     assert np.array_equal(m[:, 1], (traits != 2).sum(1))
 
 
+@pytest.mark.parametrize("G,N,T,pattern", [(300, 333, 50, "shared"), (130, 700, 70, "mixed"), (65, 129, 33, "distinct"),
+                                           (1000, 64, 17, "mixed"), (64, 10000, 50, "shared"), (500, 2000, 4, "mixed")])
+def test_counts_one_pass_many_traits_and_mask_classes(eng, orc, G, N, T, pattern):
+    """K1, round 4: up to 32 traits per pass over the gene matrix (T = 50:
+    two balanced passes of 25, T = 70: three), the quads of a row split over four wavefronts and
+    reduced in LDS, and popc(gene & valid) counted once per class of identical validity rows
+    (scoary_trait_plan) -- against the isolate-by-isolate restatement of Perform_statistics
+    (scoary/methods.py:940-965) for every (gene, trait); the plan's classes against numpy; and
+    the one-call scoary_counts (no classes) bit-identical to the planned call."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(G + N + T)
+    genes, traits = _random_case(rng, G, N, T, missing=False)
+    if pattern == "shared":                                   # like cfg3 / cfg5: two traits with missing values
+        for t in (T - 2, T - 1):
+            traits[t, rng.random(N) < 0.01] = 2
+    elif pattern == "distinct":                               # every trait its own mask
+        for t in range(T):
+            traits[t, rng.random(N) < 0.05] = 2
+    else:                                                     # a few masks, shared in an irregular order
+        holes = [rng.random(N) < 0.04 for _ in range(3)]
+        for t in range(T):
+            k = int(rng.integers(0, 4))
+            if k < 3:
+                traits[t, holes[k]] = 2
+    tb, mb = _bits(eng, traits)
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    plan = eng.trait_plan(trv, mkv, N)
+    valid = traits != 2
+    want_cls = np.array([min(u for u in range(t + 1) if np.array_equal(valid[u], valid[t])) for t in range(T)])
+    assert np.array_equal(plan.mask_class.cpu().numpy(), want_cls)
+    m = plan.margins.cpu().numpy()
+    assert np.array_equal(m[:, 0], (traits == 1).sum(1)) and np.array_equal(m[:, 1], valid.sum(1))
+    counts, margins = eng.counts(gm, trv, mkv, plan=plan)
+    got = counts.cpu().numpy()
+    want = np.stack([orc.counts_dense(genes, traits[t]) for t in range(T)])
+    assert np.array_equal(got, want)
+    # the one-call form of the C-ABI: plan (without classes) + tables
+    c2 = torch.full((T, G, 4), -7, dtype=torch.int32, device=eng.device)
+    m2 = torch.zeros((T, 2), dtype=torch.int32, device=eng.device)
+    vp = ctypes.c_void_p
+    rc = eng.lib.scoary_counts(eng.h, vp(gm.tiled.data_ptr()), vp(trv.data_ptr()), vp(mkv.data_ptr()), G, T, N,
+                               vp(c2.data_ptr()), vp(m2.data_ptr()), eng._stream())
+    assert rc == 0 and torch.equal(c2, counts) and torch.equal(m2, plan.margins)
+    with pytest.raises(ValueError):                           # a plan belongs to the tensors it was built from
+        eng.counts(gm, trv.clone(), mkv, plan=plan)
+
+
 def test_counts_all_missing_and_constant_traits(eng, orc):
     rng = np.random.default_rng(4)
     genes, _ = _random_case(rng, 200, 150, 1)
@@ -446,7 +495,7 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_list_params(5000, params) == 0 and list(params) == [8, 32, 32, 8, 8]
     assert lib.scoary_list_params(5120, params) == 0 and list(params) == [4, 16, 64, 16, 4]
     assert lib.scoary_list_params(10240, params) == 0 and list(params) == [2, 8, 64, 32, 4]
-    assert lib.scoary_list_params(20480, params) == 0 and list(params) == [2, 8, 64, 32, 4]   # 2 segments
+    assert lib.scoary_list_params(20480, params) == 0 and list(params) == [2, 8, 64, 32, 8]   # 2 segments: 16-bit entries, 8 per vector
     assert lib.scoary_list_params(131071, params) == -3 and params[0] == 0
     assert lib.scoary_list_max_isolates() == 131070
     assert [lib.scoary_list_segments(n) for n in (1, 20479, 20480, 40704, 40705, 122112, 122113, 131070, 131071)] \
@@ -898,8 +947,9 @@ def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
     64-permutation tile one segment at a time, every gene has one sub-list per segment and the
     counter planes live across the reloads (k_permute_seglists).  Checked: (1) the label tiles
     hold the rows of k_perm_generate, every segment with its own zero row; (2) every sub-list
-    holds exactly the gene's minority positions of that segment, as LDS addresses, zero-row
-    padded; (3) r is bit-identical to the dense kernels' and to the oracle's."""
+    holds exactly the gene's minority positions of that segment, as 16-bit row indices in
+    grid-compaction order, zero-row padded; (3) r is bit-identical to the dense kernels' and to
+    the oracle's."""
     rng = np.random.default_rng(G + N)
     genes, traits = _random_case(rng, G, N, T)
     genes[5] = (rng.random(N) < 0.0005)                   # sub-lists that are empty in a segment
@@ -909,7 +959,7 @@ def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
     trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
     S = int(eng.lib.scoary_list_segments(N))
     SEG, STRIDE = 20_352, 40_708
-    assert S == -(-N // SEG) and eng.list_params(N) == (2, 8, 64, 32, 4)
+    assert S == -(-N // SEG) and eng.list_params(N) == (2, 8, 64, 32, 8)
     # (1) tiles: [T][tiles][S][STRIDE dwords], row r of segment s = dwords 2r, 2r + 1
     _, margins = eng.counts(gm, trv, mkv)
     rows = eng.perm_generate(mkv, margins, N, P, 3, 17).cpu().numpy().view(np.uint32)
@@ -930,8 +980,10 @@ def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
             assert not tb_[:, tile, :n_s, hi - lo:].any()
     # (2) lists
     L = eng.build_lists(gm)
-    idx = L.idx.cpu().numpy().view(np.uint32)
-    start = L.start.cpu().numpy().astype(np.int64).reshape(S, G) * 32
+    # 16-bit entries (round 4): the row index inside the segment, eight per lane and 16-byte index
+    # vector; start counts 128-byte units = 64 entries; L.entries counts 32-bit words
+    idx = L.idx.cpu().numpy().view(np.uint16)
+    start = L.start.cpu().numpy().astype(np.int64).reshape(S, G) * 64
     nhalf = L.ngroups.cpu().numpy().astype(np.int64).reshape(S, G)
     order, flipped = L.order.cpu().numpy(), L.flipped.cpu().numpy()
     ones = genes.sum(1, dtype=np.int64)
@@ -945,13 +997,18 @@ def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
         for s in range(S):
             n_s = min(SEG, N - s * SEG)
             n = np.arange(nhalf[s, q * 64] * 16)
-            at = start[s, q * 64] + ((n // 4) * 64 + j) * 4 + n % 4
+            at = start[s, q * 64] + ((n // 8) * 64 + j) * 8 + n % 8
             vals = idx[at]
-            want = np.flatnonzero(minority[s * SEG:s * SEG + n_s]) * 8
+            want = np.flatnonzero(minority[s * SEG:s * SEG + n_s])
             assert np.array_equal(np.sort(vals[:len(want)]), want)
-            assert np.all(vals[len(want):] == n_s * 8)
+            assert np.all(vals[len(want):] == n_s)
             assert nhalf[s, k] == nhalf[s, q * 64] and start[s, k] == start[s, q * 64]
-            assert len(at) == 0 or at.max() < L.entries
+            assert len(at) == 0 or at.max() < 2 * L.entries
+            # grid-compaction order: while every residue class (position mod 32) still has a
+            # position, entry e comes from class (k + e) mod 32 -- 32 genes, 32 distinct bank slots
+            cls = np.bincount(want % 32, minlength=32)
+            full = int(cls.min()) * 32
+            assert np.array_equal(vals[:full] % 32, (k + np.arange(full)) % 32)
     # (3) r
     dense = eng.associate(gm, trv, mkv, permutations=P, seed=9, use_lists=False)
     res = eng.associate(gm, trv, mkv, permutations=P, seed=9, use_lists=True)

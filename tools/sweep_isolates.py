@@ -30,7 +30,7 @@ def timed(eng, gm, trv, mkv, P, use_lists, steps=6, warmup=2):
         eng.associate(gm, trv, mkv, permutations=P, seed=3, use_lists=use_lists, workspace=ws)
     torch.cuda.synchronize()
     step_ms = (time.perf_counter() - t0) / steps * 1e3
-    k_ms = eng.kernel_ms("k_permute_lists" if use_lists else "k_permute")
+    k_ms = eng.kernel_ms(eng.list_kernel_name(gm.N) if use_lists else "k_permute")
     eng.set_timing(False)
     return step_ms, k_ms
 
