@@ -637,7 +637,8 @@ def small_kernel_rooflines(args, G, N, T, n_mask_classes, kernel_ms):
         out["roofline_k1"] = {
             "kernel": "k_counts", "bound": "hbm" if hbm_floor >= valu_floor else "valu",
             "bytes": b1, "bytes_formula": "8*W*G + 16*W*T + 16*G*T (SURVEY 8d B1), W = ceil(N/64)",
-            "kernel_ms": t1, "gbs": b1 / sec / 1e9, "hbm_frac": b1 / sec / 1e9 / HBM_PEAK_GBS,
+            "kernel_ms": t1, "timed": "five back-to-back launches of the kernel alone, after the timed region",
+            "gbs": b1 / sec / 1e9, "hbm_frac": b1 / sec / 1e9 / HBM_PEAK_GBS,
             "passes_over_matrix": -(-T // 32), "vectors": vectors, "mask_classes_over_passes": n_mask_classes,
             "valu_lane_ops": ops, "valu_frac": ops / sec / VALU_NOMINAL_LANE_OPS,
             "valu_frac_of_measured_and_bcnt_peak": ops / sec / VALU_PEAK_AND_BCNT,
@@ -656,7 +657,8 @@ def small_kernel_rooflines(args, G, N, T, n_mask_classes, kernel_ms):
             "bytes": b2, "bytes_formula": "32*G*T (SURVEY 8d B2)", "gbs": b2 / sec / 1e9,
             "hbm_frac": b2 / sec / 1e9 / HBM_PEAK_GBS,
             "valu_insts_per_table": None if not ctr else ctr["SQ_INSTS_VALU"] * 64.0 / (G * T),
-            "overlapped": "runs on the main stream under the label-tile generator (side stream)",
+            "in_step": "runs on the main stream while the label-tile generator has the side stream: "
+                       "kernel_ms here is the kernel alone, kernel_ms['k_fisher'] of the line the shared one",
             "counters_source": ctr["source"] if ctr else None}
     return out
 
@@ -861,6 +863,22 @@ def main():
         ("k_perm_generate", "k_permute"))
     kernel_ms = {k: eng.kernel_ms(k) for k in names}
     eng.set_timing(False)
+    # K1 and K2 by themselves (roofline_k1 / roofline_k2): inside a step k_fisher shares the chip with
+    # the label-tile generator on the side stream, so its in-step duration is not its own
+    iso = {}
+    for name, fn in (("k_counts", lambda: eng.counts(gm, trv, mkv, out=(ws.counts,), plan=plan)),
+                     ("k_fisher", lambda: eng.fisher(ws.counts, out=(ws.p, ws.odds, ws.crit),
+                                                     **({"lists": gm.lists, "lcrit": ws.lcrit} if use_lists and P > 0
+                                                        else {})))):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        e1.synchronize()
+        iso[name] = e0.elapsed_time(e1) / 5
 
     dt_own = dt
     per_rank = None
@@ -962,8 +980,9 @@ def main():
         }
         cls = plan.mask_class.cpu().numpy()
         tpp = int(eng.lib.scoary_counts_traits_per_pass(T))       # classes are counted once per PASS
+        out["kernel_ms_isolated"] = iso            # five back-to-back launches of the kernel alone
         out.update(small_kernel_rooflines(
-            args, G, N, T, sum(len(np.unique(cls[a:a + tpp])) for a in range(0, T, tpp)), kernel_ms))
+            args, G, N, T, sum(len(np.unique(cls[a:a + tpp])) for a in range(0, T, tpp)), iso))
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline_port(genes, traits, N, seed, args.cpu_seconds)
             try:

@@ -525,25 +525,21 @@ class AssociationEngine:
             res = self._auto_graph(genes, traits, masks, permutations, seed, use_lists, ws, plan)
             if res is not None:
                 return res
-        lists_path = permutations > 0 and use_lists
-        if lists_path:
-            # The first batch of label tiles needs only the trait margins: it is generated on a
-            # side stream while k_counts and k_fisher run -- forked before k_counts when the
-            # margins come from a plan, after it when this step computes them itself.
-            main = torch.cuda.current_stream(self.device)
-            side = self._side_stream()
-            nb0 = min(ws.batch, permutations)
-            if plan is not None:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self.perm_generate_tiles(masks, plan.margins, genes.N, nb0, 0, seed, out=ws.tiles)
         counts, margins = self.counts(genes, traits, masks,
                                       out=(ws.counts, ws.margins, ws.mask_class, ws.plan_buf), plan=plan)
-        if lists_path:
-            if plan is None:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self.perm_generate_tiles(masks, margins, genes.N, nb0, 0, seed, out=ws.tiles)
+        if permutations > 0 and use_lists:
+            # The first batch of label tiles needs only the trait margins, not the
+            # Fisher pass: generate it on a side stream while k_fisher runs.  (With a plan the
+            # margins are there before k_counts, and the fork could move in front of it: tried,
+            # worth 0.2 % at cfg3 and nothing on the launch-bound shapes, while k_counts then
+            # shares the chip with the generator and its own duration -- the path's one HBM
+            # stream, reported as roofline_k1 -- can no longer be read off the step.)
+            main = torch.cuda.current_stream(self.device)
+            side = self._side_stream()
+            side.wait_stream(main)
+            nb0 = min(ws.batch, permutations)
+            with torch.cuda.stream(side):
+                self.perm_generate_tiles(masks, margins, genes.N, nb0, 0, seed, out=ws.tiles)
             p, odds, crit, lcrit = self.fisher(counts, out=(ws.p, ws.odds, ws.crit),
                                                lists=genes.lists, lcrit=ws.lcrit)
             main.wait_stream(side)

@@ -68,6 +68,18 @@ def test_bench_json_contract(extra):
         assert 50 < tel["sclk_mhz_mean"] < 3000 and 20 < tel["socket_power_w_mean"] < 2000
         assert r["sclk_mhz_mean"] == tel["sclk_mhz_mean"]
     assert r["ops_per_clock"] is None                       # needs the counters: refused on an overridden shape
+    # K1 / K2 carry their own roofline entries, timed by themselves
+    k1, k2 = d["roofline_k1"], d["roofline_k2"]
+    for k in ("kernel", "bound", "bytes", "kernel_ms", "gbs", "hbm_frac", "valu_frac", "hbm_floor_ms", "valu_floor_ms",
+              "frac_of_bound", "traffic", "passes_over_matrix", "vectors"):
+        assert k in k1, k
+    N, W64 = d["config"]["isolates"], -(-d["config"]["isolates"] // 64)
+    assert k1["kernel"] == "k_counts" and k1["bound"] in ("hbm", "valu") and k1["passes_over_matrix"] == 1
+    assert k1["bytes"] == 8 * W64 * G + 16 * W64 * T + 16 * G * T          # B1
+    assert 0 < k1["hbm_frac"] < 1 and 0 < k1["frac_of_bound"] <= 1.05 and k1["vectors"] >= T + 1
+    assert abs(k1["kernel_ms"] - d["kernel_ms_isolated"]["k_counts"]) < 1e-12
+    assert k2["kernel"] == "k_fisher" and k2["tables"] == G * T and k2["bytes"] == 32 * G * T
+    assert k2["tables_per_s"] > 1e6 and 0 < k2["hbm_frac"] < 1
     assert r["kernel"] == k3 and d["kernel_ms"][k3] > 0
     assert sum(d["kernel_ms"].values()) < 3 * d["ms_per_step"]
     # 3000 x 10 x 1024 = 3e7 tests per step: launch-bound, so the step is replayed as a hipGraph by
