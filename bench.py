@@ -333,7 +333,11 @@ def cpu_baseline_port(genes, traits, N, seed, target_s):
     """The C restatement (oracle/oracle.c, OpenMP over genes) on a bounded sample of the
     same workload: all T traits, a gene subsample, P_s permutations; whole path."""
     from oracle import oracle as orc
+    from oracle.scipy_baseline import usable_cpus
     from scoary_amd.engine import pack_bits_rows
+    # OpenMP would start one thread per logical CPU of the HOST (256); the container's cgroup
+    # grants far fewer (16 on the pool's boxes): oversubscribed threads only add switching
+    orc.set_num_threads(min(orc.num_threads(), usable_cpus()))
     cores = orc.num_threads()
     T = traits.shape[0]
     Gs = min(genes.shape[0], 4096)
@@ -350,7 +354,8 @@ def cpu_baseline_port(genes, traits, N, seed, target_s):
     orc.permute_r(gb, tb, mb, N, Ps, seed)
     dt = time.perf_counter() - t0
     return {"value": Gs * T * Ps / dt, "unit": "gene-permutation Fisher tests/s",
-            "cores": cores, "cores_are": "OpenMP threads = logical CPUs (SMT siblings included)",
+            "cores": cores, "cores_are": "OpenMP threads = the logical CPUs this process may use (affinity mask and "
+                                         "cgroup quota applied to os.cpu_count(); SMT siblings included)",
             "kind": "port",
             "sample": "oracle/oracle.c orc_permute_r (bit-packed popcount counts + Fisher weights + "
                       "label permutations + exceedance), %d genes x %d isolates x %d traits x %d "
