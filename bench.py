@@ -101,6 +101,9 @@ def parse(argv=None):
                          "timed region (amdsmi or hwmon); 0 switches it off")
     ap.add_argument("--inject-gather-fault", action="store_true", help=argparse.SUPPRESS)   # tests: corrupt one
     # received record before --verify-gather looks at it; every rank must then exit non-zero, together
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the timed region (single GPU): run the step back to back this long and report "
+                         "the clock / power the box sustains (the `sustained` object); 0 skips it")
     ap.add_argument("--dry-exchange", action="store_true",
                     help="CPU-only check of the launcher + exchange path (gloo, fabricated "
                          "records, no kernels): what tests/test_dist_gloo.py drives")
@@ -611,11 +614,18 @@ def roofline_report(args, eng, use_lists, G, N, T, P, pbatch, k3_name, k3_ms, ad
                                  "(kernel time x sclk_mhz_mean)); nominal 256 CU x 4 SIMD x 32 = 32768")
     out["ops_per_clock_frac"] = None if out["ops_per_clock"] is None else out["ops_per_clock"] / 32768.0
     out["useful_ops_per_clock"] = None if (useful is None or not sclk) else useful / (sec * sclk * 1e6)
-    out["clock_note"] = ("sclk_mhz_mean / socket_power_w_mean are this run's; under sustained load the list "
-                         "kernel sits at the socket power cap (1.31-1.38 kW, 2.14-2.22 of 2.4 GHz: "
-                         "profiles/r03_clock_power.txt), a 0.1 s timed region may not have reached it") \
+    out["clock_note"] = ("sclk_mhz_mean / socket_power_w_mean are amdsmi's readings during this run's timed region; "
+                         "inside a 0.1 s region after an idle GPU they are not yet calibrated (the power is a moving "
+                         "average on its way up, the clock reading varies 1.7-2.2 GHz between runs of equal kernel time): "
+                         "the `sustained` object of the line is the box's figure -- under sustained load the list kernel "
+                         "sits at the socket power cap, 1.33-1.36 kW at 2.19-2.21 GHz (cfg5's kernel: 1.90 GHz)") \
         if use_lists else None
     return out
+
+
+def ctr_lane_ops(roofline):
+    """VALU lane-ops per launch behind roofline['achieved'] (T lane-ops/s x kernel seconds)."""
+    return roofline["achieved"] * 1e12 * roofline["kernel_ms"] * 1e-3
 
 
 def small_kernel_rooflines(args, G, N, T, n_mask_classes, kernel_ms):
@@ -885,6 +895,30 @@ def main():
         e1.synchronize()
         iso[name] = e0.elapsed_time(e1) / 5
 
+    # The box under SUSTAINED load (single GPU, outside the timed region, GPU still warm): the same
+    # step back to back for --sustain-seconds, clock and power from the second half of the window.
+    # amdsmi's readings inside a 0.1 s region that follows an idle GPU are not a calibrated clock
+    # (1.73 ... 2.22 GHz reported across runs whose kernel times agree to 0.5 %; the socket power
+    # is a moving average still on its way up); after a second at the power cap they are
+    # (2.19-2.21 GHz at 1.33-1.36 kW, as rocm-smi says).  This is what tells a slow box from a
+    # slow kernel: the sustained clock the box grants this kernel, and lane-ops per that clock.
+    sustained = None
+    if args.sustain_seconds > 0 and not sharded and median_ms and median_ms < 200.0 and tele is not None:
+        tele2 = Telemetry(local_rank, period_s=0.01).start()
+        s0 = time.perf_counter()
+        nsteps = 0
+        burst = max(1, int(50.0 / median_ms))                 # ~50 ms of steps per synchronize
+        while time.perf_counter() - s0 < args.sustain_seconds:
+            for _ in range(burst):
+                step()
+            nsteps += burst
+            torch.cuda.synchronize()
+        s1 = time.perf_counter()
+        sustained = tele2.stop(s0 + 0.5 * (s1 - s0), s1)
+        sustained.update({"steps": nsteps, "seconds": s1 - s0, "ms_per_step": (s1 - s0) / nsteps * 1e3,
+                          "value": G * T * P * nsteps / (s1 - s0),
+                          "what": "the same step back to back after the timed region; clock / power over the "
+                                  "second half of the window"})
     dt_own = dt
     per_rank = None
     if sharded:                                      # MAX over ranks
@@ -985,6 +1019,17 @@ def main():
         }
         cls = plan.mask_class.cpu().numpy()
         tpp = int(eng.lib.scoary_counts_traits_per_pass(T))       # classes are counted once per PASS
+        out["kernel_source_sha256"] = kernel_source_sha()      # same hash + another time = another box
+        if sustained is not None:
+            v = out["roofline"].get("achieved")
+            lane_ops = None if v is None else ctr_lane_ops(out["roofline"])
+            sclk = sustained.get("sclk_mhz_mean")
+            sustained["ops_per_clock_frac"] = None if (lane_ops is None or not sclk) else (
+                lane_ops / (out["roofline"]["kernel_ms"] * 1e-3 * sclk * 1e6) / 32768.0)
+            sustained["ops_per_clock_note"] = ("SQ_INSTS_VALU x 64 / (the timed region's kernel time x the sustained "
+                                               "clock) / 32768: what the kernel issues per clock if the timed region "
+                                               "already ran at the sustained clock")
+        out["sustained"] = sustained
         out["kernel_ms_isolated"] = iso            # five back-to-back launches of the kernel alone
         out.update(small_kernel_rooflines(
             args, G, N, T, sum(len(np.unique(cls[a:a + tpp])) for a in range(0, T, tpp)), iso))

@@ -424,25 +424,6 @@ __global__ __launch_bounds__(256) void k_lists_crit(const uint2* __restrict__ cr
   out[(int64_t)t * G + k] = o;
 }
 
-// Which (trait, tile) column and which chunk of wave groups a block of k_permute_seglists works on.
-// The dispatcher places block b on XCD b % 8 and every XCD has its own 4 MB L2: with a plain
-// (tile fastest, chunk) grid the eight XCDs walk the SAME chunk of index lists at the same time and
-// each L2 fetches its own copy from the Infinity Cache / HBM.  The segmented kernel lives on that
-// stream (round 3: 8.4 GB of fetches per 1.87 ms launch at 20 000 x 50 000), so its grid is
-// one-dimensional, nx * 8 * ceil(ny / 8) blocks, and every XCD takes ONE chunk of each row of eight
-// -- the nx (trait, tile) blocks of a chunk share one L2 -- rows alternately forwards and backwards
-// (chunks hold ever shorter lists: XCD 0 would get the longest of every row).  Blocks whose chunk
-// does not exist leave at once.  (k_permute_lists keeps the two-dimensional grid: it is VALU-bound,
-// and the static split cost it 2-3 % in balance, profiles/r03_ab_xcd_block_map.txt.)
-struct SegJob { int bx, by; bool exists; };
-__device__ __forceinline__ SegJob seg_block_job(int ngroups, int groups_per_block) {
-  const int ny = (ngroups + groups_per_block - 1) / groups_per_block;       // chunks
-  const uint32_t nx = gridDim.x / (8u * (uint32_t)((ny + 7) / 8));          // (trait, tile) columns
-  const uint32_t b = blockIdx.x, xcd = b & 7u, k = b >> 3;
-  const uint32_t row = k / nx;
-  const int by = (int)row * 8 + (int)((row & 1u) ? 7u - xcd : xcd);
-  return SegJob{(int)(k % nx), by, by < ny};
-}
 // lane id from v_mbcnt, opaque to the optimiser (see its use in k_permute_lists)
 __device__ __forceinline__ int fresh_lane() {
   int l;
@@ -702,16 +683,20 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
   scoary_bank_defs();
   constexpr int LPG = 1, NW = kSegTW, TW = kSegTW, GPW = kWave;
   static_assert(kSegTW == 2, "two permutation words per lane");
+  // Grid as in k_permute_lists: (trait, tile) fastest, chunk of wave groups in y -- the dispatcher
+  // hands the next block to whichever CU is free.  (Round 4 also tried the XCD-aware map of
+  // tools/xcd_map.patch here, every XCD one chunk of each row of eight: FETCH 4.2 -> 0.8 GB per
+  // launch at 20 000 x 50 000 and no gain in time -- with 16-bit entries the kernel is no longer
+  // fetch-bound -- and a 3x LOSS whenever there are fewer than eight chunks, XCDs standing idle:
+  // 2432 genes x 40 959 isolates x 4 traits, P = 8192, 2.7 -> 9.1 ms.  Dropped.)
   const int ngroups = (G + GPW - 1) / GPW;
-  const SegJob job = seg_block_job(ngroups, groups_per_block);
-  if (!job.exists) return;
-  const int t = job.bx / ntiles, tile = job.bx % ntiles;
+  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q_lo = job.by * groups_per_block;
+  const int q_lo = blockIdx.y * groups_per_block;
   const int q_hi = min(ngroups, q_lo + groups_per_block);
   const uint32_t lane_off = (uint32_t)lane * 16u;
-  uint16_t* out = partial + (int64_t)job.bx * ((int64_t)ngroups * GPW);
+  uint16_t* out = partial + (int64_t)blockIdx.x * ((int64_t)ngroups * GPW);
   struct alignas(16) Ent { uint32_t e[4]; };
   constexpr int kListLoadPolicy = SCOARY_LIST_LOAD_POLICY;
   struct Group { int nhalf, last; __amdgpu_buffer_rsrc_t rsrc; };
@@ -733,7 +718,7 @@ __global__ __launch_bounds__(1024) void k_permute_seglists(const uint32_t* __res
   };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile_lds;
   const uint32_t three = 3u;                             // SDWA shift amount (an SGPR operand)
-  const uint32_t* src = tiles + (int64_t)job.bx * ((int64_t)nseg * kSegStride);
+  const uint32_t* src = tiles + (int64_t)blockIdx.x * ((int64_t)nseg * kSegStride);
   // rounds and segments are block-uniform: every wavefront meets every barrier, whether or not
   // it has a wave group in this round
   const int rounds = (q_hi - q_lo + nwaves - 1) / nwaves;
@@ -983,7 +968,7 @@ static int launch_permute_seglists(scoary_handle h, hipStream_t s, const uint32_
                        (int)G, reinterpret_cast<uint2*>(d_lcrit_sc));
   }
   const ListGeom g = list_geom(h->num_cu, G, T, N, P, entries);
-  if (T * g.ntiles * 8 * ((g.chunks + 7) / 8) > 0x7fffffffLL)
+  if (T * g.ntiles > 0x7fffffffLL || g.chunks > 65535)
     return fail(h, SCOARY_ERR_SIZE, "scoary_permute_lists: grid too large");
   const size_t lds = (size_t)kSegStride * sizeof(uint32_t);
   const void* fn = reinterpret_cast<const void*>(&k_permute_seglists<KC>);
@@ -999,8 +984,7 @@ static int launch_permute_seglists(scoary_handle h, hipStream_t s, const uint32_
   }
   {
     KernelTimer kt(h, s, "k_permute_seglists");
-    // one-dimensional, XCD-aware grid (seg_block_job)
-    hipLaunchKernelGGL((k_permute_seglists<KC>), dim3((unsigned)(T * g.ntiles * 8 * ((g.chunks + 7) / 8))),
+    hipLaunchKernelGGL((k_permute_seglists<KC>), dim3((unsigned)(T * g.ntiles), (unsigned)g.chunks),
                        dim3(1024), lds, s, d_tiles, d_lidx, d_lstart, d_lngroups,
                        reinterpret_cast<const uint2*>(d_lcrit), (int)G, (int)N, P, (int)g.ntiles,
                        (int)g.gpb, (entries + kListSlack) * (int64_t)sizeof(uint32_t),

@@ -68,6 +68,11 @@ def test_bench_json_contract(extra):
         assert 50 < tel["sclk_mhz_mean"] < 3000 and 20 < tel["socket_power_w_mean"] < 2000
         assert r["sclk_mhz_mean"] == tel["sclk_mhz_mean"]
     assert r["ops_per_clock"] is None                       # needs the counters: refused on an overridden shape
+    assert len(d["kernel_source_sha256"]) == 64
+    sus = d["sustained"]                                    # the box under ~2 s of sustained load, after the region
+    assert sus["steps"] > 0 and 1.5 < sus["seconds"] < 10 and sus["ms_per_step"] > 0
+    if sus["samples"]:
+        assert 300 < sus["sclk_mhz_mean"] < 3000 and 100 < sus["socket_power_w_mean"] < 2000
     # K1 / K2 carry their own roofline entries, timed by themselves
     k1, k2 = d["roofline_k1"], d["roofline_k2"]
     for k in ("kernel", "bound", "bytes", "kernel_ms", "gbs", "hbm_frac", "valu_frac", "hbm_floor_ms", "valu_floor_ms",
@@ -110,7 +115,11 @@ def test_bench_headline_line_explains_itself():
     assert "cfg3" in d["config"]["workload"] and d["config"]["permutations"] == 10_000
     assert tel["samples"] >= 10                              # >= 10 samples inside the timed region
     assert 500 < tel["sclk_mhz_mean"] <= 2600 and 100 < tel["socket_power_w_mean"] < 2000
+    sus = d["sustained"]
+    assert sus["samples"] >= 20 and 1500 < sus["sclk_mhz_mean"] <= 2600 and 600 < sus["socket_power_w_mean"] < 2000
+    assert abs(sus["ms_per_step"] / d["ms_per_step"] - 1) < 0.25         # the same step, back to back
     if r["frac"] is not None:                                # counters of this kernel version are on file
+        assert 0.3 < sus["ops_per_clock_frac"] < 1
         assert 0 < r["ops_per_clock"] < 32768 and abs(r["ops_per_clock_frac"] - r["ops_per_clock"] / 32768) < 1e-12
         # frac is taken against 2.4 GHz, ops_per_clock against the clock the box granted
         assert abs(r["frac"] * 2400.0 / tel["sclk_mhz_mean"] - r["ops_per_clock_frac"]) < 1e-9
