@@ -1,14 +1,24 @@
 #!/bin/bash
-# One GPU-box session collecting the round-4 evidence (outputs under gpurun_out/r04/; the summaries are
+# GPU-box sessions collecting the round-4 evidence (outputs under gpurun_out/r04/; the summaries are
 # installed under profiles/ afterwards: tools/rocpd_summary.py on the merged gpurun_out/prof_r04_<cfg>).
+#   tools/round4_run.sh [part ...]     parts: configs cfg5 wide exchange soak (default: all, in that order);
+# one part per gpurun call keeps a lost box cheap.
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r04
 mkdir -p $O
+PARTS="${*:-configs cfg5 wide exchange soak}"
+has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
+if has configs; then
 # the driver's own command, first thing on the fresh box
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_cfg3_driver_command.json 2> $O/bench_cfg3_driver_command.err
-# counter profiles + bench lines (with the CPU baselines) of every BASELINE config
-bash tools/profile_configs.sh r04 cfg3 cfg4 cfg2 cfg5 > $O/profile_configs.log 2>&1
+# counter profiles + bench lines (with the CPU baselines) of the single-GPU BASELINE configs
+bash tools/profile_configs.sh r04 cfg3 cfg4 cfg2 > $O/profile_configs.log 2>&1
 python bench.py --config cfg2 --no-graph > $O/bench_cfg2_eager.json 2>/dev/null
+fi
+if has cfg5; then
+bash tools/profile_configs.sh r04 cfg5 > $O/profile_cfg5.log 2>&1
+fi
+if has wide; then
 # the wide (segmented) shape of VERDICT r3 item 3
 bash tools/profile.sh r04_wide --genes 20000 --isolates 50000 --traits 2 --permutations 1024 > $O/profile_wide.log 2>&1
 find gpurun_out/prof_r04_wide -type f ! -name '*.db' ! -name '*.txt' ! -name '*.log' -delete
@@ -18,6 +28,8 @@ python tools/sweep_isolates.py --permutations 8192 --traits 4 > $O/sweep_isolate
 # a pan-genome-shaped evidence line next to cfg3
 python bench.py --gene-kind ushaped --no-cpu-baseline > $O/bench_cfg3_ushaped.json 2>/dev/null
 python bench.py --config cfg4 --gene-kind ushaped --no-cpu-baseline > $O/bench_cfg4_shape_ushaped.json 2>/dev/null
+fi
+if has exchange; then
 # one rank through RCCL, weak and strong
 for sc in weak strong; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
@@ -29,6 +41,8 @@ tools/clock_sample.sh > $O/clock_power.txt 2>&1
 python bench.py --steps 3000 --warmup 5 --no-cpu-baseline > $O/bench_cfg3_sustained_3000_steps.json 2>/dev/null
 # the command line end to end on a cfg3-sized table
 python tools/e2e_synth.py --genes 50000 --isolates 2000 --traits 10 --permute 10000 > $O/e2e_cli_cfg3.txt 2>&1
+fi
+if has soak; then
 # the GPU test suite and the stress soaks
 (time python -m pytest tests/ -q -m gpu --durations=8) > $O/pytest_gpu.log 2>&1
 for t in lists tiles listbuild seglists; do
@@ -36,6 +50,7 @@ for t in lists tiles listbuild seglists; do
   echo "$t rc=$? $(tail -1 $O/stress_$t.log) ($(grep -c ' ok$' $O/stress_$t.log) ok)" >> $O/stress_soak.txt
 done
 cat $O/stress_soak.txt; tail -4 $O/pytest_gpu.log
+fi
 for f in $O/bench_*.json gpurun_out/bench_r04_*.json; do python - "$f" <<'PY'
 import json, sys
 try:
