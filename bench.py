@@ -671,7 +671,7 @@ def small_kernel_rooflines(args, G, N, T, n_mask_classes, kernel_ms):
             "tables": G * T, "tables_per_s": G * T / sec, "kernel_ms": t2,
             "bytes": b2, "bytes_formula": "32*G*T (SURVEY 8d B2)", "gbs": b2 / sec / 1e9,
             "hbm_frac": b2 / sec / 1e9 / HBM_PEAK_GBS,
-            "valu_insts_per_table": None if not ctr else ctr["SQ_INSTS_VALU"] * 64.0 / (G * T),
+            "valu_lane_ops_per_table": None if not ctr else ctr["SQ_INSTS_VALU"] * 64.0 / (G * T),
             "in_step": "runs on the main stream while the label-tile generator has the side stream: "
                        "kernel_ms here is the kernel alone, kernel_ms['k_fisher'] of the line the shared one",
             "counters_source": ctr["source"] if ctr else None}
