@@ -364,7 +364,9 @@ int scoary_pack_records(scoary_handle h, const int32_t *d_counts, const double *
  * that stream (and on streams forked from it by event waits) until
  * scoary_graph_end is recorded instead of executed.  The captured sequence must not
  * allocate, synchronise or read results back: use caller-owned buffers that stay
- * alive for as long as the graph is replayed.  scoary_graph_launch replays it.
+ * alive for as long as the graph is replayed (so: scoary_counts_planned with a plan
+ * built beforehand, not the one-call scoary_counts, which takes temporary memory for
+ * its plan).  scoary_graph_launch replays it.
  * Not available while per-kernel timing (scoary_set_timing) is on. */
 typedef struct scoary_graph *scoary_graph_t;
 int scoary_graph_begin(scoary_handle h, scoary_stream_t stream);
