@@ -1,4 +1,4 @@
-"""Randomised cross-checks of the list path's three device stages, one case per call (fixed
+"""Randomised cross-checks of the list path's three device stages and of K1, one case per call (fixed
 seeds): what tools/stress_{tiles,lists,listbuild}.py and tools/bigcheck.py used to run by
 hand.  tests/test_gpu_stress.py runs them under `pytest -m gpu`; the tools are thin loops
 over the same functions for longer soaks on a GPU box.
@@ -124,6 +124,66 @@ def listbuild_case(eng, case, seed=91):
           and np.array_equal(L.ngroups.cpu().numpy(), H["ngroups"])
           and np.array_equal(L.idx.cpu().numpy().view(np.uint32)[:L.entries], H["idx"][:L.entries]))
     return bool(ok), "listbuild G=%d N=%d %s" % (G, N, dens)
+
+
+COUNT_N = [1, 31, 32, 33, 64, 127, 128, 129, 500, 511, 513, 1000, 2000, 2047, 2049, 5000, 10000, 20001, 50000]
+COUNT_T = [1, 2, 3, 4, 5, 8, 9, 12, 13, 16, 17, 25, 28, 31, 32, 33, 50, 64, 65, 70, 97]
+
+
+def counts_case(eng, case, seed=91):
+    """K1 (round 4): k_counts through the trait plan -- every kernel instance (1, 2, 4, 8 ... 32
+    traits per pass), one to four passes, one to sixteen wavefronts per 64 genes, shared / partly
+    shared / all-distinct / all-missing validity rows -- against numpy's own AND + popcount on
+    the dense arrays (tpgp, tpgn, tngp, tngn of scoary/methods.py:950-965), the plan's margins
+    and mask classes against numpy, and the one-call scoary_counts against the planned form."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng([seed, case])
+    N = int(rng.choice(COUNT_N))
+    T = int(rng.choice(COUNT_T))
+    G = int(rng.choice([1, 63, 64, 65, 300, 1000, 4097])) if N < 20000 else int(rng.choice([1, 65, 300]))
+    genes = (rng.random((G, N)) < rng.uniform(0.0, 1.0, (G, 1))).astype(np.uint8)
+    traits = (rng.random((T, N)) < rng.uniform(0.05, 0.95, (T, 1))).astype(np.uint8)
+    kind = str(rng.choice(["none", "two", "pool", "distinct", "all-missing"]))
+    if kind == "two":
+        for t in rng.choice(T, size=min(2, T), replace=False):
+            traits[t, rng.random(N) < 0.02] = 2
+    elif kind == "pool":
+        pool = [rng.random(N) < rng.uniform(0.0, 0.2) for _ in range(3)]
+        for t in range(T):
+            k = int(rng.integers(0, 4))
+            if k < 3:
+                traits[t, pool[k]] = 2
+    elif kind == "distinct":
+        for t in range(T):
+            traits[t, rng.random(N) < 0.1] = 2
+    elif kind == "all-missing":
+        traits[int(rng.integers(0, T))] = 2
+    tb, mb = _bits(traits)
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    plan = eng.trait_plan(trv, mkv, N)
+    counts, _ = eng.counts(gm, trv, mkv, plan=plan)
+    got = counts.cpu().numpy().astype(np.int64)
+    g64 = genes.astype(np.int64)
+    pos, val = (traits == 1).astype(np.int64), (traits != 2).astype(np.int64)
+    a = pos @ g64.T                                                      # [T, G]
+    gmv = val @ g64.T
+    npos, nval = pos.sum(1)[:, None], val.sum(1)[:, None]
+    want = np.stack([a, npos - a, gmv - a, nval - npos - gmv + a], axis=2)
+    valid = traits != 2
+    first = {}
+    want_cls = np.array([first.setdefault(valid[t].tobytes(), t) for t in range(T)])
+    m = plan.margins.cpu().numpy()
+    ok = (np.array_equal(got, want) and np.array_equal(plan.mask_class.cpu().numpy(), want_cls)
+          and np.array_equal(m[:, 0], npos[:, 0]) and np.array_equal(m[:, 1], nval[:, 0]))
+    c2 = torch.full((T, G, 4), -7, dtype=torch.int32, device=eng.device)
+    m2 = torch.zeros((T, 2), dtype=torch.int32, device=eng.device)
+    vp = ctypes.c_void_p
+    rc = eng.lib.scoary_counts(eng.h, vp(gm.tiled.data_ptr()), vp(trv.data_ptr()), vp(mkv.data_ptr()), G, T, N,
+                               vp(c2.data_ptr()), vp(m2.data_ptr()), eng._stream())
+    ok = ok and rc == 0 and bool(torch.equal(c2, counts)) and bool(torch.equal(m2, plan.margins))
+    return bool(ok), "counts G=%d N=%d T=%d masks=%s" % (G, N, T, kind)
 
 
 SEG_N = [20480, 20481, 31000, 40704, 40705, 61111, 100003, 131070]

@@ -52,6 +52,10 @@ def test_stress_segmented_list_builder_positions(eng):
     _soak(sc.seglists_case, eng, cases=40, min_cases=12, budget_s=60)
 
 
+def test_stress_counts_every_instance_and_mask_pattern(eng):
+    _soak(sc.counts_case, eng, cases=120, min_cases=40, budget_s=60)
+
+
 @pytest.mark.parametrize("shape", sc.BIG_SHAPES, ids=lambda s: "%dx%dx%d" % s[:3])
 def test_big_shapes_list_kernel_vs_dense_kernel(eng, shape):
     ok, what = sc.big_case(eng, shape)

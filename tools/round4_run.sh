@@ -45,7 +45,7 @@ fi
 if has soak; then
 # the GPU test suite and the stress soaks
 (time python -m pytest tests/ -q -m gpu --durations=8) > $O/pytest_gpu.log 2>&1
-for t in lists tiles listbuild seglists; do
+for t in lists tiles listbuild seglists counts; do
   timeout 330 python tools/stress_$t.py 1000 > $O/stress_$t.log 2>&1
   echo "$t rc=$? $(tail -1 $O/stress_$t.log) ($(grep -c ' ok$' $O/stress_$t.log) ok)" >> $O/stress_soak.txt
 done
