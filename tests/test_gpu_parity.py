@@ -592,6 +592,54 @@ def test_workspace_and_graph_replay_equal_eager(eng, orc, use_lists):
         eng.associate(gm, trv, mkv, permutations=P + 1, seed=3, use_lists=use_lists, workspace=ws)
 
 
+@pytest.mark.parametrize("use_lists", [True, False], ids=["lists", "dense"])
+def test_launch_bound_steps_replay_a_graph_by_themselves(eng, orc, use_lists, monkeypatch):
+    """Round 4: with a workspace AND a trait plan -- every buffer persistent --
+    associate() records a launch-bound step (auto_graph_eligible: < 5e8 tests) into a hipGraph on
+    its second call and replays it from the third on.  Results equal the eager step's and the
+    oracle's on every call; other buffers, another seed or graph=False fall back to eager; per-kernel
+    timing and SCOARY_AUTO_GRAPH=0 switch it off; a step too large is never recorded."""
+    import torch
+    rng = np.random.default_rng(78)
+    G, N, T, P = 700, 300, 3, 300
+    genes, traits = _random_case(rng, G, N, T)
+    tb, mb = _bits(eng, traits)
+    gm = eng.pack_dense(genes)
+    trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
+    eng.build_lists(gm)
+    plan = eng.trait_plan(trv, mkv, N)
+    want = orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, 5).T
+    ws = eng.workspace(gm, T, P, use_lists=use_lists)
+    assert eng.auto_graph_eligible(gm, T, P) and ws.auto is None
+    for call in range(5):
+        ws.r.fill_(-1)
+        res = eng.associate(gm, trv, mkv, permutations=P, seed=5, use_lists=use_lists, workspace=ws, plan=plan)
+        torch.cuda.synchronize()
+        assert np.array_equal(res["r"].cpu().numpy().view(np.uint32), want), call
+        assert (ws.auto["graph"] is not None) == (call >= 1)          # recorded on the second call
+    g1 = ws.auto["graph"]
+    res = eng.associate(gm, trv, mkv, permutations=P, seed=6, use_lists=use_lists, workspace=ws, plan=plan)
+    assert ws.auto["graph"] is None and g1.graph is None               # another seed: old graph closed, eager again
+    assert np.array_equal(res["r"].cpu().numpy().view(np.uint32), orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, 6).T)
+    res = eng.associate(gm, trv, mkv, permutations=P, seed=6, use_lists=use_lists, workspace=ws, plan=plan, graph=False)
+    assert ws.auto["graph"] is None                                    # graph=False never records
+    eng.set_timing(True)                                               # per-kernel events: eager
+    try:
+        eng.associate(gm, trv, mkv, permutations=P, seed=6, use_lists=use_lists, workspace=ws, plan=plan)
+        assert ws.auto["graph"] is None and eng.kernel_ms("k_counts") > 0
+    finally:
+        eng.set_timing(False)
+    monkeypatch.setenv("SCOARY_AUTO_GRAPH", "0")
+    assert not eng.auto_graph_eligible(gm, T, P)
+    monkeypatch.delenv("SCOARY_AUTO_GRAPH")
+    assert not eng.auto_graph_eligible(gm, 1000, 1000)                 # 7e8 tests: not launch-bound
+    # without a plan the step recomputes it and stays eager (nothing persistent to replay against)
+    ws2 = eng.workspace(gm, T, P, use_lists=use_lists)
+    for _ in range(3):
+        res = eng.associate(gm, trv, mkv, permutations=P, seed=5, use_lists=use_lists, workspace=ws2)
+    assert ws2.auto is None and np.array_equal(res["r"].cpu().numpy().view(np.uint32), want)
+
+
 # ------------------------------ opt-in early abort on the Fisher statistic -----
 @pytest.mark.parametrize("G,N,T,P", [(120, 90, 2, 200), (70, 700, 1, 333), (40, 2100, 2, 130), (64, 1000, 1, 120),
                                      (30, 7000, 1, 70)])
