@@ -61,7 +61,7 @@ def test_bench_json_contract(extra):
     tel = d["telemetry"]
     for k in ("source", "samples", "sclk_mhz_mean", "socket_power_w_mean", "period_ms"):
         assert k in tel, k
-    assert tel["source"] is not None, "no clock / power source on this box (amdsmi, hwmon)"
+    # (a box that exposes neither amdsmi nor the hwmon files yields nulls, never an error)
     for k in ("sclk_mhz_mean", "socket_power_w_mean", "ops_per_clock", "ops_per_clock_frac", "telemetry_samples"):
         assert k in r, k
     if tel["samples"]:
@@ -70,9 +70,12 @@ def test_bench_json_contract(extra):
     assert r["ops_per_clock"] is None                       # needs the counters: refused on an overridden shape
     assert len(d["kernel_source_sha256"]) == 64
     sus = d["sustained"]                                    # the box under ~2 s of sustained load, after the region
-    assert sus["steps"] > 0 and 1.5 < sus["seconds"] < 10 and sus["ms_per_step"] > 0
-    if sus["samples"]:
-        assert 300 < sus["sclk_mhz_mean"] < 3000 and 100 < sus["socket_power_w_mean"] < 2000
+    if tel["source"] is None:                               # no sensor at all: nulls, and no sustained window
+        assert sus is None and tel["samples"] == 0
+    else:
+        assert sus["steps"] > 0 and 1.5 < sus["seconds"] < 10 and sus["ms_per_step"] > 0
+        if sus["samples"]:
+            assert 50 < sus["sclk_mhz_mean"] < 3000 and 20 < sus["socket_power_w_mean"] < 2500
     # K1 / K2 carry their own roofline entries, timed by themselves
     k1, k2 = d["roofline_k1"], d["roofline_k2"]
     for k in ("kernel", "bound", "bytes", "kernel_ms", "gbs", "hbm_frac", "valu_frac", "hbm_floor_ms", "valu_floor_ms",
@@ -113,6 +116,8 @@ def test_bench_headline_line_explains_itself():
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     r, tel = d["roofline"], d["telemetry"]
     assert "cfg3" in d["config"]["workload"] and d["config"]["permutations"] == 10_000
+    if tel["source"] is None:
+        pytest.skip("this box exposes no clock / power source (amdsmi, hwmon): nothing to check")
     assert tel["samples"] >= 10                              # >= 10 samples inside the timed region
     assert 50 < tel["sclk_mhz_mean"] <= 3000 and 20 < tel["socket_power_w_mean"] < 2500
     sus = d["sustained"]
