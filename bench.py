@@ -903,7 +903,8 @@ def main():
     # (2.19-2.21 GHz at 1.33-1.36 kW, as rocm-smi says).  This is what tells a slow box from a
     # slow kernel: the sustained clock the box grants this kernel, and lane-ops per that clock.
     sustained = None
-    if args.sustain_seconds > 0 and not sharded and median_ms and median_ms < 200.0 and tele is not None:
+    if args.sustain_seconds > 0 and not sharded and median_ms and median_ms < 200.0 \
+            and tele is not None and tele._read is not None:
         tele2 = Telemetry(local_rank, period_s=0.01).start()
         s0 = time.perf_counter()
         nsteps = 0
