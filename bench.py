@@ -820,18 +820,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # shader clock / socket power of THIS run, sampled from a side thread during the timed region.
+    # The sensor is opened BEFORE the warm-up (amdsmi's start-up takes tens of milliseconds: the GPU
+    # must not sit idle between the warm-up steps and the timed region).
+    # A launch-bound run (cfg2: a 1-2 ms timed region of 0.06 ms graph launches) is not sampled from
+    # inside: one amdsmi read costs a few hundred microseconds of interpreter time and would be the
+    # largest thing in the region.  It gets one reading right before and one right after instead.
+    tele = Telemetry(local_rank, period_s=max(0.001, args.telemetry_ms * 1e-3)) if args.telemetry_ms > 0 else None
+    tele_inside = tele is not None and not eng.auto_graph_eligible(gm, T, P)
     for _ in range(args.warmup):
         step()
     barrier()
     if graph is None:
         eng.set_timing(True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    # shader clock / socket power of THIS run, sampled from a side thread during the timed region
-    # A launch-bound run (cfg2: a 1-2 ms timed region of 0.06 ms graph launches) is not sampled from
-    # inside: one amdsmi read costs a few hundred microseconds of interpreter time and would be the
-    # largest thing in the region.  It gets one reading right before and one right after instead.
-    tele = Telemetry(local_rank, period_s=max(0.001, args.telemetry_ms * 1e-3)) if args.telemetry_ms > 0 else None
-    tele_inside = tele is not None and not eng.auto_graph_eligible(gm, T, P)
     edge = []
     if tele is not None and not tele_inside and tele._read:
         edge.append((time.perf_counter(),) + tuple(tele._read()))
@@ -851,6 +853,8 @@ def main():
         t_kernels = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    if exchange:
+        exposed_ms = (time.perf_counter() - t_kernels) * 1e3
     if tele is not None and not tele_inside:
         if tele._read:
             edge.append((time.perf_counter(),) + tuple(tele._read()))
@@ -861,8 +865,6 @@ def main():
         telemetry = tele.stop(t0, t0 + dt) if tele is not None else None
         if telemetry is not None:
             telemetry["sampled"] = "inside the timed region"
-    if exchange:
-        exposed_ms = (time.perf_counter() - t_kernels) * 1e3
     step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if step_ms else None
     if graph is not None:                           # per-kernel times: a few eager steps afterwards
