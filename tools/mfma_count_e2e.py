@@ -96,6 +96,9 @@ def main():
         r_res = torch.full((T, G), 0x7fffffff, dtype=torch.int32, device=eng.device)
         t_res = timed(torch, lambda: run_mfma(1, r_res), a.reps)
         same_res = bool(torch.equal(r_res, r_mfma))
+    r_v3 = torch.full((T, G), 0x7fffffff, dtype=torch.int32, device=eng.device)
+    t_v3 = timed(torch, lambda: run_mfma(2, r_v3), a.reps)
+    same_v3 = bool(torch.equal(r_v3, r_mfma))
     t_dense = timed(torch, run_dense, a.reps)
     t_lists = timed(torch, run_lists, a.reps)
     same_d = bool(torch.equal(r_mfma, r_dense))
@@ -113,6 +116,10 @@ def main():
               "%8.3f ms  %.3e tests/s  %.3e dense MAC/s   r == streaming MFMA: %s   MFMA / lists = %.2f"
               % (t_res, tests / (t_res * 1e-3), macs / (t_res * 1e-3), same_res, t_res / t_lists))
         same_d = same_d and same_res
+    print("MFMA end to end, v_perm expansion + per-lane exceedance counters (no ballots per tile):             "
+          "%8.3f ms  %.3e tests/s  %.3e dense MAC/s   r == streaming MFMA: %s   MFMA / lists = %.2f"
+          % (t_v3, tests / (t_v3 * 1e-3), macs / (t_v3 * 1e-3), same_v3, t_v3 / t_lists))
+    same_d = same_d and same_v3
     print("dense AND + popcount kernel (k_permute_reg / chunked):                                               "
           "%8.3f ms  %.3e tests/s" % (t_dense, tests / (t_dense * 1e-3)))
     print("list-driven kernel (k_permute_lists + reduce, regions converted):                                    "
