@@ -754,3 +754,38 @@ def test_roofline_ops_per_clock_follows_the_run_s_clock(monkeypatch):
     assert b["sclk_mhz_mean"] == 2000.0 and b["socket_power_w_mean"] == 1350.0 and b["telemetry_samples"] == 12
     c = bench.roofline_report(args, eng, True, 50000, 2000, 10, 10000, 10240, "k_permute_lists", 4.8)
     assert c["ops_per_clock"] is None and c["sclk_mhz_mean"] is None
+
+
+def test_usable_cpus_honours_affinity_and_cgroup_quota(monkeypatch):
+    """The CPU baselines start as many workers as the process may really use (a
+    Pool(256) on a container granted 16 CPUs reported 55 tests/s per worker): os.cpu_count(), the
+    affinity mask and the cgroup v2 / v1 quota, whichever is smallest."""
+    import builtins
+    import io
+    from oracle import scipy_baseline as sb
+    monkeypatch.setattr(sb.os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(sb.os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    real_open = builtins.open
+
+    def fake(files):
+        def _open(path, *a, **k):
+            if path in files:
+                if files[path] is None:
+                    raise OSError("no such file")
+                return io.StringIO(files[path])
+            if str(path).startswith("/sys/fs/cgroup"):
+                raise OSError("no such file")
+            return real_open(path, *a, **k)
+        return _open
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "1600000 100000\n"}))
+    assert sb.usable_cpus() == 16                              # cgroup v2: quota / period
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "max 100000\n"}))
+    assert sb.usable_cpus() == 64                              # no quota: the affinity mask
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": None,
+                                                "/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "800000\n",
+                                                "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"}))
+    assert sb.usable_cpus() == 8                               # cgroup v1
+    monkeypatch.setattr(builtins, "open", fake({}))
+    assert sb.usable_cpus() == 64
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "50000 100000\n"}))
+    assert sb.usable_cpus() == 1                               # half a CPU still runs one worker
