@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SCOARY_ABI_VERSION 7
+#define SCOARY_ABI_VERSION 8
 
 /* error codes */
 #define SCOARY_OK 0
@@ -154,12 +154,21 @@ int scoary_fisher_lists(scoary_handle h, const int32_t *d_tables, int64_t T, int
 /* ---- a8: PermuteGTC (scoary/methods.py:1371-1384) ----------------------
  * Label permutations pi = perm_base .. perm_base+P-1 of the T traits whose
  * rows are given (their global trait numbers are trait_base .. trait_base+T-1,
- * the number that enters the Philox counter): the
- * trait's npos positive labels placed on a uniformly random subset of its
- * valid isolates (counter-based: Philox4x32-10 keyed by `seed`, counter
- * (isolate>>2, pi, trait, "SCOA"), sequential selection sampling -- DESIGN.md
- * spec S4; the CPU oracle regenerates the same bits).
- *   d_perms : vecrows [T][P][Wp] */
+ * the number that enters the Philox counter): the trait's npos positive labels
+ * placed on a uniformly random subset of its valid isolates.  The reference's
+ * shuffle is unseeded; here the bits are a pure function of (seed, trait,
+ * permutation) -- Philox4x32-10 keyed by `seed` -- by a sampler in which no isolate
+ * depends on the one before it (spec S4 of DESIGN.md, ABI 8; rounds 1-4 used
+ * sequential selection sampling): min(npos, nval - npos) marks; round 0 marks every
+ * valid isolate with an 8-bit probability (eight words of counter (isolate, pi >> 5,
+ * trait, "SCOB" / "SCOC") shared by 32 permutations, compared bit-sliced); the
+ * surplus or deficit is removed / added at uniformly drawn positions (counter
+ * (draw >> 2, pi, trait, "SCOD"), Lemire rejection, non-candidates rejected).
+ * Exactly uniform under ideal random words; the CPU oracle (oracle/oracle.c)
+ * regenerates the same bits.
+ *   d_perms : vecrows [T][P][Wp]
+ * N <= scoary_perm_max_isolates() (a block keeps its rows in LDS). */
+int64_t scoary_perm_max_isolates(void);
 int scoary_perm_generate(scoary_handle h, const uint32_t *d_masks,
                          const int32_t *d_margins, int64_t T, int64_t N,
                          int64_t P, int64_t perm_base, int64_t trait_base,
@@ -226,10 +235,20 @@ int64_t scoary_list_segments(int64_t N);     /* 1 for N <= 20479, else ceil(N / 
  * interleave piece } -- the last four are the arguments scoary_lists_build
  * wants.  Error if N is too large. */
 int scoary_list_params(int64_t N, int64_t *out5);
+/* Label tiles of the permutations perm_base .. perm_base + P - 1 (perm_base a multiple of 32):
+ * d_tiles = uint32 [T][ntiles][scoary_list_tile_words(N)], the same labels as
+ * scoary_perm_generate.  _range writes only the flat (trait, tile) indices first_tile ..
+ * first_tile + n_tiles - 1 of that array, in place: the ranks of a multi-GPU run can each
+ * generate one contiguous share and all-gather the rest (scoary_amd/dist.py). */
 int scoary_perm_generate_tiles(scoary_handle h, const uint32_t *d_masks,
                                const int32_t *d_margins, int64_t T, int64_t N, int64_t P,
                                int64_t perm_base, int64_t trait_base, uint64_t seed,
                                uint32_t *d_tiles, scoary_stream_t stream);
+int scoary_perm_generate_tiles_range(scoary_handle h, const uint32_t *d_masks,
+                                     const int32_t *d_margins, int64_t T, int64_t N, int64_t P,
+                                     int64_t perm_base, int64_t trait_base, uint64_t seed,
+                                     int64_t first_tile, int64_t n_tiles, uint32_t *d_tiles,
+                                     scoary_stream_t stream);
 int64_t scoary_permute_lists_scratch_bytes(int64_t G, int64_t T, int64_t N, int64_t P);
 int scoary_permute_lists(scoary_handle h, const uint32_t *d_tiles, const uint32_t *d_lidx,
                          int64_t entries, const int32_t *d_lstart, const int32_t *d_lngroups,

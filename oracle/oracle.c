@@ -285,40 +285,138 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2],
     out[3] = c3;
 }
 
-#define ORC_PERM_DOMAIN 0x53434F41u /* "SCOA": counter word 3 */
+/* Spec S4 (round 5): one label permutation = a uniformly random subset of size npos of
+ * the valid isolates (== shuffling the 0/1 labels among the non-missing isolates,
+ * PermuteGTC methods.py:1377-1383).  The reference's shuffle is unseeded, so the law is
+ * the contract, not the bits; this build's bits are defined so that NO step depends on
+ * the isolate before it (rounds 1-4 used sequential selection sampling: a chain of N
+ * dependent steps per permutation):
+ *
+ *   m     = min(npos, nval - npos) marks are placed (the complement is taken at the end
+ *           when npos > nval / 2), so the mark fraction is <= 1/2;
+ *   q/256 = an 8-bit mark probability a little BELOW m/nval (orc_perm_plan);
+ *   round 0: every valid isolate i is marked independently with probability q/256.  The
+ *           32 permutations B*32 .. B*32+31 share eight 32-bit words R_0..R_7 per isolate,
+ *           R_0..3 = Philox(key = seed, ctr = (i, B, t, "SCOB")), R_4..7 = the same with
+ *           "SCOC"; bit b of  X = fold_{j=0..7} (q>>j & 1 ? X | R_j : X & R_j), X = 0 at
+ *           the start, is the mark of permutation B*32+b (bit-sliced comparison of an 8-bit
+ *           uniform number with q: probability exactly q/256, independent across b and i);
+ *   fix-up: K = marks placed; conditional on K the marked set is uniform among the K-subsets
+ *           of the valid isolates, so adding (K < m) or removing (K > m) uniformly chosen
+ *           isolates keeps it uniform.  Draws c = 0, 1, 2, ...: u = word c&3 of
+ *           Philox(key, ctr = (c>>2, pi, t, "SCOD")); prod = u * N; rejected if the low
+ *           32 bits of prod are < 2^32 mod N (Lemire: pos = prod >> 32 is then EXACTLY
+ *           uniform on 0..N-1); pos is toggled iff it is a candidate (add: valid and
+ *           unmarked; remove: marked); stop when K = m.
+ * Under ideal random words the result is exactly uniform (no 2^-32 rounding term). */
+#define ORC_DOM_BERN_LO 0x53434F42u /* "SCOB": counter word 3, words R_0..R_3 */
+#define ORC_DOM_BERN_HI 0x53434F43u /* "SCOC": words R_4..R_7 */
+#define ORC_DOM_FIX 0x53434F44u     /* "SCOD": fix-up position draws */
+#define ORC_FIX_MAX_CALLS (1u << 20) /* safety stop of the fix-up loop (never reached on consistent input) */
 
-/* One label permutation of trait `t`, index `pi`: a uniformly random subset
- * of size npos of the valid isolates (== shuffling the 0/1 labels among the
- * non-missing isolates, PermuteGTC methods.py:1377-1383), by sequential
- * selection sampling (Knuth 3.4.2 Algorithm S).  Isolate i consumes the
- * 32-bit draw u = word (i&3) of Philox(key = seed, ctr = (i>>2, pi, t, "SCOA"));
- * it is selected iff  (u * remaining) >> 32 < needed  (the selection
- * probability needed/remaining rounded up to a multiple of 2^-32). */
+static uint64_t isqrt_u64(uint64_t v)
+{
+    uint64_t r = 0;
+    for (int s = 31; s >= 0; --s) {
+        uint64_t c = r | ((uint64_t)1 << s);
+        if (c * c <= v) r = c;
+    }
+    return r;
+}
+
+/* marks to place, whether the complement is taken, and the 8-bit round-0 probability.
+ * The target mean of round 0 sits b = 2.4 sigma (1 - 2 m/nval) below m: removing a mark
+ * costs ~nval/m position draws, adding one ~nval/(nval-m), and with this b the longest
+ * fix-up among many permutations costs about the same on either side (4.8 sigma draws). */
+void orc_perm_plan(int64_t npos, int64_t nval, int64_t *m_out, int *flip_out, uint32_t *q_out)
+{
+    int flip = 2 * npos > nval;
+    int64_t m = flip ? nval - npos : npos;
+    uint32_t q = 0;
+    if (m > 0 && nval > 0) {
+        uint64_t s = isqrt_u64((uint64_t)m * (uint64_t)(nval - m) / (uint64_t)nval);
+        uint64_t b = 12u * s * (uint64_t)(nval - 2 * m) / (5u * (uint64_t)nval);
+        uint64_t target = (uint64_t)m > b ? (uint64_t)m - b : 0;
+        q = (uint32_t)(256u * target / (uint64_t)nval);
+    }
+    *m_out = m < 0 ? 0 : m;
+    *flip_out = flip;
+    *q_out = q;
+}
+
+/* The 32 permutations pi = 32 B + b, b = 0..31, of trait t: out[b * W + w] = rows64 label
+ * bits of permutation 32 B + b (W = ceil(N/64)). */
+void orc_perm_block(uint64_t seed, uint32_t t, uint32_t B, const uint64_t *mask,
+                    int64_t npos, int64_t N, uint64_t *out)
+{
+    int64_t W = (N + 63) / 64, nval = 0, m;
+    int flip;
+    uint32_t q;
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    memset(out, 0, (size_t)(32 * W) * sizeof(uint64_t));
+    if (N < 1) return;
+    for (int64_t w = 0; w < W; ++w) nval += __builtin_popcountll(mask[w]);
+    orc_perm_plan(npos, nval, &m, &flip, &q);
+    uint32_t *X = (uint32_t *)calloc((size_t)N, sizeof(uint32_t));
+    int64_t K[32];
+    memset(K, 0, sizeof K);
+#define VALID(i) ((mask[(i) >> 6] >> ((i) & 63)) & 1)
+    if (q)
+        for (int64_t i = 0; i < N; ++i) {
+            if (!VALID(i)) continue;
+            uint32_t R[8], x = 0;
+            uint32_t ctr[4] = {(uint32_t)i, B, t, ORC_DOM_BERN_LO};
+            orc_philox4x32_10(ctr, key, R);
+            ctr[3] = ORC_DOM_BERN_HI;
+            orc_philox4x32_10(ctr, key, R + 4);
+            for (int j = 0; j < 8; ++j) x = ((q >> j) & 1u) ? (x | R[j]) : (x & R[j]);
+            X[i] = x;
+            for (int b = 0; b < 32; ++b) K[b] += (x >> b) & 1u;
+        }
+    const uint32_t reject_below = (uint32_t)(((uint64_t)1 << 32) % (uint64_t)N);
+    for (int b = 0; b < 32; ++b) {
+        const uint32_t pi = B * 32u + (uint32_t)b, bit = 1u << b;
+        int64_t d = m - K[b]; /* > 0: add marks, < 0: remove marks */
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        for (uint32_t c = 0; d != 0 && (c >> 2) < ORC_FIX_MAX_CALLS; ++c) {
+            if (!(c & 3)) {
+                uint32_t ctr[4] = {c >> 2, pi, t, ORC_DOM_FIX};
+                orc_philox4x32_10(ctr, key, rnd);
+            }
+            uint64_t prod = (uint64_t)rnd[c & 3] * (uint64_t)N;
+            if ((uint32_t)prod < reject_below) continue;
+            int64_t pos = (int64_t)(prod >> 32);
+            if (d > 0) {
+                if (VALID(pos) && !(X[pos] & bit)) { X[pos] |= bit; --d; }
+            } else if (X[pos] & bit) {
+                X[pos] &= ~bit;
+                ++d;
+            }
+        }
+    }
+    for (int64_t i = 0; i < N; ++i) {
+        if (!VALID(i)) continue;
+        uint32_t x = flip ? ~X[i] : X[i];
+        while (x) {
+            int b = __builtin_ctz(x);
+            x &= x - 1;
+            out[(int64_t)b * W + (i >> 6)] |= (uint64_t)1 << (i & 63);
+        }
+    }
+#undef VALID
+    free(X);
+}
+
+/* One permutation (index pi) of the block it belongs to. */
 void orc_perm_labels(uint64_t seed, uint32_t t, uint32_t pi,
                      const uint64_t *mask, int64_t npos, int64_t N,
                      uint64_t *out)
 {
     int64_t W = (N + 63) / 64;
-    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-    uint64_t needed = (uint64_t)npos, remaining = 0;
-    for (int64_t w = 0; w < W; ++w)
-        remaining += (uint64_t)__builtin_popcountll(mask[w]);
-    memset(out, 0, (size_t)W * sizeof(uint64_t));
-    uint32_t rnd[4] = {0, 0, 0, 0};
-    for (int64_t i = 0; i < N; ++i) {
-        if (!(i & 3)) {
-            uint32_t ctr[4] = {(uint32_t)(i >> 2), pi, t, ORC_PERM_DOMAIN};
-            orc_philox4x32_10(ctr, key, rnd);
-        }
-        if (!((mask[i >> 6] >> (i & 63)) & 1))
-            continue;
-        uint64_t hi = ((uint64_t)rnd[i & 3] * remaining) >> 32;
-        if (hi < needed) {
-            out[i >> 6] |= (uint64_t)1 << (i & 63);
-            --needed;
-        }
-        --remaining;
-    }
+    uint64_t *blk = (uint64_t *)malloc((size_t)(32 * W) * sizeof(uint64_t));
+    orc_perm_block(seed, t, pi >> 5, mask, npos, N, blk);
+    memcpy(out, blk + (int64_t)(pi & 31u) * W, (size_t)W * sizeof(uint64_t));
+    free(blk);
 }
 
 /* ------------------------------------------------------------------ S5 -- */
@@ -333,7 +431,7 @@ void orc_permute_r(const uint64_t *genes, const uint64_t *traits,
                    const uint64_t *masks, int64_t G, int64_t T, int64_t N,
                    int64_t P, uint64_t seed, int64_t perm_base, uint32_t *r_out)
 {
-    enum { PB = 256 };
+    enum { PB = 2048 };   /* 64 blocks of 32 permutations per batch (spec S4) */
     int64_t W = (N + 63) / 64;
     uint64_t *labs = (uint64_t *)malloc((size_t)(PB * W) * sizeof(uint64_t));
     memset(r_out, 0, (size_t)(G * T) * sizeof(uint32_t));
@@ -393,9 +491,20 @@ void orc_permute_r(const uint64_t *genes, const uint64_t *traits,
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
-            for (int64_t j = 0; j < nb; ++j)
-                orc_perm_labels(seed, (uint32_t)t, (uint32_t)(perm_base + p0 + j),
-                                mr, npos, N, labs + j * W);
+            for (int64_t jb = 0; jb < (nb + 31) / 32; ++jb) {
+                /* block-wise when the batch is aligned to the 32-permutation blocks of spec S4 */
+                int64_t first = perm_base + p0 + jb * 32, cnt = nb - jb * 32 < 32 ? nb - jb * 32 : 32;
+                if (!(first & 31)) {
+                    uint64_t *blk = (uint64_t *)malloc((size_t)(32 * W) * sizeof(uint64_t));
+                    orc_perm_block(seed, (uint32_t)t, (uint32_t)(first >> 5), mr, npos, N, blk);
+                    memcpy(labs + jb * 32 * W, blk, (size_t)(cnt * W) * sizeof(uint64_t));
+                    free(blk);
+                } else {
+                    for (int64_t j = 0; j < cnt; ++j)
+                        orc_perm_labels(seed, (uint32_t)t, (uint32_t)(first + j), mr, npos, N,
+                                        labs + (jb * 32 + j) * W);
+                }
+            }
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -569,8 +678,10 @@ int orc_tree_permute(const int32_t *ops, int64_t nops, const int32_t *tips,
     if (orc_tree_dp(ops, nops, ts, out_obs)) { free(ts); free(lab); return -1; }
     int key = out_obs[1] >= out_obs[2] ? 1 : 2;
     double est = (double)out_obs[key] / (double)out_obs[0];
+    uint64_t *blk = (uint64_t *)malloc((size_t)(32 * W) * sizeof(uint64_t));
     for (int64_t pi = 0; pi < P; ++pi) {
-        orc_perm_labels(seed, t, (uint32_t)pi, mbits, npos, N, lab);
+        if (!(pi & 31)) orc_perm_block(seed, t, (uint32_t)(pi >> 5), mbits, npos, N, blk);
+        memcpy(lab, blk + (pi & 31) * W, (size_t)W * sizeof(uint64_t));
         for (int64_t k = 0; k < ntips; ++k) {
             int64_t i = tips[k];
             ts[k] = (uint8_t)((BIT(gbits, i) ? 0 : 2) + (BIT(lab, i) ? 0 : 1));
@@ -582,5 +693,6 @@ int orc_tree_permute(const int32_t *ops, int64_t nops, const int32_t *tips,
 #undef BIT
     free(ts);
     free(lab);
+    free(blk);
     return 0;
 }

@@ -51,12 +51,15 @@ def lib():
         L.orc_fisher_many.argtypes = [vp, i64, vp, vp]
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]
         L.orc_perm_labels.argtypes = [u64, u32, u32, vp, i64, i64, vp]
+        L.orc_perm_block.argtypes = [u64, u32, u32, vp, i64, i64, vp]
+        L.orc_perm_plan.argtypes = [i64, i64, vp, vp, vp]
         L.orc_permute_r.argtypes = [vp, vp, vp, i64, i64, i64, i64, u64, i64, vp]
         L.orc_num_threads.restype = ctypes.c_int
         L.orc_set_num_threads.argtypes = [ctypes.c_int]
         for f in (L.orc_pack_rows, L.orc_counts_dense, L.orc_counts_packed,
                   L.orc_fisher, L.orc_fisher_many, L.orc_philox4x32_10,
-                  L.orc_perm_labels, L.orc_permute_r, L.orc_set_num_threads):
+                  L.orc_perm_labels, L.orc_perm_block, L.orc_perm_plan, L.orc_permute_r,
+                  L.orc_set_num_threads):
             f.restype = None
         _lib = L
     return _lib
@@ -130,6 +133,23 @@ def perm_labels(seed, t, pi, mask_bits, npos, N):
     out = np.zeros(words(N), dtype=np.uint64)
     lib().orc_perm_labels(int(seed), int(t), int(pi), _p(mask_bits), int(npos), int(N), _p(out))
     return out
+
+
+def perm_block(seed, t, block, mask_bits, npos, N):
+    """The 32 permutations 32*block .. 32*block+31 of trait t (spec S4): (32, W64) uint64."""
+    mask_bits = np.ascontiguousarray(mask_bits, dtype=np.uint64)
+    out = np.zeros((32, words(N)), dtype=np.uint64)
+    lib().orc_perm_block(int(seed), int(t), int(block), _p(mask_bits), int(npos), int(N), _p(out))
+    return out
+
+
+def perm_plan(npos, nval):
+    """(marks to place m, complement taken?, 8-bit round-0 probability q) of spec S4."""
+    m = ctypes.c_int64()
+    flip = ctypes.c_int()
+    q = ctypes.c_uint32()
+    lib().orc_perm_plan(int(npos), int(nval), ctypes.byref(m), ctypes.byref(flip), ctypes.byref(q))
+    return int(m.value), bool(flip.value), int(q.value)
 
 
 def permute_r(gbits, tbits, mbits, N, P, seed, perm_base=0):

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCOARY_HIP_LIB") or os.path.join(_HERE, "csrc", "libscoary_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "scoary_hip.h")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _i64, _u64, _i32, _vp, _cp = (ctypes.c_int64, ctypes.c_uint64, ctypes.c_int,
                               ctypes.c_void_p, ctypes.c_char_p)
@@ -46,6 +46,9 @@ SIGNATURES = {
     "scoary_list_segments": (_i64, [_i64]),
     "scoary_perm_generate_tiles": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp,
                                           _vp]),
+    "scoary_perm_generate_tiles_range": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _i64,
+                                                _i64, _vp, _vp]),
+    "scoary_perm_max_isolates": (_i64, []),
     "scoary_permute_lists_scratch_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "scoary_permute_lists": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 8 + [_i64, _i64, _i64, _i64, _vp,
                                                                        _i32, _vp]),

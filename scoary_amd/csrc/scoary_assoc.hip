@@ -475,50 +475,6 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
 }
 
 // ----------------------------------------------------------------------------
-// a8: label permutations (spec S4)
-// ----------------------------------------------------------------------------
-
-// One thread per (trait, permutation): sequential selection sampling over the
-// isolates, 32 at a time; the validity word is wave-uniform (blockIdx.y =
-// trait), the 32-bit draws come from Philox keyed by (isolate>>2, pi, trait).
-__global__ __launch_bounds__(64) void k_perm_generate(const uint32_t* __restrict__ masks,
-                                                      const int32_t* __restrict__ margins, int N,
-                                                      int Wp, int64_t P, int64_t perm_base,
-                                                      int trait_base, uint32_t k0, uint32_t k1,
-                                                      uint32_t* __restrict__ perms) {
-  const int t = blockIdx.y;
-  const int64_t pl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pl >= P) return;
-  const uint32_t pi = (uint32_t)(perm_base + pl);
-  uint32_t needed = (uint32_t)margins[2 * t], remaining = (uint32_t)margins[2 * t + 1];
-  const uint32_t* mrow = masks + (int64_t)t * Wp;
-  uint32_t* out = perms + ((int64_t)t * P + pl) * Wp;
-  const int nw = (N + 31) / 32;
-  for (int k = 0; k < nw; ++k) {
-    const uint32_t mw = mrow[k];
-    uint32_t word = 0;
-#pragma unroll 4
-    for (int jj = 0; jj < 8; ++jj) {             // one Philox call = four isolates
-      uint32_t r[4];
-      philox4x32_10((uint32_t)(k * 8 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int bit = 4 * jj + q;
-        if ((mw >> bit) & 1u) {
-          if (__umulhi(r[q], remaining) < needed) {
-            word |= 1u << bit;
-            --needed;
-          }
-          --remaining;
-        }
-      }
-    }
-    out[k] = word;
-  }
-  for (int k = nw; k < Wp; ++k) out[k] = 0u;
-}
-
-// ----------------------------------------------------------------------------
 // a7: permutation exceedance counts
 // ----------------------------------------------------------------------------
 // Register-resident variant: a lane keeps GL whole gene rows (RQ quads each)
@@ -862,26 +818,6 @@ int scoary_fisher_lists(scoary_handle h, const int32_t* d_tables, int64_t T, int
                      dim3(kWave), 0, s, reinterpret_cast<const int4*>(d_tables), G, d_p, d_or,
                      reinterpret_cast<uint2*>(d_crit), d_lorder, d_lflipped,
                      reinterpret_cast<uint2*>(d_lcrit));
-  HIP_TRY(h, hipGetLastError());
-  return SCOARY_OK;
-}
-
-int scoary_perm_generate(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
-                         int64_t T, int64_t N, int64_t P, int64_t perm_base, int64_t trait_base,
-                         uint64_t seed,
-                         uint32_t* d_perms, scoary_stream_t stream) {
-  if (!h) return SCOARY_ERR_ARG;
-  if (!d_masks || !d_margins || !d_perms || T < 1 || N < 1 || P < 1 || perm_base < 0 ||
-      trait_base < 0)
-    return fail(h, SCOARY_ERR_ARG, "scoary_perm_generate: bad argument");
-  if (T > 65535 || trait_base + T > 0x7fffffffLL || perm_base + P > 0xffffffffLL)
-    return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate: T > 65535 or permutation index >= 2^32");
-  DeviceGuard guard(h->device);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  KernelTimer kt(h, s, "k_perm_generate");
-  hipLaunchKernelGGL(k_perm_generate, dim3((unsigned)((P + kWave - 1) / kWave), (unsigned)T),
-                     dim3(kWave), 0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P,
-                     perm_base, (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), d_perms);
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
 }

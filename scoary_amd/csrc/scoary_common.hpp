@@ -1,6 +1,6 @@
 // scoary_common.hpp -- shared by the translation units of libscoary_hip.so: the
 // handle, error / timing helpers, layout constants and the Philox generator of
-// spec S4.  Everything here is internal; the contract is include/scoary_hip.h.
+// spec S4 (scoary_labels.hip).  Everything here is internal; the contract is include/scoary_hip.h.
 #ifndef SCOARY_COMMON_HPP
 #define SCOARY_COMMON_HPP
 #include <hip/hip_runtime.h>
@@ -21,6 +21,7 @@ struct scoary_ctx {
   std::string err;
   bool timing = false;
   int lists_lds_optin = 0;   // k_permute_lists instances (by tile width) with the 160 KB LDS opt-in done
+  int labels_lds_optin = 0;  // k_labels instances with it
   struct Timed {
     std::string name;
     hipEvent_t start, stop;
@@ -32,7 +33,6 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kGeneAlign = 256;
-constexpr uint32_t kPermDomain = 0x53434F41u;  // "SCOA", spec S4
 
 // Row sizes (in quads of four 32-bit words) for which a gene row is held
 // entirely in VGPRs by k_permute_reg.

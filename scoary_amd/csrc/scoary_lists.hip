@@ -120,280 +120,8 @@ __device__ __forceinline__ uint32_t full_add(uint32_t& c, uint32_t x, uint32_t y
 }
 
 // Isolate-major label tiles: tiles[t][tile][row 0..N][TW] dwords, row N all
-// zero; dword j of a row = labels of permutations tile*TW*32 + 32j .. +31.
-// One wavefront generates 64 consecutive permutations (spec S4, same draws as
-// k_perm_generate) and transposes them with ballots.
-// Where the 64 permutations of generator wavefront `wave` go: two adjacent dwords lo / hi of the
-// rows of one tile, `stride` dwords apart.
-struct TileOut {
-  uint32_t* lo;
-  uint32_t* hi;
-  int stride;
-};
-template <int TW>
-__device__ __forceinline__ TileOut tile_out(uint32_t* tiles, int t, int ntiles, int64_t wave, int N) {
-  static_assert(TW >= 2, "a generator wavefront writes two dwords of a tile row");
-  const int64_t tile_dw = TW == kSegTW ? list_tile_dwords_seg(N, TW) : list_tile_dwords(N, TW);
-  const int waves_per_tile = TW / 2;
-  const int tile = (int)(wave / waves_per_tile);
-  const int col = (int)(wave % waves_per_tile) * 2;   // two dwords of each row
-  uint32_t* base = tiles + ((int64_t)t * ntiles + tile) * tile_dw + col;
-  return {base, base + 1, TW};
-}
-// dword of tile row `row` relative to out.lo / out.hi: row * stride, except in the segmented
-// two-dword tiles of N > 20479 (scoary_common.hpp: every segment its own zero row)
-template <int TW>
-__device__ __forceinline__ int64_t tile_row_off(const TileOut& out, int N, int row) {
-  if constexpr (TW == kSegTW) return list_row_dword(N, row);
-  return (int64_t)row * out.stride;
-}
-// the all-zero row(s) that list padding points at (one thread)
-template <int TW>
-__device__ __forceinline__ void tile_zero_rows(const TileOut& out, int N) {
-  if constexpr (TW == kSegTW) {
-    const int nseg = list_segments(N);
-    if (nseg > 1) {
-      for (int sgm = 0; sgm < nseg; ++sgm) {
-        const int64_t z = (int64_t)sgm * kSegStride + list_seg_rows(N, sgm) * kSegTW;
-        out.lo[z] = 0u;
-        out.hi[z] = 0u;
-      }
-      return;
-    }
-  }
-  out.lo[(int64_t)N * out.stride] = 0u;
-  out.hi[(int64_t)N * out.stride] = 0u;
-}
-template <int TW>
-__global__ __launch_bounds__(64) void k_perm_generate_tiles(const uint32_t* __restrict__ masks,
-                                                            const int32_t* __restrict__ margins,
-                                                            int N, int Wp, int64_t P,
-                                                            int64_t perm_base, int trait_base,
-                                                            uint32_t k0, uint32_t k1, int ntiles,
-                                                            uint32_t* __restrict__ tiles) {
-  const int t = blockIdx.y;
-  const int lane = threadIdx.x;
-  const int64_t wave = blockIdx.x;                    // 64 permutations each
-  const int64_t pl = wave * kWave + lane;
-  const bool live = pl < P;
-  const uint32_t pi = (uint32_t)(perm_base + pl);
-  const TileOut out = tile_out<TW>(tiles, t, ntiles, wave, N);
-  uint32_t needed = (uint32_t)margins[2 * t], remaining = (uint32_t)margins[2 * t + 1];
-  const uint32_t* mrow = masks + (int64_t)t * Wp;
-  const int nw = (N + 31) / 32;
-  uint64_t mine = 0;
-  for (int k = 0; k < nw; ++k) {
-    const uint32_t mw = mrow[k];
-#pragma unroll 2
-    for (int jj = 0; jj < 8; ++jj) {
-      uint32_t r[4];
-      philox4x32_10((uint32_t)(k * 8 + jj), pi, (uint32_t)(trait_base + t), kPermDomain, k0, k1, r);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int bit = 4 * jj + q;
-        bool sel = false;
-        if ((mw >> bit) & 1u) {
-          if (__umulhi(r[q], remaining) < needed) {
-            sel = live;
-            --needed;
-          }
-          --remaining;
-        }
-        const uint64_t b = __ballot(sel);
-        const int iso = k * 32 + bit;
-        if ((iso & 63) == lane) mine = b;
-        if ((iso & 63) == 63 || iso == nw * 32 - 1) {  // 64 isolates collected: one row per lane
-          const int row = (iso & ~63) + lane;
-          if (row < N) {
-            const int64_t ro = tile_row_off<TW>(out, N, row);
-            out.lo[ro] = (uint32_t)mine;
-            out.hi[ro] = (uint32_t)(mine >> 32);
-          }
-          mine = 0;
-        }
-      }
-    }
-  }
-  if (lane == 0) tile_zero_rows<TW>(out, N);
-}
-
-// The same tiles from a workgroup per 64 permutations, for launches with fewer
-// wavefronts than the chip has SIMDs (few traits x permutations, long rows): the
-// sampling is serial over the isolates only in `needed` (two dependent VALU ops
-// per isolate) while the Philox draws are not, so kGenProducers wavefronts
-// compute umulhi(draw, valid isolates left) one 64-isolate chunk ahead into LDS
-// (lane = permutation in every wavefront) and ONE selection wavefront walks the
-// chunk; its compare mask over the 64 lanes IS the tile row of that isolate.
-constexpr int kGenProducers = 7;
-constexpr int kGenSplitBelow = 1;  // workgroup-of-8 variant below this many wavefronts per SIMD
-constexpr int kGenWg4Below = 8;    // workgroup-of-4 variant below this many
-constexpr int kGenChunk = 64;      // isolates per LDS buffer = 16 Philox counters
-// Philox counters (of the 16 per chunk) each producer wavefront computes.  A
-// workgroup's wavefronts go to the SIMDs cyclically, so wavefront 4 shares the
-// selection wavefront's SIMD and is given nothing.
-__constant__ const int8_t kGenWork[kGenProducers][3] = {
-    {0, 6, 12}, {1, 7, 13}, {2, 8, 14}, {-1, -1, -1}, {3, 9, 15}, {4, 10, -1}, {5, 11, -1}};
-
-// v[LANE] = value (wave-uniform); hipcc has no builtin for v_writelane_b32, and
-// its lane select must be an inline constant next to an SGPR value.
-template <int LANE>
-__device__ __forceinline__ void write_lane(uint32_t& v, uint32_t value) {
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(value), "n"(LANE));
-}
-// Spec-S4 selection for isolates II.. of a chunk: x[i] = umulhi(draw, valid isolates
-// left at i) as the producers stored it, mw = the chunk's validity bits
-// (wave-uniform; ALLVALID: all ones), livemask = lanes whose permutation exists.
-// The AND with livemask also makes the written value the result of a SALU op:
-// v_writelane_b32 sits in inline asm, where the compiler cannot see (and pad) the
-// gfx950 wait states between a VALU compare writing an SGPR and a VALU reading it.
-template <int II, bool ALLVALID>
-__device__ __forceinline__ void select_rows(const uint32_t (&x)[kGenChunk], uint64_t mw,
-                                            uint64_t livemask, uint32_t& needed, uint32_t& lo,
-                                            uint32_t& hi) {
-  if constexpr (II < kGenChunk) {
-    uint64_t b = 0;
-    if (ALLVALID || ((mw >> II) & 1u)) {               // wave-uniform
-      const bool hit = x[II] < needed;
-      needed -= hit ? 1u : 0u;
-      b = __builtin_amdgcn_ballot_w64(hit) & livemask;
-    }
-    write_lane<II>(lo, (uint32_t)b);                 // lane l: the row of isolate l of the chunk
-    write_lane<II>(hi, (uint32_t)(b >> 32));
-    select_rows<II + 1, ALLVALID>(x, mw, livemask, needed, lo, hi);
-  }
-}
-
-template <int TW>
-__global__ __launch_bounds__(kWave*(1 + kGenProducers)) void k_perm_generate_tiles_wg(
-    const uint32_t* __restrict__ masks, const int32_t* __restrict__ margins, int N, int Wp,
-    int64_t P, int64_t perm_base, int trait_base, uint32_t k0, uint32_t k1, int ntiles,
-    uint32_t* __restrict__ tiles) {
-  __shared__ uint32_t draws[2][kGenChunk][kWave];
-  const int t = blockIdx.y;
-  const int lane = threadIdx.x & (kWave - 1), role = threadIdx.x / kWave;   // 0: selection
-  const int64_t wave = blockIdx.x;                    // 64 permutations each
-  const int64_t pl = wave * kWave + lane;
-  const bool live = pl < P;
-  const uint32_t pi = (uint32_t)(perm_base + pl);
-  const TileOut out = tile_out<TW>(tiles, t, ntiles, wave, N);
-  uint32_t needed = (uint32_t)margins[2 * t];
-  const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
-  // valid isolates left at the start of the chunk this wavefront works on
-  // (producers run one chunk ahead of the selection wavefront)
-  uint32_t remaining = (uint32_t)__builtin_amdgcn_readfirstlane(margins[2 * t + 1]);
-  const uint32_t* mrow = masks + (int64_t)t * Wp;     // Wp >= 2*nchunks words, zero padded
-  const int nchunks = (N + kGenChunk - 1) / kGenChunk;
-  auto chunk_mask = [&](int c) -> uint64_t {
-    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * c]) |
-           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * c + 1]) << 32;
-  };
-  if (role == 0) __builtin_amdgcn_s_setprio(3);       // the serial wavefront goes first
-  for (int c = 0; c <= nchunks; ++c) {
-    if (role > 0) {
-      if (c < nchunks) {
-        const uint64_t mw = chunk_mask(c);
-        const uint32_t rem0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)remaining);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int jj = kGenWork[role - 1][k];
-          if (jj < 0) break;
-          uint32_t r[4];
-          philox4x32_10((uint32_t)(c * (kGenChunk / 4) + jj), pi, (uint32_t)(trait_base + t),
-                        kPermDomain, k0, k1, r);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {             // the quarter-rate multiply moves here too
-            const int ii = 4 * jj + q;
-            const uint32_t rem = rem0 - (uint32_t)__popcll(mw & (((uint64_t)1 << ii) - 1));
-            draws[c & 1][ii][lane] = __umulhi(r[q], rem);
-          }
-        }
-        remaining -= (uint32_t)__popcll(mw);
-      }
-    } else if (c > 0) {
-      const int cc = c - 1;
-      const uint64_t mw = chunk_mask(cc);
-      uint32_t x[kGenChunk];
-#pragma unroll
-      for (int ii = 0; ii < kGenChunk; ++ii) x[ii] = draws[cc & 1][ii][lane];
-      uint32_t lo = 0u, hi = 0u;
-      if (mw == ~(uint64_t)0)
-        select_rows<0, true>(x, mw, livemask, needed, lo, hi);
-      else
-        select_rows<0, false>(x, mw, livemask, needed, lo, hi);
-      const int row = cc * kGenChunk + lane;
-      if (row < N) {
-        const int64_t ro = tile_row_off<TW>(out, N, row);
-        out.lo[ro] = lo;
-        out.hi[ro] = hi;
-      }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) tile_zero_rows<TW>(out, N);
-}
-
-// The middle regime (one to eight wavefronts per SIMD): four wavefronts per 64
-// permutations, single LDS buffer (16 KB, eight workgroups per CU).  All four compute
-// the chunk's Philox draws, then wavefront 0 selects; the other workgroups of the CU
-// fill the gaps.  Spreads the quarter-rate Philox multiplies evenly over the SIMDs,
-// which one wavefront per 64 permutations cannot do with 1-2 wavefronts per SIMD.
-template <int TW>
-__global__ __launch_bounds__(kWave * 4) void k_perm_generate_tiles_wg4(
-    const uint32_t* __restrict__ masks, const int32_t* __restrict__ margins, int N, int Wp,
-    int64_t P, int64_t perm_base, int trait_base, uint32_t k0, uint32_t k1, int ntiles,
-    uint32_t* __restrict__ tiles) {
-  __shared__ uint32_t draws[kGenChunk][kWave];
-  const int t = blockIdx.y;
-  const int lane = threadIdx.x & (kWave - 1), role = threadIdx.x / kWave;
-  const int64_t wave = blockIdx.x;                    // 64 permutations each
-  const int64_t pl = wave * kWave + lane;
-  const bool live = pl < P;
-  const uint32_t pi = (uint32_t)(perm_base + pl);
-  const TileOut out = tile_out<TW>(tiles, t, ntiles, wave, N);
-  uint32_t needed = (uint32_t)margins[2 * t];
-  const uint64_t livemask = __builtin_amdgcn_ballot_w64(live);
-  uint32_t remaining = (uint32_t)__builtin_amdgcn_readfirstlane(margins[2 * t + 1]);
-  const uint32_t* mrow = masks + (int64_t)t * Wp;     // Wp >= 2*nchunks words, zero padded
-  const int nchunks = (N + kGenChunk - 1) / kGenChunk;
-  for (int c = 0; c < nchunks; ++c) {
-    const uint64_t mw = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * c]) |
-                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(mrow[2 * c + 1]) << 32;
-    const uint32_t rem0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)remaining);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {                      // 16 Philox counters per chunk, 4 per wavefront
-      const int jj = role + 4 * k;
-      uint32_t r[4];
-      philox4x32_10((uint32_t)(c * (kGenChunk / 4) + jj), pi, (uint32_t)(trait_base + t),
-                    kPermDomain, k0, k1, r);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ii = 4 * jj + q;
-        const uint32_t rem = rem0 - (uint32_t)__popcll(mw & (((uint64_t)1 << ii) - 1));
-        draws[ii][lane] = __umulhi(r[q], rem);
-      }
-    }
-    remaining -= (uint32_t)__popcll(mw);
-    __syncthreads();
-    if (role == 0) {
-      uint32_t x[kGenChunk];
-#pragma unroll
-      for (int ii = 0; ii < kGenChunk; ++ii) x[ii] = draws[ii][lane];
-      uint32_t lo = 0u, hi = 0u;
-      if (mw == ~(uint64_t)0)
-        select_rows<0, true>(x, mw, livemask, needed, lo, hi);
-      else
-        select_rows<0, false>(x, mw, livemask, needed, lo, hi);
-      const int row = c * kGenChunk + lane;
-      if (row < N) {
-        const int64_t ro = tile_row_off<TW>(out, N, row);
-        out.lo[ro] = lo;
-        out.hi[ro] = hi;
-      }
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) tile_zero_rows<TW>(out, N);
-}
+// zero; dword j of a row = labels of permutations tile*TW*32 + 32j .. +31
+// (written by k_labels, scoary_labels.hip).
 
 // Per (trait, list slot): the ACCEPTANCE interval of the two-sided test in terms of the
 // LIST count u (u = a for a ones-list, npos - a for a zeros-list), as [lo, hi1):
@@ -816,51 +544,6 @@ int scoary_list_params(int64_t N, int64_t* out5) {
   out5[3] = TW ? 64 / TW : 0;       /* residue classes of the isolate index (256-byte bank row) */
   out5[4] = TW ? (list_segments(N) > 1 ? kSegPiece : 4 * list_lpg(TW)) : 0;   /* interleave piece, entries (16-bit ones in segments) */
   return TW ? SCOARY_OK : SCOARY_ERR_SIZE;
-}
-
-int scoary_perm_generate_tiles(scoary_handle h, const uint32_t* d_masks, const int32_t* d_margins,
-                               int64_t T, int64_t N, int64_t P, int64_t perm_base,
-                               int64_t trait_base, uint64_t seed, uint32_t* d_tiles,
-                               scoary_stream_t stream) {
-  if (!h) return SCOARY_ERR_ARG;
-  if (!d_masks || !d_margins || !d_tiles || T < 1 || N < 1 || P < 1 || perm_base < 0 || trait_base < 0)
-    return fail(h, SCOARY_ERR_ARG, "scoary_perm_generate_tiles: bad argument");
-  if (T > 65535 || perm_base + P > 0xffffffffLL)
-    return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: T > 65535 or permutation index >= 2^32");
-  const int TW = list_tw(N);
-  if (!TW) return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: N too large for LDS tiles");
-  DeviceGuard guard(h->device);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int64_t tile_perms = TW * 32;
-  const int64_t ntiles = (P + tile_perms - 1) / tile_perms;
-  // one generator wavefront per 64 permutations of a tile row
-  const dim3 grid((unsigned)(ntiles * (tile_perms / kWave)), (unsigned)T);
-  KernelTimer kt(h, s, "k_perm_generate_tiles");
-  // three kernels for the same tiles, by how many 64-permutation wavefronts there are per
-  // SIMD: < 1: a workgroup of 8 (Philox producers + one selection wavefront, latency
-  // regime); 1..kGenWg4Below: a workgroup of 4 (balances the Philox work over the SIMDs);
-  // more: one wavefront each
-  const int64_t gen_waves = (int64_t)grid.x * grid.y, simds = (int64_t)h->num_cu * 4;
-  const int variant = gen_waves < simds * kGenSplitBelow ? 0 : (gen_waves < simds * kGenWg4Below ? 1 : 2);
-#define GEN_TILES(TWV)                                                                            \
-  if (variant == 0)                                                                               \
-    hipLaunchKernelGGL((k_perm_generate_tiles_wg<TWV>), grid, dim3(kWave * (1 + kGenProducers)),  \
-                       0, s, d_masks, d_margins, (int)N, (int)scoary_row_words(N), P, perm_base,  \
-                       (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles,      \
-                       d_tiles);                                                                  \
-  else if (variant == 1)                                                                          \
-    hipLaunchKernelGGL((k_perm_generate_tiles_wg4<TWV>), grid, dim3(kWave * 4), 0, s, d_masks,    \
-                       d_margins, (int)N, (int)scoary_row_words(N), P, perm_base,                 \
-                       (int)trait_base, (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles,      \
-                       d_tiles);                                                                  \
-  else                                                                                            \
-    hipLaunchKernelGGL((k_perm_generate_tiles<TWV>), grid, dim3(kWave), 0, s, d_masks, d_margins, \
-                       (int)N, (int)scoary_row_words(N), P, perm_base, (int)trait_base,           \
-                       (uint32_t)seed, (uint32_t)(seed >> 32), (int)ntiles, d_tiles)
-  if (TW == 16) { GEN_TILES(16); } else if (TW == 8) { GEN_TILES(8); } else if (TW == 4) { GEN_TILES(4); } else { GEN_TILES(2); }
-#undef GEN_TILES
-  HIP_TRY(h, hipGetLastError());
-  return SCOARY_OK;
 }
 
 extern "C++" {

@@ -172,6 +172,52 @@ def gather_genes(rec_local, G, dst=0, group=None, async_op=False, recv=None):
     return work, finish
 
 
+class LabelShards:
+    """Permutation shards of the label tiles (engine.label_shards): every rank generates one
+    contiguous share of a batch's flat (trait, tile) array and ONE all_gather_into_tensor over
+    RCCL / xGMI supplies the rest, in place (the tile array is padded to world equal chunks).
+
+    Spec S4's generator has no chain over the isolates, so a rank can also simply generate
+    every tile itself (cfg4: ~0.03 ms on one MI355X against ~0.8 MB per rank through a
+    collective whose latency alone is of that order).  Replication therefore stays the default;
+    the shards are opt-in (bench.py --label-shards, SCOARY_LABEL_SHARDS=1) for shapes where the
+    generator outweighs an all-gather of T * P * N / 8 bytes -- many traits x permutations on
+    long rows -- and are rehearsed at 8 ranks in tests/test_gpu_two_ranks.py."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.staged = dist.get_backend(group) != "nccl"      # gloo moves host memory
+        self.bytes_gathered = 0
+
+    def share(self, nflat):
+        """(tiles per rank, first tile of this rank, its tile count) for nflat flat tiles."""
+        per = -(-int(nflat) // self.world)
+        first = min(self.rank * per, int(nflat))
+        return per, first, min(per, int(nflat) - first)
+
+    def padded_words(self, nflat, tile_words):
+        return self.world * self.share(nflat)[0] * int(tile_words)
+
+    def all_gather(self, tiles, nflat, tile_words):
+        """tiles: int32 device tensor of >= padded_words(nflat, tile_words) words whose chunk
+        `rank` this rank has filled; on return every chunk is filled."""
+        torch = _torch()
+        import torch.distributed as dist
+        per = self.share(nflat)[0]
+        chunk = per * int(tile_words)
+        full = tiles[:self.world * chunk]
+        mine = full[self.rank * chunk:(self.rank + 1) * chunk]
+        if self.staged and tiles.device.type == "cuda":
+            recv = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(recv, mine.cpu(), group=self.group)
+            full.copy_(recv)
+        else:
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+        self.bytes_gathered += 4 * chunk * (self.world - 1)
+
+
 def all_gather_host_rows(rows, group=None):
     """rows: this rank's (R_k, W) numpy array (R_k differs between ranks) -> the (sum R_k, W)
     concatenation in rank order on every rank.  Used to put the bit rows of a table the

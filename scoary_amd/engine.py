@@ -61,10 +61,15 @@ class TraitPlan:
 
     def __init__(self, margins, mask_class, buf, traits, masks, N):
         self.margins, self.mask_class, self.buf, self.N = margins, mask_class, buf, int(N)
-        self.key = (traits.data_ptr(), masks.data_ptr(), tuple(traits.shape))
+        # strong references: the memory the plan describes cannot be recycled for other data
+        # while the plan lives, and `is` identifies the tensors (an address can be reused);
+        # _version sees in-place edits made through torch after the snapshot
+        self.traits, self.masks = traits, masks
+        self.versions = (traits._version, masks._version)
 
     def fits(self, traits, masks):
-        return self.key == (traits.data_ptr(), masks.data_ptr(), tuple(traits.shape))
+        return (traits is self.traits and masks is self.masks
+                and self.versions == (traits._version, masks._version))
 
 
 class Workspace:
@@ -85,12 +90,17 @@ class Workspace:
         self.crit = eng._empty((T, G, 2), torch.int32) if permutations > 0 else None
         self.r = eng._empty((T, G), torch.int32) if permutations > 0 else None
         self.tiles = self.scratch = self.perms = self.lcrit = None
+        self.label_shards = None
         self.auto = None        # engine.associate's cached hipGraph of a launch-bound step
         self.batch = 0
         if permutations > 0 and use_lists:
             self.batch = eng.list_batch(T, N, permutations, G)
             nb0 = min(self.batch, permutations)
-            self.tiles = eng._empty((int(eng.lib.scoary_list_tiles_words(N, nb0, T)),), torch.int32)
+            words = int(eng.lib.scoary_list_tiles_words(N, nb0, T))
+            if eng.label_shards is not None:          # room for world equal chunks (dist.LabelShards)
+                words = max(words, eng.label_shards.padded_words(*eng.tiles_per_batch(N, nb0, T)))
+            self.tiles = eng._empty((words,), torch.int32)
+            self.label_shards = eng.label_shards
             self.scratch = eng.permute_lists_scratch(G, T, N, nb0)
             self.lcrit = eng._empty((T, G, 2), torch.int32)
         elif permutations > 0:
@@ -110,14 +120,22 @@ class StepGraph:
 
     def __init__(self, eng, graph, stream):
         self.eng, self.graph, self.stream = eng, graph, stream
+        self.done = None        # event behind the most recent launch
 
     def launch(self):
         eng = self.eng
         eng._check(eng.lib.scoary_graph_launch(eng.h, self.graph, eng._stream()),
                    "scoary_graph_launch")
+        if self.done is None:
+            self.done = _torch().cuda.Event()
+        self.done.record(_torch().cuda.current_stream(eng.device))
 
     def close(self):
+        """Destroys the executable graph -- after its last launch has finished: the runtime
+        does not keep a destroyed graph alive for a launch that is still running."""
         if self.graph:
+            if self.done is not None:
+                self.done.synchronize()
             self.eng.lib.scoary_graph_destroy(self.graph)
             self.graph = None
 
@@ -144,6 +162,9 @@ class AssociationEngine:
         if rc != 0:
             raise _abi.ScoaryHipError("scoary_create(device=%d) failed: %d" % (self.device.index, rc))
         self.h = h
+        # dist.LabelShards: generate one share of every batch of label tiles and all-gather the
+        # rest (multi-GPU, opt-in); None: every rank generates all tiles (the default)
+        self.label_shards = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -225,14 +246,18 @@ class AssociationEngine:
 
     def list_budget_bytes(self):
         """Bytes build_lists may spend on one matrix's index array: SCOARY_LIST_BUDGET_MB if set
-        (tests), else 60 % of the device memory that is free right now -- label tiles (<= 8 GB)
+        (tests), else 60 % of the device memory that is free right now (the driver's figure plus what
+        torch's caching allocator holds unused) -- label tiles (<= 8 GB)
         and the count scratch (<= 4 GB) of a step still have to fit next to it."""
         import os
         mb = os.environ.get("SCOARY_LIST_BUDGET_MB")
         if mb:
             return int(float(mb) * (1 << 20))
-        free, _total = _torch().cuda.mem_get_info(self.device)
-        return int(free * 0.6)
+        torch = _torch()
+        free, _total = torch.cuda.mem_get_info(self.device)
+        # blocks the caching allocator holds but has not handed out are as good as free
+        cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        return int((free + max(cached, 0)) * 0.6)
 
     def list_kernel_name(self, N):
         """Timer label (scoary_last_kernel_ms) of the list-driven permutation kernel that
@@ -288,15 +313,31 @@ class AssociationEngine:
     def lists_supported(self, N):
         return int(N) <= int(self.lib.scoary_list_max_isolates())
 
-    def perm_generate_tiles(self, masks, margins, N, P, perm_base, seed, out=None, trait_base=0):
+    def perm_generate_tiles(self, masks, margins, N, P, perm_base, seed, out=None, trait_base=0,
+                            tile_range=None):
+        """Label tiles of permutations perm_base .. perm_base + P - 1 (perm_base a multiple of
+        32).  ``tile_range`` = (first, count): only these flat (trait, tile) indices of the
+        [T][tiles] array are written (scoary_perm_generate_tiles_range) -- one rank's share of a
+        run that all-gathers the rest (dist.LabelShards)."""
         torch = _torch()
         T = masks.shape[0]
         if out is None:
             out = self._empty((int(self.lib.scoary_list_tiles_words(N, P, T)),), torch.int32)
-        self._check(self.lib.scoary_perm_generate_tiles(
-            self.h, self._ptr(masks), self._ptr(margins), T, N, P, perm_base, trait_base,
-            ctypes.c_uint64(seed), self._ptr(out), self._stream()), "scoary_perm_generate_tiles")
+        if tile_range is None:
+            self._check(self.lib.scoary_perm_generate_tiles(
+                self.h, self._ptr(masks), self._ptr(margins), T, N, P, perm_base, trait_base,
+                ctypes.c_uint64(seed), self._ptr(out), self._stream()), "scoary_perm_generate_tiles")
+        else:
+            self._check(self.lib.scoary_perm_generate_tiles_range(
+                self.h, self._ptr(masks), self._ptr(margins), T, N, P, perm_base, trait_base,
+                ctypes.c_uint64(seed), int(tile_range[0]), int(tile_range[1]), self._ptr(out),
+                self._stream()), "scoary_perm_generate_tiles_range")
         return out
+
+    def tiles_per_batch(self, N, P, T):
+        """Flat (trait, tile) count and dwords per tile of a batch of P permutations."""
+        tw = self.list_params(N)[0]
+        return int(T) * (-(-int(P) // (32 * tw))), int(self.lib.scoary_list_tile_words(int(N)))
 
     def permute_lists_scratch(self, G, T, N, P):
         """Scratch tensor for permute_lists (list-order regions + per-part counts)."""
@@ -466,7 +507,8 @@ class AssociationEngine:
         """A step this small is bound by its five kernel launches (cfg2: 0.112 ms eager, 0.064 ms
         as one graph launch, profiles/r03_bench_cfg2*.json): associate() then records it into a
         hipGraph on its second call with the same buffers and replays it from the third on.
-        SCOARY_AUTO_GRAPH=0 switches it off."""
+        The recording call synchronises the device once (capture() warms the step up and records
+        on a fresh stream); SCOARY_AUTO_GRAPH=0 switches the whole mechanism off."""
         import os
         if os.environ.get("SCOARY_AUTO_GRAPH", "1") == "0":
             return False
@@ -478,14 +520,20 @@ class AssociationEngine:
         if getattr(self, "_timing", False) or torch.cuda.is_current_stream_capturing():
             return None
         L = genes.lists
-        key = (genes.tiled.data_ptr(), L.idx.data_ptr() if L is not None else 0, traits.data_ptr(),
-               masks.data_ptr(), plan.margins.data_ptr(), plan.mask_class.data_ptr(), genes.G, genes.N,
-               int(traits.shape[0]), int(permutations), int(seed), bool(use_lists))
+        # Everything a recorded step has baked in: the tensors themselves (compared by identity
+        # and kept alive by `refs`, so their memory cannot be recycled under the graph), their
+        # versions (in-place edits through torch since the recording) and the scalars.
+        refs = (genes.tiled, traits, masks, plan, plan.margins, plan.mask_class, plan.buf) + \
+            ((L.idx, L.start, L.ngroups, L.order, L.flipped) if L is not None else ())
+        scalars = (genes.G, genes.N, int(traits.shape[0]), int(permutations), int(seed), bool(use_lists),
+                   tuple(getattr(x, "_version", 0) for x in refs))
         st = ws.auto
-        if st is None or st["key"] != key:
+        same = st is not None and st["scalars"] == scalars and len(st["refs"]) == len(refs) and \
+            all(a is b for a, b in zip(st["refs"], refs))
+        if not same:
             if st is not None and st["graph"] is not None:
-                st["graph"].close()
-            ws.auto = {"key": key, "calls": 1, "graph": None, "res": None}
+                st["graph"].close()                       # waits for its last launch first
+            ws.auto = {"refs": refs, "scalars": scalars, "graph": None, "res": None}
             return None                                   # first call with these buffers: eager
         if st["graph"] is None:                           # second call: record (runs the step as well)
             st["graph"], st["res"] = self.capture(genes, traits, masks, permutations, seed, ws,
@@ -495,6 +543,19 @@ class AssociationEngine:
             return st["res"]
         st["graph"].launch()
         return st["res"]
+
+    def _label_tiles(self, ws, masks, margins, N, nb, base, seed):
+        """One batch of label tiles into ws.tiles: all of them, or -- with label shards -- this
+        rank's share followed by the all-gather of the others'."""
+        sh = ws.label_shards
+        if sh is None or sh.world == 1:
+            self.perm_generate_tiles(masks, margins, N, nb, base, seed, out=ws.tiles)
+            return
+        nflat, tile_words = self.tiles_per_batch(N, nb, masks.shape[0])
+        _per, first, count = sh.share(nflat)
+        self.perm_generate_tiles(masks, margins, N, nb, base, seed, out=ws.tiles,
+                                 tile_range=(first, count))
+        sh.all_gather(ws.tiles, nflat, tile_words)
 
     def associate(self, genes, traits, masks, permutations=0, seed=0, perm_buffer=None,
                   use_lists=None, workspace=None, plan=None, graph=None):
@@ -521,7 +582,7 @@ class AssociationEngine:
         # launch-bound steps with persistent buffers (workspace + plan): replay a cached hipGraph
         # (graph=None: automatic; False: never -- capture() itself, per-kernel timing)
         if graph is None and workspace is not None and plan is not None and perm_buffer is None \
-                and self.auto_graph_eligible(genes, T, permutations):
+                and ws.label_shards is None and self.auto_graph_eligible(genes, T, permutations):
             res = self._auto_graph(genes, traits, masks, permutations, seed, use_lists, ws, plan)
             if res is not None:
                 return res
@@ -539,7 +600,7 @@ class AssociationEngine:
             side.wait_stream(main)
             nb0 = min(ws.batch, permutations)
             with torch.cuda.stream(side):
-                self.perm_generate_tiles(masks, margins, genes.N, nb0, 0, seed, out=ws.tiles)
+                self._label_tiles(ws, masks, margins, genes.N, nb0, 0, seed)
             p, odds, crit, lcrit = self.fisher(counts, out=(ws.p, ws.odds, ws.crit),
                                                lists=genes.lists, lcrit=ws.lcrit)
             main.wait_stream(side)
@@ -547,7 +608,7 @@ class AssociationEngine:
             while done < permutations:
                 nb = min(ws.batch, permutations - done)
                 if done > 0:
-                    self.perm_generate_tiles(masks, margins, genes.N, nb, done, seed, out=ws.tiles)
+                    self._label_tiles(ws, masks, margins, genes.N, nb, done, seed)
                 self.permute_lists(genes, ws.tiles, None, margins, nb, ws.r, scratch=ws.scratch,
                                    lcrit=lcrit, accumulate=done > 0)
                 done += nb

@@ -39,7 +39,7 @@ def tiles_case(eng, case, seed=11):
     if case % 10 == 9:
         T, P = 3, 22000                                   # >= 1024 wavefronts: one-wavefront kernel
         N = int(rng.choice([64, 100, 333]))
-    base = int(rng.integers(0, 1000))
+    base = 32 * int(rng.integers(0, 32))               # tiles start at a multiple of 32 permutations
     traits = _traits(rng, T, N, 0.6)
     tb, mb = _bits(traits)
     masks, trv = eng.vecrows(mb, N), eng.vecrows(tb, N)

@@ -403,13 +403,14 @@ def test_permute_lists_equals_dense_and_oracle(eng, orc, G, N, T, P):
                                    (333, 4, 17000), (100, 3, 180000), (12001, 2, 130),
                                    (20479, 1, 70)])
 def test_perm_tiles_are_the_transposed_row_labels(eng, N, T, P):
-    """k_perm_generate_tiles writes the same spec-S4 labels as k_perm_generate,
+    """scoary_perm_generate_tiles writes the same spec-S4 labels as scoary_perm_generate,
     isolate-major in tiles of 512 / 256 / 128 / 64 permutations, zero row + zero ragged
-    tail (the segmented tiles of N > 20479: test_segmented_list_path_vs_dense_and_oracle).  Few (trait, 64-permutation) wavefronts -> the workgroup variant with
-    Philox producer wavefronts; 1024..8191 of them (last-but-one case) -> the
-    four-wavefront workgroup; more (last case) -> one wavefront each."""
+    tail (the segmented tiles of N > 20479: test_segmented_list_path_vs_dense_and_oracle).
+    The cases cover one, two and four dword columns per block (few / many (trait, tile)
+    pairs) and 256 ... 1024 threads per block.  Tiles start at a multiple of 32 permutations;
+    the row form takes any base (test_perm_labels_bit_exact)."""
     rng = np.random.default_rng(2)
-    base = 40
+    base = 64
     traits = (rng.random((T, N)) < 0.4).astype(np.uint8)
     traits[T - 1, rng.random(N) < 0.1] = 2
     tb, mb = _bits(eng, traits)
@@ -484,6 +485,11 @@ def test_c_abi_error_codes(eng):
     assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, null, null, p, p, 4, 1, 100, 10, p, 1, null) == -1
     assert lib.scoary_permute(h, p, p, p, 1, 70000, 10, 10, p, null) == -3          # T > 65535
     assert lib.scoary_perm_generate(h, p, p, 1, 10, 2**33, 0, 0, 1, p, null) == -3   # index >= 2^32
+    nmax = int(lib.scoary_perm_max_isolates())
+    assert nmax >= 600_000                                                             # one permutation per LDS row
+    assert lib.scoary_perm_generate(h, p, p, 1, nmax + 1, 1, 0, 0, 1, p, null) == -3
+    assert lib.scoary_perm_generate_tiles(h, p, p, 1, 100, 64, 40, 0, 1, p, null) == -1   # tiles start at a multiple of 32
+    assert lib.scoary_perm_generate_tiles_range(h, p, p, 2, 100, 600, 0, 0, 1, 3, 2, p, null) == -1   # 2 x 2 tiles: range past the end
     assert lib.scoary_permute_lists(h, p, p, 0, p, p, p, p, p, null, p, p, 4, 1, 131071, 10, p, 1, null) == -3
     assert b"LDS" in lib.scoary_last_error(h)
     assert lib.scoary_tree_pairs(h, p, 3, 40, p, p, 1, 1, 2, p, null) == -3          # stack_depth > 32
@@ -1010,8 +1016,8 @@ def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
     assert S == -(-N // SEG) and eng.list_params(N) == (2, 8, 64, 32, 8)
     # (1) tiles: [T][tiles][S][STRIDE dwords], row r of segment s = dwords 2r, 2r + 1
     _, margins = eng.counts(gm, trv, mkv)
-    rows = eng.perm_generate(mkv, margins, N, P, 3, 17).cpu().numpy().view(np.uint32)
-    tiles = eng.perm_generate_tiles(mkv, margins, N, P, 3, 17).cpu().numpy().view(np.uint32)
+    rows = eng.perm_generate(mkv, margins, N, P, 32, 17).cpu().numpy().view(np.uint32)
+    tiles = eng.perm_generate_tiles(mkv, margins, N, P, 32, 17).cpu().numpy().view(np.uint32)
     ntiles = -(-P // 64)
     assert int(eng.lib.scoary_list_tile_words(N)) == S * STRIDE
     tiles = tiles.reshape(T, ntiles, S, STRIDE)
