@@ -69,7 +69,7 @@ def parse(argv=None):
     ap.add_argument("--permutations", type=int, default=None, help="override P")
     ap.add_argument("--isolates", type=int, default=None, help="override N (shape experiments)")
     ap.add_argument("--traits", type=int, default=None, help="override T (shape experiments)")
-    ap.add_argument("--gene-kind", default=None, choices=["uniform", "rare", "ushaped"],
+    ap.add_argument("--gene-kind", default=None, choices=["uniform", "rare", "ushaped", "balanced"],
                     help="gene-frequency spectrum instead of the config's own (evidence lines next to the "
                          "BASELINE configs: ushaped = Beta(0.15, 0.15), a pan-genome-like spectrum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,7 +101,16 @@ def parse(argv=None):
                          "timed region (amdsmi or hwmon); 0 switches it off")
     ap.add_argument("--inject-gather-fault", action="store_true", help=argparse.SUPPRESS)   # tests: corrupt one
     # received record before --verify-gather looks at it; every rank must then exit non-zero, together
-    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+    ap.add_argument("--label-shards", action="store_true",
+                    help="multi-GPU: every rank generates 1/world of each batch of label tiles and one "
+                         "all_gather_into_tensor supplies the rest (dist.LabelShards); default: every rank "
+                         "generates all tiles (spec S4's generator costs less than the collective's latency "
+                         "on the BASELINE shapes)")
+    ap.add_argument("--k1-cold", action="store_true",
+                    help="also time k_counts on a working set the 256 MiB Infinity Cache cannot hold "
+                         "(roofline_k1.cold): cfg5's 125 000 x 10 000 shard with T = 1 and 4, eight matrices "
+                         "in rotation")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="after the timed region (single GPU): run the step back to back this long and report "
                          "the clock / power the box sustains (the `sustained` object); 0 skips it")
     ap.add_argument("--dry-exchange", action="store_true",
@@ -678,6 +687,59 @@ def small_kernel_rooflines(args, G, N, T, n_mask_classes, kernel_ms):
     return out
 
 
+def k1_cold_report(eng, args, G=125_000, N=10_000, copies=8, rounds=3):
+    """K1 as an HBM stream: k_counts on cfg5's per-GPU shard shape with T = 1 and
+    T = 4, over `copies` different matrices launched in rotation.  One tiled matrix is 160 MB, eight are
+    1.28 GB: when a matrix comes round again, 1.1 GB of other matrices have gone through the 256 MiB
+    Infinity Cache since its last use, so every launch reads HBM.  The content does not enter the timing
+    (random bits, made on the device).  The same kernel on ONE matrix back to back rides along as `warm`."""
+    import torch
+    from scoary_amd import synth
+    from scoary_amd.engine import GeneMatrix, pack_bits_rows
+    W64 = (N + 63) // 64
+    Qp, Gp = eng.quads(N), eng.padded_genes(G)
+    gen = torch.Generator(device=eng.device)
+    gen.manual_seed(5)
+    mats = [GeneMatrix(torch.randint(-2**31, 2**31 - 1, (Qp, Gp, 4), dtype=torch.int32, device=eng.device,
+                                     generator=gen), G, N) for _ in range(copies)]
+    copy_gbs = measured_copy_peak(eng.device)
+    out = {"shape": "%d genes x %d isolates (cfg5's per-GPU shard), %d tiled matrices of %.0f MB in rotation"
+                    % (G, N, copies, Qp * Gp * 16 / 1e6),
+           "measured_copy_peak_gbs": copy_gbs, "hbm_peak_gbs": HBM_PEAK_GBS, "runs": []}
+    rng = np.random.default_rng(11)
+    for T in (1, 4):
+        traits = synth.make_traits(T, N, rng)
+        trv = eng.vecrows(pack_bits_rows((traits == 1).astype(np.uint8)), N)
+        mkv = eng.vecrows(pack_bits_rows((traits != 2).astype(np.uint8)), N)
+        plan = eng.trait_plan(trv, mkv, N)
+        counts = eng._empty((T, G, 4), torch.int32)
+        b1 = 8.0 * W64 * G + 16.0 * W64 * T + 16.0 * G * T
+
+        def timed(seq):
+            for m in seq[:copies]:
+                eng.counts(m, trv, mkv, out=(counts,), plan=plan)
+            torch.cuda.synchronize()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)]
+            evs[0].record()
+            for i, m in enumerate(seq):
+                eng.counts(m, trv, mkv, out=(counts,), plan=plan)
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(len(seq)))
+            return sum(ms) / len(ms), ms[len(ms) // 2]
+        cold_mean, cold_med = timed(mats * rounds)
+        warm_mean, warm_med = timed([mats[0]] * (copies * rounds))
+        out["runs"].append({
+            "traits": T, "bytes": b1, "bytes_formula": "8*W*G + 16*W*T + 16*G*T (SURVEY 8d B1)",
+            "cold_ms_mean": cold_mean, "cold_ms_median": cold_med,
+            "gbs": b1 / (cold_med * 1e-3) / 1e9,
+            "hbm_frac": b1 / (cold_med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_of_measured_copy_peak": b1 / (cold_med * 1e-3) / 1e9 / copy_gbs,
+            "warm_ms_median": warm_med, "warm_gbs": b1 / (warm_med * 1e-3) / 1e9,
+            "launches": copies * rounds})
+    return out
+
+
 def dry_exchange(args, world, rank):
     """CPU-only: the launcher, process group, Exchange pipeline and rank-0 check with
     fabricated records (gloo)."""
@@ -772,6 +834,8 @@ def main():
     G_total = G_cfg if bounds is not None else G * world
 
     eng = AssociationEngine(local_rank)
+    if sharded and args.label_shards:
+        eng.label_shards = sdist.LabelShards()     # 1 / world of every batch of label tiles + one all-gather
     rows64 = pack_bits_rows(genes)                 # host packing: excluded like file parsing
     tbits = pack_bits_rows((traits == 1).astype(np.uint8))
     mbits = pack_bits_rows((traits != 2).astype(np.uint8))
@@ -883,7 +947,12 @@ def main():
     # K1 and K2 by themselves (roofline_k1 / roofline_k2): inside a step k_fisher shares the chip with
     # the label-tile generator on the side stream, so its in-step duration is not its own
     iso = {}
-    for name, fn in (("k_counts", lambda: eng.counts(gm, trv, mkv, out=(ws.counts,), plan=plan)),
+    saved_shards, ws.label_shards = ws.label_shards, None     # the generator alone: all tiles, no collective
+    gen = ()
+    if use_lists and P > 0:
+        gen = (("k_perm_generate_tiles",
+                lambda: eng.perm_generate_tiles(mkv, plan.margins, N, min(ws.batch, P), 0, seed, out=ws.tiles)),)
+    for name, fn in gen + (("k_counts", lambda: eng.counts(gm, trv, mkv, out=(ws.counts,), plan=plan)),
                      ("k_fisher", lambda: eng.fisher(ws.counts, out=(ws.p, ws.odds, ws.crit),
                                                      **({"lists": gm.lists, "lcrit": ws.lcrit} if use_lists and P > 0
                                                         else {})))):
@@ -896,6 +965,8 @@ def main():
         e1.record()
         e1.synchronize()
         iso[name] = e0.elapsed_time(e1) / 5
+    ws.label_shards = saved_shards
+    k1_cold = k1_cold_report(eng, args) if (args.k1_cold and world == 1) else None
 
     # The box under SUSTAINED load (single GPU, outside the timed region, GPU still warm): the same
     # step back to back for --sustain-seconds, clock and power from the second half of the window.
@@ -936,6 +1007,8 @@ def main():
                 "ms_per_step_median": median_ms, "kernel_ms": kernel_ms,
                 "exchange_exposed_ms": exposed_ms,
                 "exchange_bytes": T * G * sdist.REC_WORDS * 4,
+                "label_tile_bytes_gathered": None if eng.label_shards is None
+                else eng.label_shards.bytes_gathered // max(args.steps + args.warmup, 1),
                 "sclk_mhz_mean": telemetry and telemetry["sclk_mhz_mean"],
                 "socket_power_w_mean": telemetry and telemetry["socket_power_w_mean"]}
         per_rank = sdist.all_gather_objects(mine)
@@ -952,6 +1025,7 @@ def main():
         if args.inject_gather_fault:
             last[world - 1, 0, 0, 8] += 1                    # r of the last rank's first record
         gather_ok = True
+        eng.label_shards = None                      # rank 0 alone: every label tile generated here
         for rk, (a, b) in enumerate(sdist.shard_bounds(exchange.total, world)):
             g_rk = eng.tile_rows(pack_bits_rows(shard_of(rk)), N)
             if use_lists:
@@ -998,6 +1072,8 @@ def main():
                        "genes_per_gpu": G, "genes_total": G_total, "isolates": N, "traits": T,
                        "permutations": P, "parallelism": "gene-shard x%d" % world,
                        "hip_graph": bool(graph), "hip_graph_auto": bool(auto_graph),
+                       "label_tiles": "1/%d per rank + all_gather_into_tensor" % world
+                       if (sharded and args.label_shards) else "generated on every rank",
                        "exchange": ("%s %s of per-gene records" % (
                            "rccl" if args.backend == "nccl" else "gloo (shared-GPU functional check)",
                            exchange.kind)) if exchange
@@ -1036,6 +1112,14 @@ def main():
         out["kernel_ms_isolated"] = iso            # five back-to-back launches of the kernel alone
         out.update(small_kernel_rooflines(
             args, G, N, T, sum(len(np.unique(cls[a:a + tpp])) for a in range(0, T, tpp)), iso))
+        if "roofline_k1" in out:
+            out["roofline_k1"]["note"] = (
+                "timed on ONE matrix launched back to back: a matrix below the 256 MiB Infinity Cache (every "
+                "BASELINE shape but cfg5's shard) is served from it after the first launch, so gbs here is a "
+                "cache-resident rate, not an HBM rate; roofline_k1.cold (bench.py --k1-cold, "
+                "profiles/r05_k1_stream.json) is the HBM figure")
+            if k1_cold is not None:
+                out["roofline_k1"]["cold"] = k1_cold
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline_port(genes, traits, N, seed, args.cpu_seconds)
             try:

@@ -22,7 +22,7 @@
 //            (scoary_perm_generate, through 32 ballots per 64 isolates).
 //
 // A block = (trait, NB dword columns of 32 permutations); its rows live in LDS until the fix-up is
-// done: N * NB * 4 bytes (NB = 1, 2, 4 by how many blocks the launch has).  Beyond N = 40 000 a
+// done: N * NB * 4 bytes (NB = 1 or 2 by how many blocks the launch has).  Beyond N = 40 000 a
 // row keeps only 16 / 8 / ... 1 of the 32 permutations of a dword (more Philox work per label,
 // still parallel in N).
 #include "scoary_common.hpp"
@@ -100,7 +100,7 @@ struct LabelArgs {
 };
 
 // NB dword columns per block (NB > 1 only with all 32 permutations per dword); OUT 0: tiles, 1: rows
-template <int NB, int OUT>
+template <int NB, int OUT>   // NB = 1, 2
 __global__ __launch_bounds__(1024) void k_labels(const LabelArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, tpb = blockDim.x, nwaves = tpb >> 6;
@@ -203,9 +203,7 @@ __global__ __launch_bounds__(1024) void k_labels(const LabelArgs a) {
         }
     }
     if (elt == 32) {
-      if constexpr (NB == 4) {
-        *reinterpret_cast<uint4*>(xs + (int64_t)row * 4) = make_uint4(x[0], x[1], x[2], x[3]);
-      } else if constexpr (NB == 2) {
+      if constexpr (NB == 2) {
         *reinterpret_cast<uint2*>(xs + (int64_t)row * 2) = make_uint2(x[0], x[1]);
       } else {
         xs[row] = x[0];
@@ -218,6 +216,7 @@ __global__ __launch_bounds__(1024) void k_labels(const LabelArgs a) {
   // ---- marks per permutation: butterfly over the wavefront, then one LDS atomic per wavefront ----
 #pragma unroll
   for (int w = 0; w < NB; ++w) {
+    if (a.debug & 8) break;
     uint32_t c[kSumPlanes];
 #pragma unroll
     for (int k = 0; k < kSumPlanes; ++k) c[k] = k < kCntPlanes ? cp[w][k] : 0u;
@@ -249,34 +248,100 @@ __global__ __launch_bounds__(1024) void k_labels(const LabelArgs a) {
   }
   __syncthreads();
 
-  // ---- fix-up: lane = permutation ----
-  if (tid < stride_bits) {
-    const int w = tid >> 5, j = tid & 31;
-    const bool alive = (live[NB == 1 ? 0 : w] >> (bit0 + j)) & 1u;
+  // ---- fix-up: a group of L lanes per permutation ----
+  // Spec S4 consumes the position draws c = 0, 1, 2, ... one after the other; but as long as at
+  // least as many marks are missing as a batch has draws, EVERY distinct candidate the batch hits
+  // is toggled, whatever the order -- so lane l of the group takes Philox call base + l (four
+  // draws) and the group toggles with LDS atomics (the returned old bit says who was first at a
+  // position).  A round uses k = min(L, |d| / 4) calls, so it can never overshoot; the last
+  // < 4 marks are placed by the group's first lane, draw by draw.
+  {
+    const int nperm = stride_bits;                       // permutations of this block
+    const int L = min(kWave, tpb / nperm);               // a power of two, >= 2
+    const int pidx = tid / L, l = tid & (L - 1);
+    const bool in_group = pidx < nperm;                  // tpb > 64 * nperm: the last wavefronts idle
+    const int w = pidx >> 5, j = pidx & 31;
+    const bool alive = in_group && ((live[NB == 1 ? 0 : (w & (NB - 1))] >> (bit0 + j)) & 1u);
     const uint32_t pi = (Bglob + (uint32_t)w) * 32u + (uint32_t)(bit0 + j);
-    int d = alive && !(a.debug & 1) ? (int)plan.m - kc[tid] : 0;          // > 0: add marks, < 0: remove marks
+    int d = alive && !(a.debug & 1) ? (int)plan.m - kc[in_group ? pidx : 0] : 0;   // > 0: add marks, < 0: remove
     const uint32_t reject_below = (uint32_t)(((uint64_t)1 << 32) % (uint64_t)N);
-    for (uint32_t c4 = 0; d != 0 && c4 < kFixMaxCalls; ++c4) {
-      uint32_t r[4];
-      philox4x32_10(c4, pi, tglob, kDomFix, a.k0, a.k1, r);
+    const uint64_t gmask = (L == 64 ? ~(uint64_t)0 : (((uint64_t)1 << L) - 1)) << (lane & ~(L - 1));
+    const int leader = lane & ~(L - 1);
+    // one draw: position from a Philox word, toggled if it is a candidate; returns 1 if this lane
+    // changed the bit
+    // Four draws of one Philox call: positions, then the toggles as LDS atomics -- an OR on a
+    // marked isolate / an AND on an unmarked one changes nothing, so only invalid isolates have
+    // to be kept away (add mode), and the returned old word says whether THIS lane changed the
+    // bit.  The four atomics are independent: issued back to back, one wait.  `upto`: stop after
+    // that many changes (the sequential tail; 4 = no limit).
+    auto draws4 = [&](const uint32_t (&rnd)[4], bool add) -> int {
+      uint32_t idx[4], bit[4];
+      bool ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (d == 0) break;
-        const uint64_t prod = (uint64_t)r[u] * (uint64_t)(uint32_t)N;
-        if ((uint32_t)prod < reject_below) continue;
+        const uint64_t prod = (uint64_t)rnd[u] * (uint64_t)(uint32_t)N;
         const uint32_t pos = (uint32_t)(prod >> 32);
-        const uint32_t bp = pos * (uint32_t)stride_bits + (uint32_t)tid;
-        const uint32_t word = __hip_atomic_load(&xs[bp >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const bool marked = (word >> (bp & 31u)) & 1u;
-        if (d > 0) {
-          if (!marked && ((vm[pos >> 5] >> (pos & 31u)) & 1u)) {
-            __hip_atomic_fetch_xor(&xs[bp >> 5], 1u << (bp & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            --d;
-          }
-        } else if (marked) {
-          __hip_atomic_fetch_xor(&xs[bp >> 5], 1u << (bp & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          ++d;
+        const uint32_t bp = pos * (uint32_t)stride_bits + (uint32_t)pidx;
+        idx[u] = bp >> 5;
+        bit[u] = 1u << (bp & 31u);
+        ok[u] = (uint32_t)prod >= reject_below;          // Lemire rejection: no draw otherwise
+        if (add) ok[u] = ok[u] && ((vm[pos >> 5] >> (pos & 31u)) & 1u);
+      }
+      uint32_t old[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        old[u] = add ? bit[u] : 0u;                      // "no change" for the draws that are none
+        if (ok[u])
+          old[u] = add ? __hip_atomic_fetch_or(&xs[idx[u]], bit[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                       : __hip_atomic_fetch_and(&xs[idx[u]], ~bit[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      int won = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) won += add ? ((old[u] & bit[u]) ? 0 : 1) : ((old[u] & bit[u]) ? 1 : 0);
+      return won;
+    };
+    // one draw at a time (the last < 4 marks): returns 1 if the bit changed
+    auto draw1 = [&](uint32_t rnd, bool add) -> int {
+      const uint64_t prod = (uint64_t)rnd * (uint64_t)(uint32_t)N;
+      if ((uint32_t)prod < reject_below) return 0;
+      const uint32_t pos = (uint32_t)(prod >> 32);
+      const uint32_t bp = pos * (uint32_t)stride_bits + (uint32_t)pidx, b1 = 1u << (bp & 31u);
+      if (add) {
+        if (!((vm[pos >> 5] >> (pos & 31u)) & 1u)) return 0;
+        return (__hip_atomic_fetch_or(&xs[bp >> 5], b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & b1) ? 0 : 1;
+      }
+      return (__hip_atomic_fetch_and(&xs[bp >> 5], ~b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & b1) ? 1 : 0;
+    };
+    uint32_t base = 0;                                   // next Philox call of this permutation
+    while (d != 0 && base < kFixMaxCalls) {              // group-uniform
+      const bool add = d > 0;
+      const int need = add ? d : -d;
+      const int k = min(L, need >> 2);
+      uint32_t r[4];
+      if (k == 0) {                                      // the last marks: in draw order
+        int left = need;
+        if (l == 0) {
+          philox4x32_10(base, pi, tglob, kDomFix, a.k0, a.k1, r);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (left > 0) left -= draw1(r[u], add);
         }
+        left = __shfl(left, leader);
+        d = add ? left : -left;
+        base += 1u;
+      } else {
+        int won = 0;
+        if (l < k) {
+          philox4x32_10(base + (uint32_t)l, pi, tglob, kDomFix, a.k0, a.k1, r);
+          won = draws4(r, add);
+        }
+        // marks toggled by the group in this round
+        int got = 0;
+#pragma unroll
+        for (int bitn = 0; bitn < 3; ++bitn)
+          got += __popcll(__ballot((won >> bitn) & 1) & gmask) << bitn;
+        d = add ? d - got : d + got;
+        base += (uint32_t)k;
       }
     }
   }
@@ -298,15 +363,14 @@ __global__ __launch_bounds__(1024) void k_labels(const LabelArgs a) {
     }
     return f;
   };
+  if (a.debug & 4) return;
   if constexpr (OUT == 0) {
     const bool seg = a.TW == kSegTW;                  // two-dword tiles: segmented above N = 20479
     auto row_off = [&](int64_t row) -> int64_t { return seg ? list_row_dword(N, row) : row * a.TW; };
     if (elt == 32) {
       for (int row = tid; row < N; row += tpb) {
         uint32_t* dst = tile_base + row_off(row);
-        if constexpr (NB == 4) {
-          *reinterpret_cast<uint4*>(dst) = make_uint4(row_field(row, 0), row_field(row, 1), row_field(row, 2), row_field(row, 3));
-        } else if constexpr (NB == 2) {
+        if constexpr (NB == 2) {
           *reinterpret_cast<uint2*>(dst) = make_uint2(row_field(row, 0), row_field(row, 1));
         } else {
           dst[0] = row_field(row, 0);
@@ -369,6 +433,11 @@ int labels_elt(int64_t N, int min_elt) {
   for (int elt = 32; elt >= min_elt; elt >>= 1)
     if (labels_lds_bytes(N, elt, 1) <= kLabelsMaxLds) return elt;
   return 0;
+}
+// tuning experiments (tools/gen_time.py): SCOARY_LABELS_TPB / SCOARY_LABELS_NB override the launch geometry
+int labels_env(const char* name) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : 0;
 }
 int labels_debug() {
   static const int v = [] { const char* e = std::getenv("SCOARY_LABELS_DEBUG"); return e ? std::atoi(e) : 0; }();
@@ -469,20 +538,23 @@ int scoary_perm_generate_tiles_range(scoary_handle h, const uint32_t* d_masks, c
   a.debug = labels_debug();
   // dword columns per block: as many as keep >= 2 blocks per CU in the launch and >= 2 blocks
   // of LDS per CU (wider pieces per tile row, fewer count reductions)
+  // (four columns per block were measured too: the fix-up then has two lanes per permutation and
+  // the kernel is slower at the headline shape, 0.086 against 0.077 ms)
   int NB = 1;
   if (elt == 32)
-    for (int nb = 4; nb > 1; nb >>= 1)
+    for (int nb = 2; nb > 1; nb >>= 1)
       if (nb <= TW && n_tiles * (TW / nb) >= 2 * (int64_t)h->num_cu &&
           labels_lds_bytes(N, 32, nb) <= kLabelsMaxLds / 2) {
         NB = nb;
         break;
       }
+  if (elt == 32 && labels_env("SCOARY_LABELS_NB") && labels_env("SCOARY_LABELS_NB") <= (TW < 2 ? TW : 2)) NB = labels_env("SCOARY_LABELS_NB");
   const int64_t units = (int64_t)TW * (32 / elt) / NB;
   const int64_t gx = (n_tiles + 7) / 8 * 8 * units;
   if (gx > 0x7fffffffLL) return fail(h, SCOARY_ERR_SIZE, "scoary_perm_generate_tiles: grid too large");
-  const int tpb = labels_threads(n_tiles * units, N, h->num_cu);
+  int tpb = labels_threads(n_tiles * units, N, h->num_cu);
+  if (labels_env("SCOARY_LABELS_TPB")) tpb = labels_env("SCOARY_LABELS_TPB");
   KernelTimer kt(h, s, "k_perm_generate_tiles");
-  if (NB == 4) return launch_labels<4, 0>(h, s, a, dim3((unsigned)gx), tpb, elt);
   if (NB == 2) return launch_labels<2, 0>(h, s, a, dim3((unsigned)gx), tpb, elt);
   return launch_labels<1, 0>(h, s, a, dim3((unsigned)gx), tpb, elt);
 }

@@ -595,15 +595,21 @@ class AssociationEngine:
             # worth 0.2 % at cfg3 and nothing on the launch-bound shapes, while k_counts then
             # shares the chip with the generator and its own duration -- the path's one HBM
             # stream, reported as roofline_k1 -- can no longer be read off the step.)
+            import os
             main = torch.cuda.current_stream(self.device)
-            side = self._side_stream()
-            side.wait_stream(main)
             nb0 = min(ws.batch, permutations)
-            with torch.cuda.stream(side):
+            if os.environ.get("SCOARY_GEN_SIDE_STREAM", "1") == "1":
+                side = self._side_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._label_tiles(ws, masks, margins, genes.N, nb0, 0, seed)
+                p, odds, crit, lcrit = self.fisher(counts, out=(ws.p, ws.odds, ws.crit),
+                                                   lists=genes.lists, lcrit=ws.lcrit)
+                main.wait_stream(side)
+            else:
                 self._label_tiles(ws, masks, margins, genes.N, nb0, 0, seed)
-            p, odds, crit, lcrit = self.fisher(counts, out=(ws.p, ws.odds, ws.crit),
-                                               lists=genes.lists, lcrit=ws.lcrit)
-            main.wait_stream(side)
+                p, odds, crit, lcrit = self.fisher(counts, out=(ws.p, ws.odds, ws.crit),
+                                                   lists=genes.lists, lcrit=ws.lcrit)
             done = 0
             while done < permutations:
                 nb = min(ws.batch, permutations - done)

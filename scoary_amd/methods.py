@@ -144,24 +144,77 @@ class TraitResults(Mapping):
 
     FIELDS = ("tpgp", "tngp", "tpgn", "tngn", "sens", "spes", "OR", "p_v", "B_p", "BH_p")
 
-    def __init__(self, genes, nugn, annotation, cols, number_of_tests, members=None):
-        self.genes = list(genes)
-        self.nugn = list(nugn)
-        self.annotation = list(annotation)
+    def __init__(self, genes, nugn, annotation, cols, number_of_tests, members=None, table=None,
+                 rows_idx=None):
+        """Either explicit name lists (``genes`` / ``nugn`` / ``annotation``: the --collapse units,
+        plain reference dicts) or -- the common case -- ``table`` + ``rows_idx``: row i is gene
+        ``rows_idx[i]`` of the GeneTable and its names are looked up when asked for.  A result set
+        of G genes x T traits then costs T index arrays, not G x T Python strings; only the rows
+        that are written (or read through the mapping interface) are ever materialised."""
+        self._table, self._rows_idx = table, rows_idx
+        self._genes = None if table is not None else list(genes)
+        self._nugn = None if table is not None else list(nugn)
+        self._annotation = None if table is not None else list(annotation)
         self.cols = cols                         # field -> ndarray
         self.number_of_tests = number_of_tests
         self.members = members                   # collapse: row -> list of source gene ids
-        self._index = {g: i for i, g in enumerate(self.genes)}
+        self._index_cache = None
+        self.p_order = None                      # stable argsort of cols["p_v"], if already known
+
+    # names of one row: O(1), nothing materialised
+    def gene_at(self, i):
+        return self._genes[i] if self._genes is not None else self._table.ids[self._rows_idx[i]]
+
+    def nugn_at(self, i):
+        return self._nugn[i] if self._nugn is not None else self._table.nugn[self._rows_idx[i]]
+
+    def annotation_at(self, i):
+        return self._annotation[i] if self._annotation is not None \
+            else self._table.annotation[self._rows_idx[i]]
+
+    def source_index(self, i):
+        """Row of the GeneTable behind result row i (the last member of a --collapse unit)."""
+        if self._rows_idx is not None:
+            return int(self._rows_idx[i])
+        return None
+
+    # whole name lists (the reference's dict view): built on first use
+    @property
+    def genes(self):
+        if self._genes is None:
+            ids = self._table.ids
+            self._genes = [ids[i] for i in self._rows_idx]
+        return self._genes
+
+    @property
+    def nugn(self):
+        if self._nugn is None:
+            v = self._table.nugn
+            self._nugn = [v[i] for i in self._rows_idx]
+        return self._nugn
+
+    @property
+    def annotation(self):
+        if self._annotation is None:
+            v = self._table.annotation
+            self._annotation = [v[i] for i in self._rows_idx]
+        return self._annotation
+
+    @property
+    def _index(self):
+        if self._index_cache is None:
+            self._index_cache = {g: i for i, g in enumerate(self.genes)}
+        return self._index_cache
 
     def __len__(self):
-        return len(self.genes)
+        return len(self._rows_idx) if self._genes is None else len(self._genes)
 
     def __iter__(self):
         return iter(self.genes)
 
     def __getitem__(self, gene):
         i = self._index[gene]
-        row = {"NUGN": self.nugn[i], "Annotation": self.annotation[i]}
+        row = {"NUGN": self.nugn_at(i), "Annotation": self.annotation_at(i)}
         for k, col in self.cols.items():
             v = col[i]
             row[k] = int(v) if k in ("tpgp", "tngp", "tpgn", "tngn") else \
@@ -178,12 +231,23 @@ class GeneTraitCombinations(Mapping):
     only the tree stage of the reference consumes it."""
 
     def __init__(self, table, genes, members, trait_row, trait_index=0):
-        self.table, self.genes, self.members, self.trait_row = table, list(genes), members, trait_row
+        """``genes``: a list of names or the trait's TraitResults (names looked up on demand)."""
+        self.table, self._names, self.members, self.trait_row = table, genes, members, trait_row
         self.trait_index = trait_index           # enters the permutation counters (spec S4)
-        self._index = {g: i for i, g in enumerate(self.genes)}
+        self._index_cache = None
+
+    @property
+    def genes(self):
+        return self._names.genes if isinstance(self._names, TraitResults) else self._names
+
+    @property
+    def _index(self):
+        if self._index_cache is None:
+            self._index_cache = {g: i for i, g in enumerate(self.genes)}
+        return self._index_cache
 
     def __len__(self):
-        return len(self.genes)
+        return len(self._names)
 
     def __iter__(self):
         return iter(self.genes)
@@ -203,6 +267,36 @@ class GeneTraitCombinations(Mapping):
 
 
 # ---------------------------------------------------------------------------
+# Stage clock: seconds per named stage of a command-line run ("Stage detail" log line)
+# ---------------------------------------------------------------------------
+class _Stages:
+    def __init__(self):
+        self.seconds = {}
+
+    def reset(self):
+        self.seconds = {}
+
+    def __call__(self, name):
+        return _StageTimer(self, name)
+
+
+class _StageTimer:
+    def __init__(self, owner, name):
+        self.owner, self.name = owner, name
+
+    def __enter__(self):
+        self.t0 = _time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        self.owner.seconds[self.name] = self.owner.seconds.get(self.name, 0.0) + _time.perf_counter() - self.t0
+        return False
+
+
+_stage = _Stages()
+
+
+# ---------------------------------------------------------------------------
 # Engine singleton
 # ---------------------------------------------------------------------------
 _ENGINE = None
@@ -212,7 +306,24 @@ def get_engine():
     global _ENGINE
     if _ENGINE is None:
         _ENGINE = AssociationEngine()
+        _warm_up(_ENGINE)
     return _ENGINE
+
+
+def _warm_up(eng):
+    """One tiny pass through the path when the engine is created: the first launch of the
+    library loads its code object, the first copies set up torch's allocator and staging
+    buffers -- tens of milliseconds that belong to process start-up, not to the association
+    stage of the first (and usually only) data set."""
+    import torch
+    g = eng.pack_dense(np.array([[1, 0, 1, 0], [0, 1, 1, 0]], dtype=np.uint8))
+    lab = pack_bits_rows(np.array([[1, 1, 0, 0]], dtype=np.uint8))
+    val = pack_bits_rows(np.ones((1, 4), dtype=np.uint8))
+    trv, mkv = eng.vecrows(lab, 4), eng.vecrows(val, 4)
+    eng.build_lists(g)
+    res = eng.associate(g, trv, mkv, permutations=32, seed=1)
+    eng.pack_records(res).cpu()
+    torch.cuda.synchronize(eng.device)
 
 
 # ---------------------------------------------------------------------------
@@ -546,7 +657,7 @@ def Perform_statistics(traits, genes):
             "hash": int(pattern, 2) if pattern else 0, "gene_trait": gene_trait}
 
 
-def bonferroni_bh(p_sorted_input, number_of_tests):
+def bonferroni_bh(p_sorted_input, number_of_tests, order=None):
     """Bonferroni and step-up Benjamini-Hochberg exactly as methods.py:903-925.
 
     ``p_sorted_input``: p-values in insertion order.  The reference sorts
@@ -555,13 +666,14 @@ def bonferroni_bh(p_sorted_input, number_of_tests):
     tie = exact equality with the next sorted p.  Vectorised without changing
     a single floating-point operation: inside a run of equal p only the run's
     last (highest-rank) element evaluates min(); every other member copies it.
-    So: reversed cumulative minimum over the run ends, broadcast to the runs."""
+    So: reversed cumulative minimum over the run ends, broadcast to the runs.
+    ``order``: the stable ascending argsort of the p-values if the caller already has it."""
     p = np.asarray(p_sorted_input, dtype=np.float64)
     n = p.shape[0]
     if n == 0:
         # the reference raises IndexError at methods.py:914 here (SURVEY A.4-3)
         raise IndexError("no testable genes for this trait")
-    order = np.argsort(p, kind="stable")
+    order = np.argsort(p, kind="stable") if order is None else order
     sp = p[order]
     v = sp * number_of_tests / (np.arange(n, dtype=np.float64) + 1.0)
     v[n - 1] = sp[n - 1]
@@ -610,14 +722,17 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
     from . import dist
     eng = get_engine()
     G, N, T = len(table), len(table.strains), tarr.shape[0]
-    trv = eng.vecrows(pack_bits_rows(tarr == 1), N)
-    mkv = eng.vecrows(pack_bits_rows(tarr != 2), N)
-    plan = eng.trait_plan(trv, mkv, N)            # margins + mask classes: once per trait set
+    with _stage("device setup (H2D, tiling, trait plan)"):
+        trv = eng.vecrows(pack_bits_rows(tarr == 1), N)
+        mkv = eng.vecrows(pack_bits_rows(tarr != 2), N)
+        plan = eng.trait_plan(trv, mkv, N)            # margins + mask classes: once per trait set
 
     def local(a, b):
         if b <= a:
             return torch.zeros((T, 0, dist.REC_WORDS), dtype=torch.int32, device=eng.device)
-        gm = table.on_device(eng) if (a, b) == (0, G) else eng.tile_rows(table.rows64[a:b], N)
+        with _stage("device setup (H2D, tiling, trait plan)"):
+            gm = table.on_device(eng) if (a, b) == (0, G) else eng.tile_rows(table.rows64[a:b], N)
+            torch.cuda.synchronize(eng.device)
         if permutations > 0 and not early_abort and gm.lists is None and eng.lists_supported(N):
             # list-driven permutation kernel: cost follows each gene's minority count.  The
             # index array (4 bytes per padded minority entry, 2 for N > 20479) is sized by the
@@ -625,7 +740,9 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
             # dense kernels (same results, no lists) instead of dying in the allocator
             from .engine import ListMemoryError
             try:
-                eng.build_lists(gm)
+                with _stage("index lists (device)"):
+                    eng.build_lists(gm)
+                    torch.cuda.synchronize(eng.device)
             except (ListMemoryError, torch.cuda.OutOfMemoryError) as e:
                 gm.lists = None
                 log.info("index lists not built (%s); using the dense permutation kernels" % e)
@@ -642,13 +759,51 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
                                               T_._abort_thresholds(permutations))
             res["r"] = r
             return eng.pack_records(res, nstop=nstop)
-        res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed, plan=plan)
-        return eng.pack_records(res)
+        with _stage("kernels (counts, Fisher, permutations)"):
+            res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed, plan=plan)
+            rec = eng.pack_records(res)
+            torch.cuda.synchronize(eng.device)
+        return rec
 
-    out = dist.numpy_records(dist.associate_sharded(local, G))
+    rec = dist.associate_sharded(local, G)
+    with _stage("results D2H"):
+        p_order = _p_order_on_device(rec)
+        out = dist.numpy_records(rec)
+        out["p_order"] = p_order
     if permutations <= 0:
         out["r"] = None
     return out
+
+
+def _p_order_on_device(rec):
+    """Per trait: the testable genes (skip rule, methods.py:804-814) in ascending order of their
+    Fisher p, ties in file order -- the stable sort Benjamini-Hochberg (methods.py:903-925) and
+    the results writer (:1124) both start from.  The records are still on the device here, so the
+    one O(G log G) step of the host statistics is one batched torch.argsort there (a stable sort
+    of 200 000 doubles is 25-40 ms per trait in numpy, 50 traits x 1 M genes would be a minute).
+    Returns a list of int64 arrays of positions into the trait's testable genes."""
+    torch = _torch_mod()
+    T, G, _ = rec.shape
+    if G == 0:
+        return [np.zeros(0, dtype=np.int64) for _ in range(T)]
+    r = rec.contiguous()
+    c = r[:, :, 0:4]
+    testable = ((c[:, :, 0] + c[:, :, 2]) != 0) & ((c[:, :, 1] + c[:, :, 3]) != 0)
+    pv = r[:, :, 4:6].reshape(-1).clone().view(torch.float64).view(T, G)
+    key = torch.where(testable, pv, torch.full_like(pv, float("inf")))
+    order = torch.argsort(key, dim=1, stable=True).to(torch.int32).cpu().numpy()
+    tst = testable.cpu().numpy()
+    out = []
+    for t in range(T):
+        n = int(tst[t].sum())
+        pos = np.cumsum(tst[t]) - 1                       # gene index -> position among the testable
+        out.append(pos[order[t, :n]].astype(np.int64))
+    return out
+
+
+def _torch_mod():
+    import torch
+    return torch
 
 
 def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEED,
@@ -668,8 +823,10 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
                                        eng.vecrows(pack_bits_rows(tarr != 2), N))
     all_traits, combos = {}, {}
     G = len(table)
-    for t, trait in enumerate(names):
-        log.info("Gene-wise counting and Fisher's exact tests for trait: %s" % str(trait))
+    t_host = _time.perf_counter()
+
+    def one_trait(t):
+        trait = names[t]
         c = dev["counts"][t]                                   # tpgp, tpgn, tngp, tngn
         testable = ((c[:, 0] + c[:, 2]) != 0) & ((c[:, 1] + c[:, 3]) != 0)
         number_of_tests = G - int((~testable).sum())
@@ -683,9 +840,10 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
             emp = (dev["r"][t].astype(np.float64) + 1.0) / (n_used + 1.0)
 
         if not collapse:
-            rows_idx, members, names_out = idx, None, [table.ids[i] for i in idx]
-            nugn = [table.nugn[i] for i in idx]
-            ann = [table.annotation[i] for i in idx]
+            # names stay in the GeneTable: the result rows are (table, idx) -- nothing per
+            # (gene, trait) is materialised in Python (a cfg5-sized run has 50 M such pairs)
+            rows_idx, members, names_out = idx, None, None
+            nugn = ann = None
             plist = p_all[idx]
             bh_rank_p = plist
         else:
@@ -724,12 +882,17 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
         with np.errstate(divide="ignore", invalid="ignore"):
             sens = np.where(num_pos > 0, cc[:, 0].astype(np.float64) / num_pos * 100, 0.0)
             spes = np.where(num_neg > 0, cc[:, 3].astype(np.float64) / num_neg * 100, 0.0)
-        if len(names_out) == 0:
+        if len(rows_idx) == 0:
             raise IndexError("Trait %s has no testable genes" % trait)
+        # stable ascending order of the testable genes' p: from the device if it came along
+        p_order = dev["p_order"][t] if dev.get("p_order") is not None else None
         if not collapse:
-            B, BH = bonferroni_bh(plist, number_of_tests)
+            if p_order is None:
+                p_order = np.argsort(plist, kind="stable")
+            B, BH = bonferroni_bh(plist, number_of_tests, order=p_order)   # order shared with the writer
         else:
-            _, bh_all = bonferroni_bh(bh_rank_p, number_of_tests)
+            _, bh_all = bonferroni_bh(bh_rank_p, number_of_tests, order=p_order)
+            p_order = None                                   # the units' own p order is the writer's business
             BH = bh_all[bh_entry]
             B = np.minimum(plist * number_of_tests, 1.0)
         cols = {"tpgp": cc[:, 0], "tngp": cc[:, 2], "tpgn": cc[:, 1], "tngn": cc[:, 3],
@@ -737,8 +900,20 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
                 "B_p": B, "BH_p": BH}
         if emp is not None:
             cols["Empirical_p"] = emp[rows_idx]
-        all_traits[trait] = TraitResults(names_out, nugn, ann, cols, number_of_tests, members)
-        combos[trait] = GeneTraitCombinations(table, names_out, members, tarr[t], t)
+        if collapse:
+            tr = TraitResults(names_out, nugn, ann, cols, number_of_tests, members)
+        else:
+            tr = TraitResults(None, None, None, cols, number_of_tests, None, table=table, rows_idx=rows_idx)
+            tr.p_order = p_order
+        return tr, GeneTraitCombinations(table, tr, members, tarr[t], t)
+
+    for trait in names:
+        log.info("Gene-wise counting and Fisher's exact tests for trait: %s" % str(trait))
+    done = [one_trait(t) for t in range(len(names))]
+    for trait, (tr, gtc) in zip(names, done):
+        all_traits[trait], combos[trait] = tr, gtc
+    _stage.seconds["host statistics (skip rule, B / BH, columns)"] = \
+        _stage.seconds.get("host statistics (skip rule, B / BH, columns)", 0.0) + _time.perf_counter() - t_host
     return {"Results": all_traits, "Gene_trait_combinations": combos}
 
 
@@ -848,9 +1023,10 @@ def StoreResults(Results, max_hits, cutoffs, upgmatree, GTC, Prunedic, outdir, p
     for Trait in Results:
         sys.stdout.write("\n")
         log.info("Storing results: " + Trait)
-        StoreTraitResult(Results[Trait], Trait, max_hits, cutoffs, upgmatree, GTC, Prunedic,
-                         outdir, permutations, num_threads, no_pairwise, genedic,
-                         extracolstoprint, firstcolnames, time, delimiter, seed=seed)
+        with _stage("result files (sort, filter, pairwise stage, write)"):
+            StoreTraitResult(Results[Trait], Trait, max_hits, cutoffs, upgmatree, GTC, Prunedic,
+                             outdir, permutations, num_threads, no_pairwise, genedic,
+                             extracolstoprint, firstcolnames, time, delimiter, seed=seed)
 
 
 def decideifbreak(cutoffs, currentgene):
@@ -906,7 +1082,8 @@ def _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC, Prunedic, 
     if len(Prunedic[Traitname]) > 0:
         tree = T.prune_missing(upgmatree, Prunedic[Traitname])
     stage = _TreeStage(get_engine(), tree, table.strains, gtc.trait_row, gtc.trait_index, seed)
-    src = [table.index(Trait.members[i][-1] if Trait.members is not None else Trait.genes[i])
+    src = [Trait.source_index(i) if Trait.source_index(i) is not None else
+           table.index(Trait.members[i][-1] if Trait.members is not None else Trait.gene_at(i))
            for i in keep]
     rows64 = table.rows64[src]
     obs = stage.observed(rows64)
@@ -963,7 +1140,8 @@ def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Pruned
 
     n = len(Trait)
     num_results = n if max_hits is None else min(max_hits, n)
-    order = np.argsort(np.asarray(Trait.column("p_v"), dtype=np.float64), kind="stable")
+    order = Trait.p_order if getattr(Trait, "p_order", None) is not None else \
+        np.argsort(np.asarray(Trait.column("p_v"), dtype=np.float64), kind="stable")
     order = order[:num_results]
     fields = ["tpgp", "tngp", "tpgn", "tngn", "sens", "spes", "OR", "p_v", "B_p", "BH_p"]
     if no_pairwise:
@@ -1019,15 +1197,15 @@ def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Pruned
             if ok:
                 rows.append((i, int(k)))
     log.info("Storing results to file")
-    names, nugn, ann, members = Trait.genes, Trait.nugn, Trait.annotation, Trait.members
+    members = Trait.members
     with open(fname, "w") as out:
         out.write(delimiter.join('"' + c + '"' for c in columns) + "\n")
         for i, k in rows:
-            gene = names[i]
+            gene = Trait.gene_at(i)                     # only the rows that are written get names
             if "_|_" in gene:
                 cells = gene.split("_|_")
             else:
-                cells = [gene, str(nugn[i]), str(ann[i])]
+                cells = [gene, str(Trait.nugn_at(i)), str(Trait.annotation_at(i))]
             cells += [_fmt(colget[f][i]) for f in fields]
             if extra is not None:
                 cells += [_fmt(extra["max_total_pairs"][k]), _fmt(extra["max_propairs"][k]),
@@ -1233,13 +1411,17 @@ def main(**kwargs):
                 allowed = {iso: "all" for line in f for iso in line.rstrip().split(",")}
         elif args.write_reduced:
             sys.exit("You cannot use the -w argument without specifying a subset (-r)")
+        _stage.reset()
+        with _stage("import torch, HIP library, engine"):
+            get_engine()               # the first GPU call of the process: torch import, library load, context
         with open(args.genes, "r", newline=None) as genes, \
                 open(args.traits, "r", newline=None) as traits:
             log.info("Reading gene presence absence file")
             grab = [-999] if args.grabcols == "ALL" else args.grabcols
-            gd = Csv_to_dic_Roary(genes, args.delimiter, grab, startcol=int(args.start_col) - 1,
-                                  allowed_isolates=allowed, writereducedset=args.write_reduced,
-                                  time=stamp, outdir=args.outdir)
+            with _stage("read gene table"):
+                gd = Csv_to_dic_Roary(genes, args.delimiter, grab, startcol=int(args.start_col) - 1,
+                                      allowed_isolates=allowed, writereducedset=args.write_reduced,
+                                      time=stamp, outdir=args.outdir)
             genedic, strains = gd["Roarydic"], gd["Strains"]
             upgmatree = None
             if args.newicktree is None and not args.no_pairwise:
@@ -1265,7 +1447,8 @@ def main(**kwargs):
                     keepset = set(strains)
                     upgmatree = T.prune_missing(upgmatree, [i for i in members if i not in keepset])
             log.info("Reading traits file")
-            traitsdic, prunedic = Csv_to_dic(traits, args.delimiter, allowed, strains)
+            with _stage("read traits"):
+                traitsdic, prunedic = Csv_to_dic(traits, args.delimiter, allowed, strains)
         t_loaded = _time.time()
         log.info("Finished loading files into memory.\n\n")
         log.info("==== Performing statistics ====")
@@ -1288,6 +1471,9 @@ def main(**kwargs):
                          gd["Firstcolnames"], time=stamp, delimiter=args.delimiter, seed=seed)
         log.info("Stage seconds: load (+tree) %.2f, association (+permutations) %.2f, pairwise stage and "
                  "output %.2f" % (t_loaded - start, t_stats - t_loaded, _time.time() - t_stats))
+        gene_bytes = os.path.getsize(args.genes) if os.path.isfile(args.genes) else 0
+        log.info("Stage detail: " + "; ".join("%s %.3f s" % kv for kv in _stage.seconds.items())
+                 + ("; gene table %.0f MB" % (gene_bytes / 1e6) if gene_bytes else ""))
         log.info("\n")
         log.info("==== Finished ====")
         log.info("Checked a total of %d genes for associations to %d trait(s). Total time "

@@ -18,7 +18,8 @@ CONFIGS = {
 def make_genes(G, N, rng, kind="uniform", core_frac=0.0, block=4096):
     """(G, N) uint8 presence matrix.  kind="uniform": gene frequency
     f_g ~ U(0.02, 0.98); kind="rare": minor-allele frequency ~ Beta(0.3, 3)
-    (VCF-like); kind="ushaped": f_g ~ Beta(0.15, 0.15) (U-shaped pan-genome spectrum).  core_frac of the genes are forced all-present / all-absent
+    (VCF-like); kind="ushaped": f_g ~ Beta(0.15, 0.15) (U-shaped pan-genome spectrum);
+    kind="balanced": f_g ~ U(0.4, 0.6) (the list-driven kernel's worst case).  core_frac of the genes are forced all-present / all-absent
     (alternating) to exercise the skip rule (methods.py:804-814)."""
     out = np.empty((G, N), dtype=np.uint8)
     for g0 in range(0, G, block):
@@ -30,6 +31,10 @@ def make_genes(G, N, rng, kind="uniform", core_frac=0.0, block=4096):
             # few at intermediate frequency -- Beta(0.15, 0.15); not a BASELINE config, an evidence
             # line next to cfg3 (bench.py --gene-kind ushaped)
             f = rng.beta(0.15, 0.15, size=(g1 - g0, 1)).astype(np.float32)
+        elif kind == "balanced":
+            # the list kernel's floor: every gene near 50 %, the minority lists as long as they get
+            # (bench.py --gene-kind balanced)
+            f = rng.uniform(0.4, 0.6, size=(g1 - g0, 1)).astype(np.float32)
         else:
             f = rng.uniform(0.02, 0.98, size=(g1 - g0, 1)).astype(np.float32)
         out[g0:g1] = rng.random((g1 - g0, N), dtype=np.float32) < f

@@ -151,6 +151,48 @@ def test_gather_to_rank0_gloo():
     assert got[1] == [None, None] and got[2] == [None, None]
 
 
+def _label_shard_worker(rank, world, port, outq):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from scoary_amd import dist as sd
+    sd.init_from_env()
+    sh = sd.LabelShards()
+    res = []
+    for nflat, tw in ((7, 5), (3, 4), (12, 1), (1, 6)):        # fewer tiles than ranks included
+        per, first, count = sh.share(nflat)
+        tiles = torch.full((sh.padded_words(nflat, tw) + 3,), -1, dtype=torch.int32)
+        full = torch.arange(nflat * tw, dtype=torch.int32) + 100 * nflat
+        tiles[first * tw:(first + count) * tw] = full[first * tw:(first + count) * tw]    # this rank's share
+        sh.all_gather(tiles, nflat, tw)
+        res.append((per, first, count, tiles[:nflat * tw].numpy().copy(), full.numpy()))
+    outq.put((rank, res, sh.bytes_gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_label_tile_shards_all_gather_gloo():
+    """dist.LabelShards: every rank fills its contiguous share of the flat (trait, tile) array and
+    one all_gather_into_tensor, in place, supplies the others' -- the permutation shards of the
+    label generator (engine.label_shards, bench.py --label-shards)."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_label_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res, nbytes in got:
+        for per, first, count, tiles, full in res:
+            assert np.array_equal(tiles, full), rank
+            assert first <= rank * per and 0 <= count <= per
+        assert nbytes > 0
+
+
 def _exchange_worker(rank, world, port, outq):
     """bench.py's Exchange (async gather, two receive buffers, drained at the
     barrier) driven for several steps on CPU tensors."""

@@ -486,6 +486,77 @@ def test_cli_cfg2_sized_table_every_row_vs_oracle(tmp_path):
     assert top[0] == "g00011"                          # the planted gene wins its trait
 
 
+def test_cli_vcf_pipeline_every_row_vs_oracle(tmp_path):
+    """BASELINE configs[3] as it is literally defined -- "VCF-derived" -- at 20 000 sites x 1000
+    isolates: a synthetic haploid VCF (rare variants, ~3 % multi-allelic sites, a few missing
+    calls; tools/e2e_vcf.py writes the same file at 200 000 x 5000) -> scoary_amd.vcf2scoary ->
+    the command line with -s 11 (nine fixed columns + DUMMY), --no_pairwise --permute, and every
+    output row against the oracle fed by an INDEPENDENT reading of the VCF that applies the
+    reference's rules itself: one table row per ALT allele (scoary/vcf2scoary.py:186-214), the
+    identifier CHROM_|_POS_|_ID (scoary/methods.py:437-460) -- so the rows of a multi-allelic
+    site collide and the last allele's row replaces the earlier ones in place (dict overwrite) --
+    and a missing call "." that is written through at bi-allelic sites and therefore READS AS
+    PRESENT, but is "0" at multi-allelic ones."""
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import e2e_vcf
+    from oracle import oracle as orc
+    from scoary_amd import vcf2scoary
+    from scoary_amd.engine import pack_bits_rows
+    sites, N, P, seed = 20_000, 1000, 500, 31
+    rng = np.random.default_rng(9)
+    vcf, table = str(tmp_path / "in.vcf"), str(tmp_path / "mutations.csv")
+    nrows, names = e2e_vcf.write_vcf(vcf, sites, N, rng, multi_frac=0.03, missing_frac=0.001)
+    lab = rng.random(N) < 0.3
+    with open(tmp_path / "traits.csv", "w") as f:
+        f.write(",resistance\n" + "".join("%s,%d\n" % (s, v) for s, v in zip(names, lab)))
+    assert vcf2scoary.convert_file(vcf, table, log=lambda *a: None) == nrows > sites
+    files = run_cli(["-g", table, "-t", str(tmp_path / "traits.csv"), "-s", "11", "--no_pairwise",
+                     "-e", str(P), "--seed", str(seed), "-p", "1.0"], tmp_path / "out")
+    # independent reading of the VCF
+    dense = np.zeros((sites, N), dtype=np.uint8)
+    ident = []
+    with open(vcf) as f:
+        k = 0
+        for line in f:
+            if line.startswith("#"):
+                continue
+            q = line.rstrip("\n").split("\t")
+            alts = q[4].split(",")
+            if len(alts) == 1:
+                dense[k] = [0 if g in ("", "0", "-") else 1 for g in q[9:]]       # "." reads as present
+            else:
+                last = len(alts)                                                  # the last allele's row survives
+                dense[k] = [1 if g == str(last) else 0 for g in q[9:]]
+            ident.append((q[0], q[1], q[2]))
+            k += 1
+    assert k == sites
+    gb = orc.pack_rows(dense)
+    tb = pack_bits_rows(lab[None].astype(np.uint8))
+    mb = pack_bits_rows(np.ones((1, N), dtype=np.uint8))
+    r = orc.permute_r(gb, tb, mb, N, P, seed)
+    cnt = orc.counts_packed(gb, tb, mb)[:, 0]
+    _, p = orc.fisher_many(cnt)
+    rows = list(csv.reader(io.StringIO(files["resistance.results.csv"])))
+    col = {c: i for i, c in enumerate(rows[0])}
+    assert rows[0][:3] == ["#CHROM", "POS", "ID"]
+    keep = [g for g in range(sites) if cnt[g, 0] + cnt[g, 2] and cnt[g, 1] + cnt[g, 3]]
+    assert len(rows) - 1 == len(keep) > sites // 2
+    seen = set()
+    for d in rows[1:]:
+        g = int(d[2])                                    # the ID column is the site number
+        seen.add(g)
+        assert (d[0], d[1], d[2]) == ident[g]
+        assert [int(d[col[c]]) for c in
+                ("Number_pos_present_in", "Number_neg_present_in",
+                 "Number_pos_not_present_in", "Number_neg_not_present_in")] == \
+            [cnt[g, 0], cnt[g, 2], cnt[g, 1], cnt[g, 3]]
+        assert abs(float(d[col["Naive_p"]]) - p[g]) <= 1e-12 + 1e-11 * p[g]
+        assert d[col["Empirical_p"]] == repr((float(r[g, 0]) + 1.0) / (P + 1.0))
+    assert seen == set(keep)
+    naive = [float(d[col["Naive_p"]]) for d in rows[1:]]
+    assert all(a <= b * (1 + 1e-9) for a, b in zip(naive, naive[1:]))
+
+
 def test_cli_wide_table_takes_the_segmented_list_path(tmp_path, caplog):
     """The command line on a table WIDER than one LDS label tile (41 000 isolates > 20 479, and
     past the 40 959 at which the dense kernels used to take over; round 3): the list-driven

@@ -132,6 +132,29 @@ def test_bench_eight_ranks_cfg4_strong_split():
     assert abs(d["value"] - 200_000 * 10_000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_eight_ranks_cfg4_label_tile_shards():
+    """The same launch with PERMUTATION SHARDS of the label tiles (bench.py --label-shards,
+    dist.LabelShards): every rank generates 5 of the 40 tiles of 256 permutations
+    (scoary_perm_generate_tiles_range) and one all_gather_into_tensor, in place, supplies the
+    other 35; --verify-gather then compares every rank's records with rank 0's recomputation
+    from tiles it generated all by itself -- so a tile that arrived wrong, or in the wrong
+    place, shows up as a wrong exceedance count."""
+    d = _bench(["--scaling", "strong", "--no-cpu-baseline", "--label-shards"], ranks=8, config="cfg4", steps=2)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["gather_matches_single_rank"] is True
+    assert d["config"]["label_tiles"].startswith("1/8 per rank")
+    tile_bytes = 4 * ((5000 + 1) * 8)                      # one tile: 5001 rows of 8 dwords
+    assert all(r["label_tile_bytes_gathered"] == 7 * 5 * tile_bytes for r in d["per_rank"])
+
+
+def test_bench_three_ranks_label_tile_shards_many_traits():
+    """Label-tile shards where the flat (trait, tile) array does not divide by the ranks: 4 traits x
+    3 tiles of 512 permutations over 3 ranks = 4 tiles each, a share that crosses a trait boundary."""
+    d = _bench(["--scaling", "weak", "--no-cpu-baseline", "--label-shards", "--traits", "4",
+                "--permutations", "1500", "--genes", "3000"], ranks=3, config="cfg2", steps=2)
+    assert d["n_gpus"] == 3 and d["rccl_ranks"] == 3 and d["gather_matches_single_rank"] is True
+    assert d["config"]["label_tiles"].startswith("1/3 per rank")
+
+
 def test_bench_eight_ranks_cfg5_weak_shards():
     """cfg5 (BASELINE.json configs[4], 8 x MI355X): every rank its own shard of the 10 000-isolate
     x 50-trait x 100 000-permutation problem (8000 genes per rank here instead of 125 000 -- the
