@@ -52,7 +52,7 @@ VALU_PEAK_AND_BCNT = 4.1e13
 # 6.06e13 at 8 waves per SIMD (out of its reach: <= 64 VGPRs)
 VALU_PEAK_BITOP3_4WAVES = 5.61e13
 VALU_PEAK_BITOP3_8WAVES = 6.06e13
-KERNEL_SOURCES = ("scoary_lists.hip", "scoary_list_walk.inc", "scoary_assoc.hip", "scoary_common.hpp",
+KERNEL_SOURCES = ("scoary_lists.hip", "scoary_list_walk.inc", "scoary_assoc.hip", "scoary_labels.hip", "scoary_common.hpp",
                   "scoary_ctr_regs.inc", "scoary_vgpr_banks.inc")
 
 

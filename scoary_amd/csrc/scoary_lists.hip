@@ -245,6 +245,12 @@ struct Carry4 { uint32_t w[4]; };
 // wavefront, NW permutation words per lane (4; 2 / 1 for the 2- / 1-dword rows of
 // N > 10239 / 20479, one lane per gene).  Lists are walked in sub-steps of 4 entries: lane j of a gene
 // group holds entries 4j..4j+3 of each 4*LPG-entry piece.
+// Cache policy of the tile's LDS-DMA loads (A/B builds: -DSCOARY_TILE_LOAD_POLICY='" nt"').  A tile is
+// read once per block and never again by that CU; the index lists next to it in L2 are re-read by
+// every block of the chunk.
+#ifndef SCOARY_TILE_LOAD_POLICY
+#define SCOARY_TILE_LOAD_POLICY ""
+#endif
 template <int LPG, int NW, int KC>
 __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restrict__ tiles,
                                                         const uint32_t* __restrict__ lidx,
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
       if (i + lane < n4) {
         uint32_t m0_saved;     // M0 is handed back as it was: nothing else may be assumed about it
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     "global_load_lds_dwordx4 %2, %3" SCOARY_TILE_LOAD_POLICY "\n\ts_mov_b32 m0, %0"
                      : "=&s"(m0_saved)
                      : "s"(lds0 + (uint32_t)i * 16u), "v"(lane_off), "s"(src4 + i)
                      : "memory");
@@ -549,13 +555,18 @@ int scoary_list_params(int64_t N, int64_t* out5) {
 extern "C++" {
 // Bytes of index lists one k_permute_lists block walks against its LDS tile.  SCOARY_LIST_CHUNK_MB
 // (1..64) overrides it for same-box A/B runs (tools/ab_chunk.sh); read once per process.
-static int64_t list_chunk_bytes() {
-  static const int64_t bytes = [] {
+static int64_t list_chunk_bytes(int TW) {
+  static const long env_mb = [] {
     const char* e = std::getenv("SCOARY_LIST_CHUNK_MB");
     const long mb = e ? std::strtol(e, nullptr, 10) : 0;
-    return (int64_t)((mb >= 1 && mb <= 64) ? mb : kListChunkMB) << 20;
+    return (mb >= 1 && mb <= 64) ? mb : 0L;
   }();
-  return bytes;
+  // One lane per gene (TW <= 4, N > 5119): sixteen wave groups of 64 genes are ~10 MB of lists at
+  // N = 10 000 whatever is asked for here, more than an L2 holds -- the lists of such a launch
+  // stream from the Infinity Cache / HBM once per wave of concurrent blocks either way, and larger
+  // chunks re-load the 160 KB tile less often: 16 MB is -1.7 % of kernel time on a cfg5-shaped
+  // shard (profiles/r05_ab_cfg5_traffic.txt; round 3 measured -1.2 %).
+  return (int64_t)(env_mb ? env_mb : (TW <= 4 ? 16 : kListChunkMB)) << 20;
 }
 // Launch geometry of k_permute_lists (also sizes the scratch)
 struct ListGeom {
@@ -572,7 +583,7 @@ static ListGeom list_geom(int num_cu, int64_t G, int64_t T, int64_t N, int64_t P
   // (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the chunk run;
   // each chunk a multiple of 16 wave groups (one per wavefront)
   int64_t chunks = ((int64_t)num_cu * 16 + g.ntiles * T - 1) / (g.ntiles * T);
-  const int64_t chunk_bytes = list_chunk_bytes();
+  const int64_t chunk_bytes = list_chunk_bytes(TW);
   const int64_t by_l2 = (entries * 4 + chunk_bytes - 1) / chunk_bytes;
   if (chunks < by_l2) chunks = by_l2;
   if (chunks > 65535) chunks = 65535;
