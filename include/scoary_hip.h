@@ -84,7 +84,9 @@ int scoary_tile_rows(scoary_handle h, const uint64_t *d_rows64, int64_t G,
  * valid for that trait.  d_traits / d_masks are vecrows [T][Wp] (label bits,
  * validity bits; traits & ~masks must be 0).
  *   d_counts  : int32 [T][G][4]   (tpgp, tpgn, tngp, tngn)  -- bit-exact
- *   d_margins : int32 [T][2]      (npos, nval) per trait */
+ *   d_margins : int32 [T][2]      (npos, nval) per trait
+ * Not for a stream that is capturing a hipGraph (SCOARY_ERR_ARG: it allocates its plan in
+ * stream-ordered temporary memory): record scoary_counts_planned instead. */
 int scoary_counts(scoary_handle h, const uint32_t *d_tiled,
                   const uint32_t *d_traits, const uint32_t *d_masks, int64_t G,
                   int64_t T, int64_t N, int32_t *d_counts, int32_t *d_margins,
@@ -95,9 +97,11 @@ int scoary_counts(scoary_handle h, const uint32_t *d_tiled,
  * that streams the gene matrix once per pass of up to 32 traits.
  *   scoary_trait_plan : d_margins int32 [T][2] = (npos, nval) per trait (the isolate loop of
  *       scoary/methods.py:940-965 sees exactly the valid isolates: :591-598); d_mask_class
- *       int32 [T] (may be NULL) = the smallest t' <= t whose validity row equals trait t's --
- *       traits of one class share popc(gene & valid), counted once per class and pass (most
- *       traits of a real file have no missing values: a single class); d_plan = an opaque
+ *       int32 [T] (may be NULL) = the smallest t' <= t IN THE SAME PASS (traits
+ *       [k tb, (k + 1) tb), tb = scoary_counts_traits_per_pass(T)) whose validity row equals
+ *       trait t's -- traits of one class share popc(gene & valid), counted once per class and
+ *       pass (most traits of a real file have no missing values: one class per pass; ABI 8: the
+ *       search no longer leaves the pass, at most 31 row compares per trait); d_plan = an opaque
  *       buffer of scoary_trait_plan_bytes(T, N) bytes: the classes as dense slots per pass and
  *       the label / validity rows gathered quad-major, one contiguous operand row per gene
  *       quad and pass (what k_counts reads with wide scalar loads).

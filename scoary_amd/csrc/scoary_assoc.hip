@@ -102,9 +102,12 @@ __host__ __device__ inline PlanLayout plan_layout(int64_t T, int64_t Qp) {
   return L;
 }
 // One wavefront per trait; the class search compares rows front to back with an early exit
-// (different masks differ within the first words, identical ones are found at t' = cls).
+// (different masks differ within the first words, identical ones are found at t' = cls).  Classes
+// are shared WITHIN a pass of tb <= 32 traits only -- that is all k_counts can use -- so the search
+// looks at the traits of the own pass: at most 31 row compares per trait, whatever T is (it ran
+// over all earlier traits before round 5: O(T^2) row compares for T distinct masks, T <= 524 280).
 __global__ __launch_bounds__(64) void k_trait_plan(const uint32_t* __restrict__ traits,
-                                                   const uint32_t* __restrict__ masks, int Wp, int T,
+                                                   const uint32_t* __restrict__ masks, int Wp, int T, int tb,
                                                    int32_t* __restrict__ margins,
                                                    int32_t* __restrict__ cls,
                                                    int32_t* __restrict__ cls_user) {
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(64) void k_trait_plan(const uint32_t* __restrict__ 
     margins[2 * t + 1] = nval;
   }
   int found = t;
-  for (int u = 0; u < t; ++u) {
+  for (int u = t / tb * tb; u < t; ++u) {
     const uint32_t* urow = masks + (int64_t)u * Wp;
     bool same = true;
     for (int w0 = 0; w0 < Wp && same; w0 += 64) {
@@ -698,7 +701,7 @@ static int launch_trait_plan(scoary_handle h, hipStream_t s, const uint32_t* d_t
   const PlanLayout L = plan_layout(T, Qp);
   KernelTimer kt(h, s, "k_trait_plan");
   hipLaunchKernelGGL(k_trait_plan, dim3((unsigned)T), dim3(64), 0, s, d_traits, d_masks,
-                     (int)scoary_row_words(N), (int)T, d_margins, d_plan + L.cls, d_mask_class);
+                     (int)scoary_row_words(N), (int)T, (int)L.tb, d_margins, d_plan + L.cls, d_mask_class);
   hipLaunchKernelGGL(k_trait_slots, dim3((unsigned)L.passes), dim3(64), 0, s, d_plan, (int)T, (int)Qp);
   hipLaunchKernelGGL(k_trait_vecq, dim3((unsigned)Qp, (unsigned)L.passes), dim3(64), 0, s,
                      reinterpret_cast<const uint4*>(d_traits), reinterpret_cast<const uint4*>(d_masks),
@@ -777,7 +780,12 @@ int scoary_counts(scoary_handle h, const uint32_t* d_tiled, const uint32_t* d_tr
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the one-call form: a plan in stream-ordered temporary memory, then the tables.  Callers with more
-  // than one step per trait set build the plan once (scoary_trait_plan + scoary_counts_planned).
+  // than one step per trait set build the plan once (scoary_trait_plan + scoary_counts_planned) --
+  // and so must a caller that records a hipGraph: the temporary allocation does not belong in one.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    return fail(h, SCOARY_ERR_ARG, "scoary_counts: the stream is capturing a graph; use scoary_trait_plan "
+                                   "(outside the capture) + scoary_counts_planned");
   void* tmp = nullptr;
   HIP_TRY(h, hipMallocAsync(&tmp, (size_t)scoary_trait_plan_bytes(T, N), s));
   int rc = launch_trait_plan(h, s, d_traits, d_masks, T, N, d_margins, nullptr, static_cast<int32_t*>(tmp));

@@ -54,7 +54,7 @@ class GeneLists:
 
 class TraitPlan:
     """What the counts need that depends on the traits alone (scoary_trait_plan): margins
-    int32 [T, 2] = (positives, valid isolates), mask_class int32 [T] = first trait with the same
+    int32 [T, 2] = (positives, valid isolates), mask_class int32 [T] = first trait OF THE SAME PASS with the same
     validity row, buf = the opaque plan buffer (class slots per pass + the label / validity
     rows gathered quad-major).  Built once per trait set; valid for exactly the traits / masks
     tensors it was built from (a snapshot: later in-place changes of them are not seen)."""

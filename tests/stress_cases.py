@@ -172,8 +172,8 @@ def counts_case(eng, case, seed=91):
     npos, nval = pos.sum(1)[:, None], val.sum(1)[:, None]
     want = np.stack([a, npos - a, gmv - a, nval - npos - gmv + a], axis=2)
     valid = traits != 2
-    first = {}
-    want_cls = np.array([first.setdefault(valid[t].tobytes(), t) for t in range(T)])
+    first, tpp = {}, int(eng.lib.scoary_counts_traits_per_pass(T))   # classes: per pass of tpp traits
+    want_cls = np.array([first.setdefault((t // tpp, valid[t].tobytes()), t) for t in range(T)])
     m = plan.margins.cpu().numpy()
     ok = (np.array_equal(got, want) and np.array_equal(plan.mask_class.cpu().numpy(), want_cls)
           and np.array_equal(m[:, 0], npos[:, 0]) and np.array_equal(m[:, 1], nval[:, 0]))
