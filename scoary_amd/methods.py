@@ -767,12 +767,18 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
 
     rec = dist.associate_sharded(local, G)
     with _stage("results D2H"):
-        p_order = _p_order_on_device(rec)
+        # the stable p order for BH: numpy does 200 000 doubles in 25-40 ms, which beats the
+        # first-use cost of torch's sort kernels in a fresh process (0.2-0.4 s of lazy code loading,
+        # profiles/r05_e2e_cli_*); from a few million (gene, trait) pairs on the device sort wins
+        p_order = _p_order_on_device(rec) if T * G >= DEVICE_SORT_MIN_PAIRS else None
         out = dist.numpy_records(rec)
         out["p_order"] = p_order
     if permutations <= 0:
         out["r"] = None
     return out
+
+
+DEVICE_SORT_MIN_PAIRS = 4_000_000
 
 
 def _p_order_on_device(rec):

@@ -486,6 +486,26 @@ def test_cli_cfg2_sized_table_every_row_vs_oracle(tmp_path):
     assert top[0] == "g00011"                          # the planted gene wins its trait
 
 
+@pytest.mark.parametrize("collapse", [False, True])
+def test_p_order_from_the_device_equals_numpy(exampledir, monkeypatch, collapse):
+    """Large results take the stable p order of Benjamini-Hochberg (scoary/methods.py:903-925) from one
+    batched torch.argsort on the device records instead of numpy on the host: forced on for the
+    example data, every column and the writer's row order must be what the host path gives
+    (ties -- the example data has many equal p -- included)."""
+    from scoary_amd import methods as m
+    gd, td = _load(exampledir)
+    monkeypatch.setattr(m, "DEVICE_SORT_MIN_PAIRS", 1 << 60)
+    host = m.Setup_results(gd["Roarydic"], td, collapse)["Results"]
+    monkeypatch.setattr(m, "DEVICE_SORT_MIN_PAIRS", 0)
+    dev = m.Setup_results(gd["Roarydic"], td, collapse)["Results"]
+    for trait in host:
+        assert list(dev[trait]) == list(host[trait])
+        for k in ("p_v", "B_p", "BH_p", "tpgp", "sens"):
+            assert np.array_equal(dev[trait].column(k), host[trait].column(k)), (trait, k)
+        if not collapse:
+            assert np.array_equal(dev[trait].p_order, host[trait].p_order)
+
+
 def test_cli_vcf_pipeline_every_row_vs_oracle(tmp_path):
     """BASELINE configs[3] as it is literally defined -- "VCF-derived" -- at 20 000 sites x 1000
     isolates: a synthetic haploid VCF (rare variants, ~3 % multi-allelic sites, a few missing

@@ -1071,3 +1071,29 @@ def test_segmented_list_path_vs_dense_and_oracle(eng, orc, G, N, T, P):
     assert np.array_equal(res["r"].cpu().numpy(), dense["r"].cpu().numpy())
     assert np.array_equal(res["r"].cpu().numpy().view(np.uint32),
                           orc.permute_r(orc.pack_rows(genes), tb, mb, N, P, 9).T)
+
+
+# ------------------------------------------------ spec S4 at the widths where a block keeps fewer bits ------
+@pytest.mark.parametrize("N,T,P,base", [(39_684, 1, 40, 0), (39_685, 2, 33, 64), (77_041, 1, 70, 31),
+                                        (145_521, 1, 20, 5), (300_000, 2, 9, 0), (654_848, 1, 3, 1)])
+def test_perm_labels_bit_exact_beyond_one_dword_per_row(eng, orc, N, T, P, base):
+    """The label generator keeps a block's rows in LDS: all 32 permutations of a Philox block per row
+    up to N = 39 684, then 16, 8, 4, 2 and finally 1 of them (N <= 654 848 = scoary_perm_max_isolates;
+    the list-driven kernels stop at 131 070, the dense ones and the tree stage take the row form at
+    any width).  Every width class against the oracle, with a base that is no multiple of 32."""
+    rng = np.random.default_rng(N % 1000 + T)
+    traits = (rng.random((T, N)) < 0.3).astype(np.uint8)
+    traits[T - 1, rng.random(N) < 0.05] = 2
+    tb, mb = _bits(eng, traits)
+    masks = eng.vecrows(mb, N)
+    margins = __import__("torch").tensor([[int((traits[t] == 1).sum()), int((traits[t] != 2).sum())] for t in range(T)],
+                                         dtype=__import__("torch").int32, device="cuda")
+    perms = eng.perm_generate(masks, margins, N, P, base, 99).cpu().numpy().view(np.uint32)
+    W = (N + 63) // 64
+    for t in range(T):
+        npos = int((traits[t] == 1).sum())
+        for j in sorted({0, 1, P // 2, P - 1}):
+            want = orc.perm_labels(99, t, base + j, mb[t], npos, N)
+            got = np.ascontiguousarray(perms[t, j, :2 * W]).view(np.uint64)
+            assert np.array_equal(got, want), (t, j)
+            assert not perms[t, j, 2 * W:].any()
