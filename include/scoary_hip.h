@@ -381,6 +381,19 @@ int scoary_pack_records(scoary_handle h, const int32_t *d_counts, const double *
                         const double *d_odds, const uint32_t *d_r, const uint32_t *d_nstop,
                         int64_t M, uint32_t *d_rec, scoary_stream_t stream);
 
+/* ---- e: the exchange step itself, for hosts that do not go through torch.distributed ----------
+ * (replaces the pickled result weave of scoary/methods.py:1115-1122.)  Gather to `root`:
+ * every rank sends `bytes` bytes at d_send (its scoary_pack_records block); the root receives nranks
+ * blocks into d_recv, rank r's at offset r * bytes (d_recv may be NULL elsewhere).  One RCCL group of
+ * ncclSend / ncclRecv on `stream`, over xGMI inside a node; returns once the group is enqueued.
+ *   comm    : the caller's ncclComm_t (as void*: this header does not include rccl.h)
+ *   rccl_dl : dlopen handle of the RCCL instance `comm` was created with (a process can hold more
+ *             than one librccl -- PyTorch ships its own); NULL: the one the loader already has,
+ *             else "librccl.so.1".  libscoary_hip.so has no link-time dependency on RCCL.
+ * scoary_amd itself issues the same exchange through torch.distributed (scoary_amd/dist.py). */
+int scoary_gather(scoary_handle h, void *rccl_dl, void *comm, const void *d_send, void *d_recv,
+                  int64_t bytes, int rank, int nranks, int root, scoary_stream_t stream);
+
 /* ---- hipGraph capture ----------------------------------------------------------
  * Small workloads are launch-bound (BASELINE configs[1]: six kernels, 0.14 ms).
  * scoary_graph_begin puts `stream` into capture mode; every scoary_* call made on

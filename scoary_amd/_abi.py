@@ -66,6 +66,7 @@ SIGNATURES = {
                                    _vp]),
     "scoary_row_hash": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "scoary_pack_records": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "scoary_gather": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "scoary_graph_begin": (_i32, [_vp, _vp]),
     "scoary_graph_end": (_i32, [_vp, _vp, ctypes.POINTER(_vp)]),
     "scoary_graph_launch": (_i32, [_vp, _vp, _vp]),

@@ -1,4 +1,7 @@
-// scoary_context.hip -- handle lifetime, layout queries, kernel timing (include/scoary_hip.h).
+// scoary_context.hip -- handle lifetime, layout queries, kernel timing, the RCCL gather entry
+// (include/scoary_hip.h).
+#include <dlfcn.h>
+
 #include "scoary_common.hpp"
 
 extern "C" {
@@ -155,6 +158,50 @@ void scoary_graph_destroy(scoary_graph_t g) {
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   if (g->graph) (void)hipGraphDestroy(g->graph);
   delete g;
+}
+
+// ---- e: the path's one exchange step through RCCL, for a host without torch.distributed ----
+// No link-time dependency and no rccl.h in the public header: the four entry points are looked up
+// in the RCCL instance the CALLER names (the one its communicator came from -- a process can hold
+// more than one librccl, PyTorch ships its own), or in the first one the loader finds.
+int scoary_gather(scoary_handle h, void* rccl_dl, void* comm, const void* d_send, void* d_recv,
+                  int64_t bytes, int rank, int nranks, int root, scoary_stream_t stream) {
+  if (!h) return SCOARY_ERR_ARG;
+  if (!comm || !d_send || bytes < 1 || nranks < 1 || rank < 0 || rank >= nranks || root < 0 ||
+      root >= nranks || (rank == root && !d_recv))
+    return fail(h, SCOARY_ERR_ARG, "scoary_gather: bad argument");
+  void* dl = rccl_dl;
+  if (!dl) dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+  if (!dl) dl = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!dl) dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!dl) return fail(h, SCOARY_ERR_DEVICE, std::string("scoary_gather: no librccl: ") + (dlerror() ? dlerror() : ""));
+  using group_fn = int (*)();
+  using p2p_fn = int (*)(void*, size_t, int, int, void*, hipStream_t);
+  using err_fn = const char* (*)(int);
+  auto gstart = reinterpret_cast<group_fn>(dlsym(dl, "ncclGroupStart"));
+  auto gend = reinterpret_cast<group_fn>(dlsym(dl, "ncclGroupEnd"));
+  auto send = reinterpret_cast<p2p_fn>(dlsym(dl, "ncclSend"));
+  auto recv = reinterpret_cast<p2p_fn>(dlsym(dl, "ncclRecv"));
+  auto errs = reinterpret_cast<err_fn>(dlsym(dl, "ncclGetErrorString"));
+  if (!gstart || !gend || !send || !recv)
+    return fail(h, SCOARY_ERR_DEVICE, "scoary_gather: the RCCL library lacks ncclGroupStart / ncclSend / ncclRecv");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr int kNcclInt8 = 0;                       // ncclInt8 / ncclChar of rccl.h
+  auto check = [&](int rc, const char* what) -> int {
+    if (rc == 0) return SCOARY_OK;
+    return fail(h, SCOARY_ERR_HIP, std::string("scoary_gather: ") + what + ": " + (errs ? errs(rc) : "RCCL error"));
+  };
+  // one group: every rank's send to the root, and on the root one receive per rank (its own block included:
+  // a self send / receive pair inside a group is a device copy)
+  int rc = check(gstart(), "ncclGroupStart");
+  if (rc != SCOARY_OK) return rc;
+  rc = check(send(const_cast<void*>(d_send), (size_t)bytes, kNcclInt8, root, comm, s), "ncclSend");
+  if (rc == SCOARY_OK && rank == root)
+    for (int r = 0; r < nranks && rc == SCOARY_OK; ++r)
+      rc = check(recv(static_cast<char*>(d_recv) + (int64_t)r * bytes, (size_t)bytes, kNcclInt8, r, comm, s), "ncclRecv");
+  const int rc_end = check(gend(), "ncclGroupEnd");
+  return rc != SCOARY_OK ? rc : rc_end;
 }
 
 }  // extern "C"

@@ -1146,8 +1146,16 @@ def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Pruned
 
     n = len(Trait)
     num_results = n if max_hits is None else min(max_hits, n)
-    order = Trait.p_order if getattr(Trait, "p_order", None) is not None else \
-        np.argsort(np.asarray(Trait.column("p_v"), dtype=np.float64), kind="stable")
+    pcol = np.asarray(Trait.column("p_v"), dtype=np.float64)
+    order = getattr(Trait, "p_order", None)
+    if order is not None and len(order) == n and n > 1:
+        # the order Setup_results already had -- valid only while the p column is the one it was
+        # taken from (a caller may have replaced it): ascending, ties in row order, O(n) to check
+        sp = pcol[order]
+        if not np.all((sp[:-1] < sp[1:]) | ((sp[:-1] == sp[1:]) & (order[:-1] < order[1:]))):
+            order = None
+    if order is None or len(order) != n:
+        order = np.argsort(pcol, kind="stable")
     order = order[:num_results]
     fields = ["tpgp", "tngp", "tpgn", "tngn", "sens", "spes", "OR", "p_v", "B_p", "BH_p"]
     if no_pairwise:
