@@ -106,10 +106,11 @@ def parse(argv=None):
                          "all_gather_into_tensor supplies the rest (dist.LabelShards); default: every rank "
                          "generates all tiles (spec S4's generator costs less than the collective's latency "
                          "on the BASELINE shapes)")
-    ap.add_argument("--k1-cold", action="store_true",
-                    help="also time k_counts on a working set the 256 MiB Infinity Cache cannot hold "
-                         "(roofline_k1.cold): cfg5's 125 000 x 10 000 shard with T = 1 and 4, eight matrices "
-                         "in rotation")
+    ap.add_argument("--k1-cold", action="store_true", help=argparse.SUPPRESS)     # the default since round 5
+    ap.add_argument("--no-k1-cold", action="store_true",
+                    help="skip roofline_k1.cold: k_counts timed on a working set the 256 MiB Infinity Cache cannot "
+                         "hold (cfg5's 125 000 x 10 000 shard shape with T = 1 and 4, eight 160 MB matrices in "
+                         "rotation; single GPU only, ~1 s and 1.3 GB)")
     ap.add_argument("--sustain-seconds", type=float, default=6.0,
                     help="after the timed region (single GPU): run the step back to back this long and report "
                          "the clock / power the box sustains (the `sustained` object); 0 skips it")
@@ -966,7 +967,7 @@ def main():
         e1.synchronize()
         iso[name] = e0.elapsed_time(e1) / 5
     ws.label_shards = saved_shards
-    k1_cold = k1_cold_report(eng, args) if (args.k1_cold and world == 1) else None
+    k1_cold = k1_cold_report(eng, args) if (not args.no_k1_cold and not sharded) else None
 
     # The box under SUSTAINED load (single GPU, outside the timed region, GPU still warm): the same
     # step back to back for --sustain-seconds, clock and power from the second half of the window.

@@ -8,7 +8,7 @@ mkdir -p $O gpurun_out/profiles_r05
 PARTS="${*:-configs cfg5 extras soak}"
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 if has configs; then
-python bench.py --gpus 1 --steps 20 --warmup 5 --k1-cold > $O/bench_cfg3_driver_command_k1cold.json 2> $O/bench_cfg3_driver_command.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_cfg3_driver_command.json 2> $O/bench_cfg3_driver_command.err
 bash tools/profile_configs.sh r05 cfg3 cfg4 cfg2 > $O/profile_configs.log 2>&1
 python bench.py --config cfg2 --no-graph > $O/bench_cfg2_eager.json 2>/dev/null
 python bench.py --config cfg4 --genes 25000 --no-cpu-baseline > $O/bench_cfg4_rank_of_8.json 2>/dev/null
