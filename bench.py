@@ -1111,6 +1111,10 @@ def main():
                                                "already ran at the sustained clock")
         out["sustained"] = sustained
         out["kernel_ms_isolated"] = iso            # five back-to-back launches of the kernel alone
+        out["kernel_ms_note"] = ("kernel_ms: hipEvent durations inside the timed steps -- there the label generator "
+                                 "(k_perm_generate_tiles) runs on a side stream WHILE k_fisher runs on the main one, so "
+                                 "both durations are those of two kernels sharing the chip; kernel_ms_isolated: each of "
+                                 "them (and k_counts) launched alone, five times back to back")
         out.update(small_kernel_rooflines(
             args, G, N, T, sum(len(np.unique(cls[a:a + tpp])) for a in range(0, T, tpp)), iso))
         if "roofline_k1" in out:
