@@ -595,6 +595,9 @@ class AssociationEngine:
             # worth 0.2 % at cfg3 and nothing on the launch-bound shapes, while k_counts then
             # shares the chip with the generator and its own duration -- the path's one HBM
             # stream, reported as roofline_k1 -- can no longer be read off the step.)
+            # (Round 5, with the 0.04-0.08 ms generator: the overlap is still worth 0.3 % at cfg3 and
+            # 2.5 % on a 25 000-gene shard of cfg4, nothing on cfg4 itself; SCOARY_GEN_SIDE_STREAM=0
+            # runs the two back to back on the main stream for such A/B runs.)
             import os
             main = torch.cuda.current_stream(self.device)
             nb0 = min(ws.batch, permutations)
