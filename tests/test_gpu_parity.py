@@ -1097,3 +1097,44 @@ def test_perm_labels_bit_exact_beyond_one_dword_per_row(eng, orc, N, T, P, base)
             got = np.ascontiguousarray(perms[t, j, :2 * W]).view(np.uint64)
             assert np.array_equal(got, want), (t, j)
             assert not perms[t, j, 2 * W:].any()
+
+
+def test_perm_labels_every_margin_of_small_traits(eng, orc):
+    """Spec S4 at its corners: every (valid isolates, positives) pair of traits over N = 1 ... 9 and a
+    few over N = 33 / 70 -- no positives, all positive, one valid isolate, the complemented side,
+    round-0 probability zero -- rows and tiles against the oracle, all in one launch per N."""
+    import torch
+    for N in (1, 2, 3, 5, 9, 33, 70):
+        cases = []
+        for nval in sorted({1, 2, 3, N // 2, N - 1, N} - {0}):
+            if nval > N:
+                continue
+            for npos in sorted({0, 1, nval // 2, nval - 1, nval} - {-1}):
+                if 0 <= npos <= nval:
+                    cases.append((nval, npos))
+        cases = sorted(set(cases))
+        T, P = len(cases), 96
+        rng = np.random.default_rng(N)
+        traits = np.full((T, N), 2, dtype=np.uint8)
+        for t, (nval, npos) in enumerate(cases):
+            idx = rng.permutation(N)[:nval]
+            traits[t, idx] = 0
+            traits[t, idx[:npos]] = 1
+        tb, mb = _bits(eng, traits)
+        masks = eng.vecrows(mb, N)
+        margins = torch.tensor([[npos, nval] for nval, npos in cases], dtype=torch.int32, device="cuda")
+        rows = eng.perm_generate(masks, margins, N, P, 0, 2024).cpu().numpy().view(np.uint32)
+        tiles = eng.perm_generate_tiles(masks, margins, N, P, 0, 2024).cpu().numpy().view(np.uint32)
+        tw, stride, _g, _c, _p = eng.list_params(N)
+        tile_words = int(eng.lib.scoary_list_tile_words(N))
+        tiles = tiles.reshape(T, -1, tile_words)[:, :, :(N + 1) * tw].reshape(T, -1, N + 1, tw)
+        W = (N + 63) // 64
+        for t, (nval, npos) in enumerate(cases):
+            want = np.stack([orc.perm_labels(2024, t, pi, mb[t], npos, N) for pi in range(P)])
+            got = np.ascontiguousarray(rows[t, :, :2 * W]).view(np.uint64).reshape(P, W)
+            assert np.array_equal(got, want), (N, nval, npos)
+            wbits = np.unpackbits(want.view(np.uint8), axis=1, bitorder="little")[:, :N]        # (P, N)
+            tbits = np.unpackbits(np.ascontiguousarray(tiles[t, 0, :N]).view(np.uint8), axis=1,
+                                  bitorder="little")[:, :P]                                       # (N, P)
+            assert np.array_equal(tbits.T, wbits), (N, nval, npos)
+            assert np.all(wbits.sum(axis=1) == npos)
