@@ -462,8 +462,21 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
                 extra[header[c] + "_name"].append(v)
 
     if native:
-        for r, q in enumerate(meta_rows):
-            take(q, r, None)
+        if startcol > max(genecol, nugcol, anncol, *grabcols, 2):
+            # the native reader's rows all have startcol cells: the dict semantics of the reference
+            # (a repeated identifier keeps its first position and takes the last row's content)
+            # are those of dict(zip(...)) -- no per-row Python function
+            idents = [q[genecol] for q in meta_rows] if roary else \
+                ["_|_".join((q[genecol], q[nugcol], q[anncol])) for q in meta_rows]
+            last = dict(zip(idents, range(len(idents))))
+            ids, source = list(last.keys()), list(last.values())
+            nugn = [meta_rows[r][nugcol] for r in source]
+            ann = [meta_rows[r][anncol] for r in source]
+            for c in grabcols:
+                extra[header[c] + "_name"] = [meta_rows[r][c] for r in source]
+        else:
+            for r, q in enumerate(meta_rows):
+                take(q, r, None)
         rows64 = bits[np.array(source, dtype=np.int64)] if ids else bits[:0]
         table = GeneTable(ids, nugn, ann, kept_strains, rows64, extra)
         file_rows64 = np.ascontiguousarray(bits, dtype=np.uint64)     # EVERY file row, see below
