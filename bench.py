@@ -14,12 +14,17 @@ HBM.  tests per step = G*T*P.
 launcher (WORLD_SIZE set), and refuses to run with fewer than N visible GPUs.
 
 Multi-GPU: genes shard across ranks -- weak scaling: every rank holds its own G-gene
-shard (a G*N-gene matrix); strong scaling: the config's G genes are split into
-contiguous shards (scoary_amd.dist.shard_bounds).  Trait / permutation vectors are
-regenerated identically on every rank from the seed (no broadcast); the one exchange
-step of the path -- gathering per-gene results on rank 0 -- is an RCCL gather inside the
-timed region (asynchronous, overlapped with the next step's kernels), and rank 0
-checks the records it received from every rank.
+shard (a G*N-gene matrix); strong scaling: the config's G genes are split into the
+reference's stride domains, rank r = genes r, r + N, r + 2N, ... (scoary_amd.dist.GenePartition;
+scoary/methods.py:1076-1078).  Trait / permutation vectors are regenerated identically on every
+rank from the seed (no broadcast); the one exchange step of the path -- gathering per-gene
+results on rank 0 -- is an RCCL gather inside the timed region (asynchronous, overlapped with
+the next step's kernels), and rank 0 checks the records it received from every rank.
+
+The default line is the WEAK one (`value`, `scaling`); next to it `scaling_strong` carries, timed
+in the same process group, the strong split of the headline config (cfg3's 50 000 genes over the
+N ranks) and of cfg4 (200 000 variants over the N ranks), so the 1/2/4/8 runs give the strong
+curve SURVEY 8e asks for as well (at N = 1 they are the denominators).
 
 Prints ONE JSON line (rank 0).
 """
@@ -65,6 +70,16 @@ def parse(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own G-gene shard; strong: the config's G genes "
                          "split across the ranks")
+    ap.add_argument("--partition", default="stride", choices=["stride", "contiguous"],
+                    help="strong scaling: which genes a rank owns -- stride (rank r: genes r, r + N, ...: the "
+                         "reference's domains, balanced for any gene order) or contiguous equal-count blocks "
+                         "(rounds 1-5; unbalanced on frequency-sorted tables, kept as the A/B)")
+    ap.add_argument("--gene-order", default="config", choices=["config", "sorted"],
+                    help="sorted: the matrix rows in descending gene frequency, the order Roary writes its "
+                         "table in (scoary/exampledata/Gene_presence_absence.csv: 100, ..., 0 isolates)")
+    ap.add_argument("--strong-extra", default="auto", choices=["auto", "on", "off"],
+                    help="also time the strong split of cfg3 and cfg4 over the ranks of this run "
+                         "(`scaling_strong`); auto: on for the default cfg3 weak line")
     ap.add_argument("--genes", type=int, default=None, help="override G (per GPU / total)")
     ap.add_argument("--permutations", type=int, default=None, help="override P")
     ap.add_argument("--isolates", type=int, default=None, help="override N (shape experiments)")
@@ -441,19 +456,19 @@ class Exchange:
     gathered on rank 0 over RCCL/xGMI (north_star: "only an RCCL gather of
     per-gene results").  It is issued asynchronously and drained before its
     buffers are reused, so step i's gather overlaps step i+1's kernels; every
-    gather has completed before the closing barrier of the timed region."""
+    gather has completed before the closing barrier of the timed region.
+    ``partition``: scoary_amd.dist.GenePartition of ALL the genes of the run (weak
+    scaling: world contiguous blocks of G; strong: the config's genes, stride)."""
 
-    def __init__(self, torch, eng, world, rank, T, G, bounds=None):
+    def __init__(self, torch, eng, world, rank, T, partition):
         from scoary_amd import dist as sdist
-        self.sdist, self.world, self.rank, self.G = sdist, world, rank, G
+        self.sdist, self.world, self.rank, self.part = sdist, world, rank, partition
         self.eng = eng if hasattr(eng, "lib") else None
-        # weak scaling: every rank sends G genes (G*world in all); strong: shard_bounds(G)
-        self.total = G * world if bounds is None else bounds[-1][1]
+        self.total = partition.G
         self.pending, self.step_no, self.kind = [], 0, "gather"
         self.recv = [None, None]
         if rank == 0:
-            cap = sdist.max_shard(self.total, world)
-            self.recv = [torch.empty((world, T, cap, sdist.REC_WORDS), dtype=torch.int32,
+            self.recv = [torch.empty((world, T, partition.cap, sdist.REC_WORDS), dtype=torch.int32,
                                      device=eng.device) for _ in range(2)]
 
     def drain(self, keep=0):
@@ -463,14 +478,16 @@ class Exchange:
     def submit(self, res):
         sdist = self.sdist
         self.drain(keep=1)
-        if self.eng is not None and hasattr(self.eng, "pack_records"):
+        if res.get("records") is not None:                # packed inside the (replayed) step
+            rec = res["records"]
+        elif self.eng is not None and hasattr(self.eng, "pack_records"):
             rec = self.eng.pack_records(res)              # one kernel (scoary_pack_records)
         else:                                             # CPU tensors (gloo tests)
             rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
         if self.kind == "gather":
             try:
                 _, finish = sdist.gather_genes(rec, self.total, dst=0, async_op=True,
-                                               recv=self.recv[self.step_no % 2])
+                                               recv=self.recv[self.step_no % 2], partition=self.part)
                 self.pending.append(finish)
             except (RuntimeError, NotImplementedError) as e:   # backend without gather
                 if self.rank == 0:
@@ -478,8 +495,12 @@ class Exchange:
                           file=sys.stderr)
                 self.kind = "all_gather"
         if self.kind == "all_gather":
-            res["gathered"] = sdist.all_gather_genes(rec, self.total)
+            res["gathered"] = sdist.all_gather_genes(rec, self.total, partition=self.part)
         self.step_no += 1
+
+    def last_block(self):
+        """rank 0: the receive buffer of the last step, [world, T, cap, words]."""
+        return self.recv[(self.step_no - 1) % 2]
 
     def check(self, T, nval):
         """Rank 0, after the last drain: the receive buffer of the last step holds one
@@ -489,16 +510,22 @@ class Exchange:
         ranks whose block passed."""
         if self.rank != 0 or self.kind != "gather":
             return None
-        sdist = self.sdist
-        last = self.recv[(self.step_no - 1) % 2]
-        bounds = sdist.shard_bounds(self.total, self.world)
+        last = self.last_block()
         ok = 0
-        for rk, (a, b) in enumerate(bounds):
-            counts = last[rk, :, :b - a, 0:4].sum(dim=2).cpu().numpy()     # [T, shard]
-            if counts.shape == (T, b - a) and np.array_equal(
+        for rk, n in enumerate(self.part.lengths()):
+            counts = last[rk, :, :n, 0:4].sum(dim=2).cpu().numpy()     # [T, shard]
+            if counts.shape == (T, n) and np.array_equal(
                     counts, np.broadcast_to(np.asarray(nval)[:, None], counts.shape)):
                 ok += 1
         return ok
+
+
+def order_genes(genes, how):
+    """--gene-order sorted: rows in descending gene frequency (stable), Roary's table order."""
+    if how != "sorted":
+        return genes
+    ones = genes.sum(axis=1, dtype=np.int64)
+    return np.ascontiguousarray(genes[np.argsort(-ones, kind="stable")])
 
 
 def measured_copy_peak(device):
@@ -741,6 +768,128 @@ def k1_cold_report(eng, args, G=125_000, N=10_000, copies=8, rounds=3):
     return out
 
 
+def make_step(torch, eng, gm, trv, mkv, P, seed, ws, use_lists, plan, exchange, use_graph):
+    """-> (step(i), graphs): one pass of the hot path on this rank's genes + (sharded) the submit of
+    its records to the exchange.  With ``use_graph`` the local step is a hipGraph replay; a sharded
+    rank records TWO graphs that pack their records into alternating buffers, because step i's
+    gather is still reading its buffer while step i + 1 runs."""
+    graphs = []
+    if use_graph:
+        # recorded here, outside the warm-up count: what engine.associate does by itself on the
+        # second call of a launch-bound step
+        if exchange is not None:
+            from scoary_amd import dist as sdist
+            for _ in range(2):
+                rec = torch.empty((trv.shape[0], gm.G, sdist.REC_WORDS), dtype=torch.int32, device=eng.device)
+                graphs.append(eng.capture(gm, trv, mkv, P, seed, ws, use_lists=use_lists, plan=plan, records=rec))
+        else:
+            graphs.append(eng.capture(gm, trv, mkv, P, seed, ws, use_lists=use_lists, plan=plan))
+
+    def step(i):
+        if exchange is not None:
+            # before anything of this step is launched: all gathers but the newest are complete, so
+            # the record buffer this step packs into (graph i % 2) is no longer being read
+            exchange.drain(keep=1)
+        if graphs:
+            g, res = graphs[i % len(graphs)]
+            g.launch()
+        else:
+            res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=use_lists,
+                                workspace=ws, plan=plan, graph=False)
+        if exchange is not None:
+            exchange.submit(res)
+        return res
+    return step, graphs
+
+
+def strong_split_case(torch, dist, eng, args, cfg, world, rank, local_rank, sharded):
+    """One point of the strong-scaling curve: config `cfg` at its full size, its genes split over the
+    ranks of this run (GenePartition, --partition), timed like the line itself -- warm-up, barrier,
+    `--steps` steps with the asynchronous gather on rank 0, barrier, MAX over ranks.  A launch-bound
+    shard replays its local step from a hipGraph.  Returns the entry of `scaling_strong` (rank 0)."""
+    from scoary_amd import synth
+    from scoary_amd import dist as sdist
+    from scoary_amd.engine import pack_bits_rows
+    base, traits, P, seed = synth.make_config(cfg)
+    base = order_genes(base, args.gene_order)
+    part = sdist.GenePartition(base.shape[0], world, args.partition)
+    genes = np.ascontiguousarray(base[part.index(rank)])
+    del base
+    G, N = genes.shape
+    T = traits.shape[0]
+    ones = genes.sum(axis=1, dtype=np.int64)
+    list_entries = int(np.minimum(ones, N - ones).sum())
+    gm = eng.tile_rows(pack_bits_rows(genes), N)
+    del genes
+    trv = eng.vecrows(pack_bits_rows((traits == 1).astype(np.uint8)), N)
+    mkv = eng.vecrows(pack_bits_rows((traits != 2).astype(np.uint8)), N)
+    plan = eng.trait_plan(trv, mkv, N)
+    use_lists = args.kernel != "dense" and LISTS_DEFAULT and eng.lists_supported(N)
+    if use_lists:
+        eng.build_lists(gm)
+    ws = eng.workspace(gm, T, P, use_lists=use_lists)
+    exchange = Exchange(torch, eng, world, rank, T, part) if sharded else None
+    use_graph = (not args.no_graph and not (sharded and args.label_shards)
+                 and eng.auto_graph_eligible(gm, T, P))
+    step, graphs = make_step(torch, eng, gm, trv, mkv, P, seed, ws, use_lists, plan, exchange, use_graph)
+
+    def barrier():
+        if exchange:
+            exchange.drain()
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    last = torch.cuda.Event()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    exposed_ms = None
+    if exchange:
+        last.record()
+        last.synchronize()
+        t_kernels = time.perf_counter()
+    barrier()
+    dt_own = dt = time.perf_counter() - t0
+    if exchange:
+        exposed_ms = (time.perf_counter() - t_kernels) * 1e3
+    # per-kernel durations: a few eager steps with the library's event timers on
+    eng.set_timing(True)
+    for _ in range(3):
+        eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=use_lists, workspace=ws, plan=plan,
+                      graph=False)
+    torch.cuda.synchronize()
+    k3_name = eng.list_kernel_name(N) if use_lists else "k_permute"
+    names = ("k_counts", "k_fisher") + (("k_perm_generate_tiles", k3_name, "k_lists_reduce") if use_lists
+                                        else ("k_perm_generate", "k_permute"))
+    kernel_ms = {k: eng.kernel_ms(k) for k in names}
+    eng.set_timing(False)
+    per_rank = rccl_ranks = None
+    if sharded:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        per_rank = sdist.all_gather_objects({
+            "rank": rank, "genes": G, "list_entries": list_entries, "ms_per_step": dt_own / args.steps * 1e3,
+            "kernel_ms": kernel_ms, "exchange_exposed_ms": exposed_ms,
+            "exchange_bytes": T * G * sdist.REC_WORDS * 4})
+        rccl_ranks = exchange.check(T, (traits != 2).sum(1))
+        if rank == 0 and exchange.kind == "gather" and rccl_ranks != world:
+            raise SystemExit("bench.py: scaling_strong %s: valid records from %s of %d ranks"
+                             % (cfg, rccl_ranks, world))
+    for g_ in graphs:
+        g_[0].close()
+    tests = float(part.G) * T * P
+    return {"workload": "%s: %d genes x %d isolates x %d traits, --permute %d in all, split over %d GPU(s)"
+                        % (cfg, part.G, N, T, P, world),
+            "n_gpus": world, "value": tests * args.steps / dt, "unit": "tests/s",
+            "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+            "genes_per_gpu": part.lengths(), "gene_partition": part.kind, "gene_order": args.gene_order,
+            "hip_graph": bool(graphs), "kernel_ms": kernel_ms, "exchange_exposed_ms": exposed_ms,
+            "rccl_ranks": rccl_ranks, "per_rank": per_rank}
+
+
 def dry_exchange(args, world, rank):
     """CPU-only: the launcher, process group, Exchange pipeline and rank-0 check with
     fabricated records (gloo)."""
@@ -750,9 +899,10 @@ def dry_exchange(args, world, rank):
     from scoary_amd import dist as sdist
     sdist.init_from_env()
     T, G, nval = 2, 7, [11, 13]
-    bounds = sdist.shard_bounds(G, world) if args.scaling == "strong" else None
-    Gs = G if bounds is None else bounds[rank][1] - bounds[rank][0]
-    ex = Exchange(torch, types.SimpleNamespace(device="cpu"), world, rank, T, G, bounds=bounds)
+    part = sdist.GenePartition(G, world, args.partition) if args.scaling == "strong" \
+        else sdist.GenePartition(G * world, world, "contiguous")
+    Gs = part.length(rank)
+    ex = Exchange(torch, types.SimpleNamespace(device="cpu"), world, rank, T, part)
     for step in range(args.steps):
         counts = torch.zeros((T, Gs, 4), dtype=torch.int32)
         for t in range(T):
@@ -810,29 +960,34 @@ def main():
 
     c = synth.CONFIGS[args.config]
     G_cfg = args.genes or (c["G"] // 8 if args.config == "cfg5" else c["G"])   # cfg5: the per-GPU shard
-    bounds = sdist.shard_bounds(G_cfg, world) if (args.scaling == "strong" and world > 1) else None
+    strong = args.scaling == "strong" and world > 1
     base_genes, traits, P, seed = synth.make_config(args.config, G=G_cfg, N=args.isolates, T=args.traits,
                                                     gene_kind=args.gene_kind)
+    base_genes = order_genes(base_genes, args.gene_order)
+    # the genes of the whole run: strong -- the config's, in the reference's stride domains (or
+    # --partition contiguous); weak -- world blocks of G_cfg, one per rank
+    part = sdist.GenePartition(G_cfg, world, args.partition) if strong \
+        else sdist.GenePartition(G_cfg * world, world, "contiguous")
 
     def shard_of(rk):
         """The gene rows rank rk works on.  strong: the config's genes, split -- every rank
         generates the same matrix and keeps its rows; weak: every rank its own G-gene shard
         (different seed offset), same traits."""
-        if bounds is not None:
-            a, b = bounds[rk]
-            return np.ascontiguousarray(base_genes[a:b])
+        if strong:
+            return np.ascontiguousarray(base_genes[part.index(rk)])
         if rk == 0:
             return base_genes
         rng = np.random.default_rng(seed + 1000 * rk)
-        return synth.make_genes(base_genes.shape[0], base_genes.shape[1], rng,
-                                kind=args.gene_kind or ("rare" if args.config == "cfg4" else "uniform"),
-                                core_frac=0.05 if args.config in ("cfg3", "cfg5") else 0.0)
+        return order_genes(synth.make_genes(
+            base_genes.shape[0], base_genes.shape[1], rng,
+            kind=args.gene_kind or ("rare" if args.config == "cfg4" else "uniform"),
+            core_frac=0.05 if args.config in ("cfg3", "cfg5") else 0.0), args.gene_order)
     genes = shard_of(rank)
     if args.permutations:
         P = args.permutations
     G, N = genes.shape
     T = traits.shape[0]
-    G_total = G_cfg if bounds is not None else G * world
+    G_total = part.G
 
     eng = AssociationEngine(local_rank)
     if sharded and args.label_shards:
@@ -859,25 +1014,21 @@ def main():
 
     pbatch = eng.perm_batch(T, N, P)
     ws = eng.workspace(gm, T, P, use_lists=use_lists)
-    exchange = Exchange(torch, eng, world, rank, T, G, bounds=bounds) if sharded else None
-    graph = graph_res = None
-    auto_graph = (not args.graph and not args.no_graph and not sharded
+    exchange = Exchange(torch, eng, world, rank, T, part) if sharded else None
+    # a launch-bound step is replayed from a hipGraph -- also on a gene-sharded rank (round 6: a rank of
+    # cfg4's 8-way split has 0.1 ms of launch-bound kernels in 0.35 ms): the LOCAL step is recorded,
+    # record packing included; the exchange (a collective) stays outside the graph.  Label shards put
+    # a collective INSIDE the step: those run eagerly.
+    auto_graph = (not args.graph and not args.no_graph and not (sharded and args.label_shards)
                   and eng.auto_graph_eligible(gm, T, P))
-    if args.graph or auto_graph:
-        # recorded here, outside the warm-up count: what engine.associate does by itself on the
-        # second call of a launch-bound step
-        graph, graph_res = eng.capture(gm, trv, mkv, P, seed, ws, use_lists=use_lists, plan=plan)
+    step_fn, graphs = make_step(torch, eng, gm, trv, mkv, P, seed, ws, use_lists, plan, exchange,
+                                use_graph=args.graph or auto_graph)
+    graph = graphs[0][0] if graphs else None
+    step_no = [0]
 
     def step():
-        if graph is not None:
-            graph.launch()
-            res = graph_res
-        else:
-            res = eng.associate(gm, trv, mkv, permutations=P, seed=seed, use_lists=use_lists,
-                                workspace=ws, plan=plan, graph=False)
-        if exchange:
-            exchange.submit(res)
-        return res
+        step_no[0] += 1
+        return step_fn(step_no[0])
 
     def barrier():
         if exchange:
@@ -1004,8 +1155,11 @@ def main():
         # one line per rank, so that a sub-linear point of the scaling curve explains itself:
         # its own wall clock, its kernels, the bytes it sends per step and how long the
         # exchange kept it waiting after its last kernel
+        ones = genes.sum(axis=1, dtype=np.int64)
         mine = {"rank": rank, "device": local_rank, "genes": G, "ms_per_step": dt_own / args.steps * 1e3,
                 "ms_per_step_median": median_ms, "kernel_ms": kernel_ms,
+                # what the list kernel's cost follows: the minority entries of this rank's genes
+                "list_entries": int(np.minimum(ones, N - ones).sum()),
                 "exchange_exposed_ms": exposed_ms,
                 "exchange_bytes": T * G * sdist.REC_WORDS * 4,
                 "label_tile_bytes_gathered": None if eng.label_shards is None
@@ -1022,18 +1176,28 @@ def main():
     if args.verify_gather and exchange and rank == 0 and exchange.kind == "gather" and failure is None:
         # rank 0 alone recomputes every rank's shard and compares the block it received from
         # that rank in the last step, record for record (counts, p, odds, r: 40 bytes each)
-        last = exchange.recv[(exchange.step_no - 1) % 2]
+        last = exchange.last_block()
         if args.inject_gather_fault:
             last[world - 1, 0, 0, 8] += 1                    # r of the last rank's first record
         gather_ok = True
-        eng.label_shards = None                      # rank 0 alone: every label tile generated here
-        for rk, (a, b) in enumerate(sdist.shard_bounds(exchange.total, world)):
+        saved_label_shards, eng.label_shards = eng.label_shards, None   # rank 0 alone: every tile generated here
+        for rk, n in enumerate(part.lengths()):
             g_rk = eng.tile_rows(pack_bits_rows(shard_of(rk)), N)
             if use_lists:
                 eng.build_lists(g_rk)
             alone = eng.pack_records(eng.associate(g_rk, trv, mkv, permutations=P, seed=seed,
                                                    use_lists=use_lists, plan=plan))
-            gather_ok = gather_ok and bool(torch.equal(last[rk, :, :b - a], alone))
+            gather_ok = gather_ok and bool(torch.equal(last[rk, :, :n], alone))
+        if gather_ok and strong:
+            # ... and woven back into gene order (GenePartition.weave) they are the records of ONE
+            # GPU working on the whole matrix
+            g_all = eng.tile_rows(pack_bits_rows(base_genes), N)
+            if use_lists:
+                eng.build_lists(g_all)
+            whole = eng.pack_records(eng.associate(g_all, trv, mkv, permutations=P, seed=seed,
+                                                   use_lists=use_lists, plan=plan))
+            gather_ok = bool(torch.equal(part.weave(last), whole))
+        eng.label_shards = saved_label_shards
         if not gather_ok:
             failure = "bench.py: the gathered records differ from a single-rank run"
     if sharded:
@@ -1047,6 +1211,24 @@ def main():
             raise SystemExit(verdict[0] if rank == 0 else 1)
     elif failure is not None:
         raise SystemExit(failure)
+
+    # ---- the strong curve next to the weak line (same process group, after the line's own timing) ----
+    default_line = (args.config == "cfg3" and args.genes is None and args.permutations is None
+                    and args.isolates is None and args.traits is None and args.gene_kind is None
+                    and args.scaling == "weak")
+    scaling_strong = None
+    if args.strong_extra == "on" or (args.strong_extra == "auto" and default_line):
+        scaling_strong = {"what": "the config's genes split over the n_gpus ranks of this run (stride domains, "
+                                  "scoary_amd.dist.GenePartition), exchange included; value = the config's "
+                                  "G x T x P tests / the slowest rank's time; speed-up over one GPU = value / the "
+                                  "same entry of the n_gpus = 1 line"}
+        for cfg_ in ("cfg3", "cfg4"):
+            if world == 1 and cfg_ == args.config and default_line and not sharded:
+                scaling_strong[cfg_] = {"same_as": "the line's own value (one GPU holds all genes)",
+                                        "value": G_total * T * P * args.steps / dt,
+                                        "ms_per_step": dt / args.steps * 1e3, "n_gpus": 1}
+                continue
+            scaling_strong[cfg_] = strong_split_case(torch, dist, eng, args, cfg_, world, rank, local_rank, sharded)
 
     if rank == 0:
         tests_per_step = G_total * T * P
@@ -1067,9 +1249,11 @@ def main():
             "config": {"workload": "%s%s: %d genes x %d isolates x %d traits, --permute %d %s; "
                                    "counts + Fisher + label permutations + exceedance counts"
                                    % (args.config, "" if not args.gene_kind else " shape, %s gene frequencies"
-                                      % args.gene_kind, G_total if bounds is not None else G, N, T, P,
-                                      "in all (split across the GPUs)" if bounds is not None else "per GPU"),
-                       "gene_kind": args.gene_kind or "config",
+                                      % args.gene_kind, G_total if strong else G, N, T, P,
+                                      "in all (split across the GPUs)" if strong else "per GPU"),
+                       "gene_kind": args.gene_kind or "config", "gene_order": args.gene_order,
+                       "gene_partition": ("%s (scoary_amd.dist.GenePartition)" % part.kind) if strong
+                       else "every rank its own genes (weak scaling)",
                        "genes_per_gpu": G, "genes_total": G_total, "isolates": N, "traits": T,
                        "permutations": P, "parallelism": "gene-shard x%d" % world,
                        "hip_graph": bool(graph), "hip_graph_auto": bool(auto_graph),
@@ -1082,6 +1266,7 @@ def main():
             "rccl_ranks": rccl_ranks,
             "gather_matches_single_rank": gather_ok,
             "per_rank": per_rank,
+            "scaling_strong": scaling_strong,
             # once per data set, outside the timed region: H2D of the packed bits + device tiling +
             # device list build + trait vectors and their plan (margins, mask classes); host
             # bit-packing and parsing excluded

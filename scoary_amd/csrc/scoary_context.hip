@@ -174,7 +174,10 @@ int scoary_gather(scoary_handle h, void* rccl_dl, void* comm, const void* d_send
   if (!dl) dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
   if (!dl) dl = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
   if (!dl) dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!dl) return fail(h, SCOARY_ERR_DEVICE, std::string("scoary_gather: no librccl: ") + (dlerror() ? dlerror() : ""));
+  if (!dl) {
+    const char* why = dlerror();                     // one call: it clears the message it returns
+    return fail(h, SCOARY_ERR_DEVICE, std::string("scoary_gather: no librccl: ") + (why ? why : ""));
+  }
   using group_fn = int (*)();
   using p2p_fn = int (*)(void*, size_t, int, int, void*, hipStream_t);
   using err_fn = const char* (*)(int);

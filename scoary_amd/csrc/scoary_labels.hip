@@ -35,6 +35,7 @@ constexpr uint32_t kDomFix = 0x53434F44u;      // "SCOD": fix-up position draws
 constexpr uint32_t kFixMaxCalls = 1u << 20;    // safety stop of the fix-up loop (the CPU checker has the same bound)
 constexpr int kCntPlanes = 10;                 // per-lane bit-sliced mark count: <= 1023 rows per thread
 constexpr int kSumPlanes = 16;                 // per-wavefront sum: <= 64 * 1023
+constexpr int kMaxRowsPerThread = (1 << kCntPlanes) - 1;
 constexpr int kLabelsMaxLds = 160 * 1024;
 
 struct LabelPlan {
@@ -453,11 +454,19 @@ int ilog2(int v) {
 int labels_threads(int64_t blocks, int64_t N, int num_cu) {
   int tpb = 256;
   while (tpb < 1024 && blocks * (tpb / 64) < (int64_t)num_cu * 8 && N / tpb >= 4) tpb *= 2;
+  // a lane counts its round-0 marks in kCntPlanes bit-sliced planes: at most 1023 rows per thread
+  // (N > 261 888 needs 512 threads, N > 523 776 needs 1024; scoary_perm_max_isolates() = 654 848)
+  while (tpb < 1024 && (N + tpb - 1) / tpb > kMaxRowsPerThread) tpb *= 2;
   return tpb;
 }
 template <int NB, int OUT>
 int launch_labels(scoary_handle h, hipStream_t s, const LabelArgs& a, dim3 grid, int tpb, int elt) {
   const size_t lds = (size_t)labels_lds_bytes(a.N, elt, NB);
+  // the per-lane mark counters would wrap (labels_threads never picks such a geometry; an
+  // SCOARY_LABELS_TPB override can)
+  if (tpb < 64 || tpb > 1024 || (tpb & (tpb - 1)) || (a.N + tpb - 1) / tpb > kMaxRowsPerThread)
+    return fail(h, SCOARY_ERR_SIZE, "k_labels: more than 1023 isolates per thread (or a block size that is no "
+                                    "power of two in 64..1024)");
   const void* fn = reinterpret_cast<const void*>(&k_labels<NB, OUT>);
   const int bit = 1 << (NB + 8 * OUT);             // 2, 4, 16 | 512
   if (lds > 64 * 1024 && !(h->labels_lds_optin & bit)) {

@@ -81,6 +81,7 @@ class Workspace:
         if use_lists is None:
             use_lists = genes.lists is not None and eng.lists_supported(N)
         self.key = (G, N, int(T), int(permutations), bool(use_lists and permutations > 0))
+        self.eng = eng
         self.counts = eng._empty((T, G, 4), torch.int32)
         self.margins = eng._empty((T, 2), torch.int32)
         self.mask_class = eng._empty((T,), torch.int32)
@@ -111,6 +112,11 @@ class Workspace:
                                         torch.int32)
 
     def fits(self, genes, T, permutations, use_lists):
+        # the label shards are part of the shape: a workspace made before eng.label_shards was set
+        # (or kept after it was reset) has the wrong tile padding, and ranks that disagree about
+        # the shards would block in the all-gather of _label_tiles
+        if self.tiles is not None and self.label_shards is not self.eng.label_shards:
+            return False
         return self.key == (genes.G, genes.N, int(T), int(permutations),
                             bool(use_lists and permutations > 0))
 
@@ -558,7 +564,7 @@ class AssociationEngine:
         sh.all_gather(ws.tiles, nflat, tile_words)
 
     def associate(self, genes, traits, masks, permutations=0, seed=0, perm_buffer=None,
-                  use_lists=None, workspace=None, plan=None, graph=None):
+                  use_lists=None, workspace=None, plan=None, graph=None, records=None):
         """counts -> Fisher -> (optional) permutation exceedance counts.
         Returns dict of device tensors: counts [T,G,4], margins [T,2],
         p / odds [T,G], r [T,G] (uint32 bit pattern in int32) or None.  With
@@ -566,7 +572,21 @@ class AssociationEngine:
         next step that uses it).  ``plan``: the TraitPlan of these traits (trait_plan, once
         per trait set); without one every step rebuilds it (one more small launch).  With a
         workspace AND a plan, a launch-bound step (auto_graph_eligible) is recorded into a
-        hipGraph on its second call and replayed afterwards; ``graph=False`` keeps it eager."""
+        hipGraph on its second call and replayed afterwards; ``graph=False`` keeps it eager.
+        ``records``: an int32 [T, G, 10] device tensor -- the result is also packed into it
+        (pack_records) and returned as res["records"]."""
+        res = self._associate(genes, traits, masks, permutations, seed, perm_buffer, use_lists,
+                              workspace, plan, graph if records is None else False)
+        if records is not None:
+            # the exchange records of the step, packed as its last kernel (inside a captured step:
+            # one launch less per replay for a gene-sharded rank)
+            res = dict(res)
+            res["records"] = self.pack_records(res, out=records)
+        return res
+
+    def _associate(self, genes, traits, masks, permutations, seed, perm_buffer, use_lists, workspace,
+                   plan, graph):
+        """The step behind associate() (its docstring)."""
         torch = _torch()
         T = traits.shape[0]
         if use_lists is None:
@@ -637,7 +657,8 @@ class AssociationEngine:
                 done += nb
         return {"counts": counts, "margins": margins, "p": p, "odds": odds, "crit": crit, "r": r}
 
-    def capture(self, genes, traits, masks, permutations, seed, workspace, use_lists=None, plan=None):
+    def capture(self, genes, traits, masks, permutations, seed, workspace, use_lists=None, plan=None,
+                records=None):
         """Record one associate() step into a hipGraph (scoary_graph_*): returns
         (StepGraph, result dict).  The results live in ``workspace``; ``launch()``
         recomputes them with a single graph launch.  The step is run once eagerly
@@ -648,8 +669,11 @@ class AssociationEngine:
         # synchronize, which is illegal on a capturing stream
         if torch.cuda.is_current_stream_capturing():
             raise _abi.ScoaryHipError("capture(): the current stream is already capturing")
+        if workspace.label_shards is not None and workspace.label_shards.world > 1:
+            raise _abi.ScoaryHipError("capture(): label shards are active -- their all-gather is a collective "
+                                      "and cannot be recorded into a hipGraph")
         self.associate(genes, traits, masks, permutations=permutations, seed=seed,
-                       use_lists=use_lists, workspace=workspace, plan=plan, graph=False)
+                       use_lists=use_lists, workspace=workspace, plan=plan, graph=False, records=records)
         torch.cuda.synchronize(self.device)
         stream = torch.cuda.Stream(device=self.device)      # a fresh stream: never mid-capture
         with torch.cuda.stream(stream):
@@ -657,7 +681,8 @@ class AssociationEngine:
             failed = True
             try:
                 res = self.associate(genes, traits, masks, permutations=permutations, seed=seed,
-                                     use_lists=use_lists, workspace=workspace, plan=plan, graph=False)
+                                     use_lists=use_lists, workspace=workspace, plan=plan, graph=False,
+                                     records=records)
                 failed = False
             finally:
                 # the capture must be ended either way; a graph that came out of a failed step

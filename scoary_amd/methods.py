@@ -305,8 +305,12 @@ _ENGINE = None
 def get_engine():
     global _ENGINE
     if _ENGINE is None:
-        _ENGINE = AssociationEngine()
-        _warm_up(_ENGINE)
+        eng = AssociationEngine()
+        try:
+            _warm_up(eng)
+        except Exception as e:      # only an optimisation: a tiny list budget, a failed LDS opt-in or an
+            log.debug("engine warm-up skipped: %s: %s" % (type(e).__name__, e))   # OOM must not cost the run
+        _ENGINE = eng
     return _ENGINE
 
 
@@ -726,8 +730,9 @@ def _pattern_groups(table, maskrow, idx, hashes):
 
 def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False):
     """Whole hot path for all traits; under torchrun (world > 1) every rank
-    takes a contiguous gene shard and the per-gene records are all-gathered
-    over RCCL (scoary_amd.dist), so every rank returns the full arrays.
+    takes a stride gene shard (dist.GenePartition: the reference's domains,
+    scoary/methods.py:1076-1078) and the per-gene records are all-gathered
+    over RCCL and woven back into file order, so every rank returns the full arrays.
     ``early_abort``: the reference's sequential estimator (scoary/methods.py:1360-1363)
     on the Fisher statistic instead of the fixed-P count: out["nstop"] then holds the
     permutation count every gene stopped at (0 = ran to the end)."""
@@ -740,11 +745,13 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
         mkv = eng.vecrows(pack_bits_rows(tarr != 2), N)
         plan = eng.trait_plan(trv, mkv, N)            # margins + mask classes: once per trait set
 
-    def local(a, b):
-        if b <= a:
+    def local(sel):
+        a = sel.start
+        whole = sel == slice(0, G, 1)
+        if len(range(*sel.indices(G))) == 0:
             return torch.zeros((T, 0, dist.REC_WORDS), dtype=torch.int32, device=eng.device)
         with _stage("device setup (H2D, tiling, trait plan)"):
-            gm = table.on_device(eng) if (a, b) == (0, G) else eng.tile_rows(table.rows64[a:b], N)
+            gm = table.on_device(eng) if whole else eng.tile_rows(table.rows64[sel], N)
             torch.cuda.synchronize(eng.device)
         if permutations > 0 and not early_abort and gm.lists is None and eng.lists_supported(N):
             # list-driven permutation kernel: cost follows each gene's minority count.  The

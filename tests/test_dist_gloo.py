@@ -30,10 +30,10 @@ def _case():
     return genes, traits, N, P, 77
 
 
-def _worker(rank, world, port, outq):
+def _worker(rank, world, port, outq, kind="stride"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), SCOARY_GENE_PARTITION=kind)
     from oracle import oracle as orc
     from scoary_amd import dist as sd
     from scoary_amd.engine import pack_bits_rows
@@ -44,10 +44,10 @@ def _worker(rank, world, port, outq):
     mb = pack_bits_rows((traits != 2).astype(np.uint8))
     T = traits.shape[0]
 
-    def local(a, b):
-        if b <= a:
+    def local(sel):
+        if len(range(*sel.indices(genes.shape[0]))) == 0:
             return torch.zeros((T, 0, sd.REC_WORDS), dtype=torch.int32)
-        gb = orc.pack_rows(genes[a:b])
+        gb = orc.pack_rows(np.ascontiguousarray(genes[sel]))
         c = orc.counts_packed(gb, tb, mb).transpose(1, 0, 2).copy()
         o, p = orc.fisher_many(c.reshape(-1, 4))
         rr = orc.permute_r(gb, tb, mb, N, P, seed).T.copy()
@@ -62,14 +62,16 @@ def _worker(rank, world, port, outq):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gene_shard_all_gather_gloo(world):
+@pytest.mark.parametrize("world,kind", [(2, "stride"), (3, "stride"), (3, "contiguous")])
+def test_gene_shard_all_gather_gloo(world, kind):
+    """Every rank computes its shard (stride domains by default, the reference's partition;
+    uneven at world 3) and the all-gathered, re-woven records equal the single-process result."""
     from oracle import oracle as orc
     from scoary_amd.engine import pack_bits_rows
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(world)]
@@ -101,6 +103,68 @@ def test_shard_bounds_cover_exactly():
             assert max(sizes) - min(sizes) <= 1 and max(sizes) == max_shard(G, world)
 
 
+def test_gene_partition_covers_and_weaves():
+    """GenePartition: the shards of every rank are disjoint and cover the genes; lengths add up and
+    the longest is `cap`; weave() puts gathered (padded) shards back into gene order -- numpy and
+    torch, stride and contiguous, even and uneven splits, more ranks than genes."""
+    from scoary_amd.dist import GenePartition
+    for kind in ("stride", "contiguous"):
+        for G in (1, 5, 8, 9, 203, 1000):
+            for world in (1, 2, 3, 8):
+                part = GenePartition(G, world, kind)
+                seen = np.zeros(G, dtype=np.int64)
+                T, W = 2, 3
+                full = np.arange(T * G * W, dtype=np.int32).reshape(T, G, W)
+                recv = np.full((world, T, part.cap, W), -1, dtype=np.int32)
+                for r in range(world):
+                    sel = part.index(r)
+                    seen[sel] += 1
+                    n = part.length(r)
+                    assert n == len(range(G)[sel]) and n <= part.cap
+                    recv[r, :, :n] = full[:, sel]
+                assert (seen == 1).all() and sum(part.lengths()) == G and max(part.lengths()) == part.cap
+                assert np.array_equal(part.weave(recv), full)
+                assert torch.equal(part.weave(torch.from_numpy(recv)), torch.from_numpy(full))
+    # the stride shard IS the reference's domain (scoary/methods.py:1076-1078)
+    part = GenePartition(11, 4)
+    assert [list(range(11))[part.index(t)] for t in range(4)] == [list(range(t, 11, 4)) for t in range(4)]
+
+
+def _list_work(rows_ones, N, part):
+    """Minority entries per rank: what the list-driven permutation kernel's time follows."""
+    minority = np.minimum(rows_ones, N - rows_ones)
+    return np.array([minority[part.index(r)].sum() for r in range(part.world)], dtype=np.float64)
+
+
+def test_stride_shards_balance_list_work_on_roary_order(exampledir):
+    """Roary writes its table sorted by gene frequency (the reference's own
+    exampledata: 100, ..., 0 isolates), and the list kernel's cost follows min(ones, N - ones).
+    An 8-way contiguous equal-count split of that table leaves two ranks idle (max / mean 1.84);
+    the stride domains -- the reference's own partition -- are within 10 % of the mean (in fact
+    within 1 %)."""
+    from scoary_amd import methods as m
+    from scoary_amd.dist import GenePartition
+    with open(os.path.join(exampledir, "Gene_presence_absence.csv"), "r", newline=None) as f:
+        table = m.Csv_to_dic_Roary(f, ",", [], startcol=14)["Roarydic"]
+    N = len(table.strains)
+    ones = np.unpackbits(table.rows64.view(np.uint8), axis=1).sum(axis=1).astype(np.int64)
+    assert (np.diff(ones) <= 0).all()                         # the file really is frequency-sorted
+    G = len(ones)
+    old = _list_work(ones, N, GenePartition(G, 8, "contiguous"))
+    new = _list_work(ones, N, GenePartition(G, 8, "stride"))
+    assert old.min() == 0 and old.max() / old.mean() > 1.8    # what rounds 1-5 did
+    assert new.max() / new.mean() <= 1.10
+    assert new.max() / new.mean() <= 1.01
+    # and on a synthetic cfg3-like spectrum sorted the same way, 2 ... 8 ranks
+    rng = np.random.default_rng(3)
+    ones = np.sort(rng.binomial(2000, rng.uniform(0.02, 0.98, 50000)))[::-1]
+    for world in (2, 4, 8):
+        w = _list_work(ones, 2000, GenePartition(50000, world, "stride"))
+        assert w.max() / w.mean() <= 1.001
+        c = _list_work(ones, 2000, GenePartition(50000, world, "contiguous"))
+        assert c.max() / c.mean() > (1.4 if world > 2 else 0.99)
+
+
 def test_record_pack_roundtrip():
     from scoary_amd import dist as sd
     rng = np.random.default_rng(0)
@@ -110,9 +174,16 @@ def test_record_pack_roundtrip():
     o = torch.from_numpy(np.where(rng.random((T, G)) < 0.2, np.inf, rng.random((T, G)) * 50))
     o[0, 0] = float("nan")
     r = torch.from_numpy(rng.integers(0, 2**31 - 1, (T, G)).astype(np.int32))
-    d = sd.unpack_records(sd.pack_records(c, p, o, r))
+    rec = sd.pack_records(c, p, o, r)
+    d = sd.unpack_records(rec)
     assert torch.equal(d["counts"], c) and torch.equal(d["p"], p) and torch.equal(d["r"], r)
     assert torch.equal(d["odds"].view(torch.int64), o.view(torch.int64))   # bit pattern, nan incl.
+    # numpy_records: one copy of the record tensor, numpy slices (no torch kernels) -- same content
+    h = sd.numpy_records(rec)
+    assert np.array_equal(h["counts"], c.numpy()) and np.array_equal(h["p"], p.numpy())
+    assert np.array_equal(h["odds"].view(np.int64), o.numpy().view(np.int64))
+    assert np.array_equal(h["r"], r.numpy().view(np.uint32)) and not h["nstop"].any()
+    assert all(v.flags["C_CONTIGUOUS"] for v in h.values())
 
 
 def _gather_worker(rank, world, port, outq):
@@ -122,19 +193,21 @@ def _gather_worker(rank, world, port, outq):
     from scoary_amd import dist as sd
     sd.init_from_env()
     G, T = 11, 2
-    a, b = sd.shard_bounds(G, world)[rank]
     full = torch.arange(T * G * sd.REC_WORDS, dtype=torch.int32).view(T, G, sd.REC_WORDS)
     outs = []
-    for async_op in (False, True):
-        _, finish = sd.gather_genes(full[:, a:b].contiguous(), G, dst=0, async_op=async_op)
-        outs.append(finish())
+    for kind in ("stride", "contiguous"):
+        part = sd.GenePartition(G, world, kind)
+        for async_op in (False, True):
+            _, finish = sd.gather_genes(full[:, part.index(rank)].contiguous(), G, dst=0, async_op=async_op,
+                                        partition=part)
+            outs.append(finish())
     outq.put((rank, [None if o is None else o.numpy() for o in outs]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_gather_to_rank0_gloo():
-    """bench.py's exchange step: a true gather (uneven shards), sync and async."""
+    """bench.py's exchange step: a true gather (uneven shards; stride and contiguous), sync and async."""
     world = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -148,7 +221,7 @@ def test_gather_to_rank0_gloo():
         assert p.exitcode == 0
     want = np.arange(2 * 11 * 10, dtype=np.int32).reshape(2, 11, 10)
     assert all(np.array_equal(o, want) for o in got[0])
-    assert got[1] == [None, None] and got[2] == [None, None]
+    assert len(got[0]) == 4 and got[1] == [None] * 4 and got[2] == [None] * 4
 
 
 def _label_shard_worker(rank, world, port, outq):
@@ -204,7 +277,8 @@ def _exchange_worker(rank, world, port, outq):
     from scoary_amd import dist as sd
     sd.init_from_env()
     T, G, steps = 2, 5, 5
-    ex = bench.Exchange(torch, types.SimpleNamespace(device="cpu"), world, rank, T, G)
+    ex = bench.Exchange(torch, types.SimpleNamespace(device="cpu"), world, rank, T,
+                        sd.GenePartition(G * world, world, "contiguous"))
     for step in range(steps):
         base = 1000 * step + 100 * rank
         res = {"counts": torch.full((T, G, 4), base, dtype=torch.int32),

@@ -35,6 +35,7 @@ def test_bench_json_contract(extra):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["scaling"] == "weak"
+    assert d["scaling_strong"] is None                      # an overridden shape: only the default line carries it
     assert "workload" in d["config"] and "model" not in d["config"]
     G, T, P = d["config"]["genes_per_gpu"], d["config"]["traits"], d["config"]["permutations"]
     assert (G, P) == (3000, 1024)
@@ -128,6 +129,17 @@ def test_bench_headline_line_explains_itself():
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     r, tel = d["roofline"], d["telemetry"]
     assert "cfg3" in d["config"]["workload"] and d["config"]["permutations"] == 10_000
+    # the strong curve's entries ride along (at one GPU: the denominators) -- cfg3 is the line itself,
+    # cfg4 (200 000 variants x 5000 isolates, one trait) is timed the same way
+    ss = d["scaling_strong"]
+    assert ss["cfg3"]["n_gpus"] == 1 and abs(ss["cfg3"]["value"] - d["value"]) < 1e-6 * d["value"]
+    c4 = ss["cfg4"]
+    for k in ("workload", "n_gpus", "value", "unit", "ms_per_step", "steps", "warmup", "genes_per_gpu",
+              "gene_partition", "gene_order", "hip_graph", "kernel_ms", "exchange_exposed_ms", "rccl_ranks", "per_rank"):
+        assert k in c4, k
+    assert c4["n_gpus"] == 1 and c4["genes_per_gpu"] == [200_000] and c4["per_rank"] is None
+    assert abs(c4["value"] - 200_000 * 10_000 / (c4["ms_per_step"] * 1e-3)) < 1e-6 * c4["value"]
+    assert c4["value"] > 1e11 and c4["kernel_ms"]["k_permute_lists"] > 0
     if tel["source"] is None:
         pytest.skip("this box exposes no clock / power source (amdsmi, hwmon): nothing to check")
     assert tel["samples"] >= 10                              # >= 10 samples inside the timed region

@@ -1099,6 +1099,38 @@ def test_perm_labels_bit_exact_beyond_one_dword_per_row(eng, orc, N, T, P, base)
             assert not perms[t, j, 2 * W:].any()
 
 
+def test_perm_labels_per_lane_mark_counters_do_not_wrap(eng, orc):
+    """a lane counts its round-0 marks in 10 bit-sliced planes (<= 1023).  With
+    >= 512 blocks in the launch the generator kept 256 threads per block, so at N > 261 888 a thread
+    owned up to 2 558 rows and a ~50 % trait (q near 128) wrapped the count: K came out 1024 short per
+    overflowed lane, the fix-up ADDED the difference, and the permuted labels no longer had npos
+    positives.  The launch now widens the block until a thread has at most 1023 rows.  N = 654 848
+    (the largest the generator takes) and N = 300 000, a 50 % trait, P = 1024 (a launch of >= 512
+    blocks): every permutation has exactly npos positives among the valid isolates, and selected
+    permutations equal the oracle bit for bit."""
+    import torch
+    for N, P in ((654_848, 1024), (300_000, 1056)):
+        rng = np.random.default_rng(N % 977)
+        traits = (rng.random((1, N)) < 0.5).astype(np.uint8)
+        traits[0, rng.random(N) < 0.01] = 2
+        tb, mb = _bits(eng, traits)
+        npos, nval = int((traits[0] == 1).sum()), int((traits[0] != 2).sum())
+        masks = eng.vecrows(mb, N)
+        margins = torch.tensor([[npos, nval]], dtype=torch.int32, device="cuda")
+        perms = eng.perm_generate(masks, margins, N, P, 0, 31337)
+        W = (N + 63) // 64
+        # positives per permutation, counted on the host from the bit rows (32-bit words)
+        host = perms.cpu().numpy().view(np.uint32)[0]                       # [P, Wp]
+        ones = np.bitwise_count(host[:, :2 * W]).sum(axis=1, dtype=np.int64)
+        assert np.array_equal(ones, np.full(P, npos)), (N, int(ones.min()), int(ones.max()), npos)
+        mask32 = np.ascontiguousarray(mb[0]).view(np.uint32)
+        assert not (host[:, :2 * W] & ~mask32[None, :]).any()               # labels only on valid isolates
+        for j in (0, 517, P - 1):
+            want = orc.perm_labels(31337, 0, j, mb[0], npos, N)
+            assert np.array_equal(np.ascontiguousarray(host[j, :2 * W]).view(np.uint64), want), (N, j)
+        del perms, host
+
+
 def test_perm_labels_every_margin_of_small_traits(eng, orc):
     """Spec S4 at its corners: every (valid isolates, positives) pair of traits over N = 1 ... 9 and a
     few over N = 33 / 70 -- no positives, all positive, one valid isolate, the complemented side,

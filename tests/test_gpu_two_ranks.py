@@ -3,12 +3,13 @@
 No multi-GPU box is available to the build or to `pytest -m gpu`, so the two ranks share the
 one device (`--share-gpu`) and exchange over gloo; everything else is the multi-GPU path as
 it runs on 8 GPUs: bench.py's own launcher (re-exec under torch.distributed.run), one
-process per rank, gene shards (weak: every rank its own shard; strong: shard_bounds of the
-config's genes), labels regenerated from the seed on every rank, scoary_pack_records, the
-asynchronous gather of 10-word records overlapped with the next step, and rank 0's checks.
-`--verify-gather`: rank 0 recomputes every rank's shard alone and compares the records it
-received bit for bit.  Reference analogue: the stride domains and the result weave of
-scoary/methods.py:1076-1097, :1115-1122.
+process per rank, gene shards (weak: every rank its own shard; strong: the reference's stride
+domains of the config's genes, dist.GenePartition), labels regenerated from the seed on every
+rank, scoary_pack_records, the asynchronous gather of 10-word records overlapped with the next
+step, and rank 0's checks.  `--verify-gather`: rank 0 recomputes every rank's shard alone and
+compares the records it received bit for bit, then weaves the blocks back into gene order and
+compares them with ONE run over the whole matrix.  Reference analogue: the stride domains and
+the result weave of scoary/methods.py:1076-1097, :1115-1122.
 """
 import json
 import os
@@ -66,10 +67,11 @@ def _free_port():
 
 
 def test_bench_three_ranks_uneven_strong_shards():
-    """Three ranks, strong scaling: 10 000 genes do not divide by three (3334 / 3333 / 3333), so
-    the gather pads the shorter shards to the longest and rank 0 trims them again; every
-    record still equals the single-rank run's."""
+    """Three ranks, strong scaling: 10 000 genes do not divide by three (stride domains of 3334 /
+    3333 / 3333), so the gather pads the shorter shards to the longest and the weave drops the pad
+    slots again; every record still equals the single-rank run's."""
     d = _bench(["--scaling", "strong"], ranks=3)
+    assert d["config"]["gene_partition"].startswith("stride")
     assert d["n_gpus"] == 3 and d["rccl_ranks"] == 3 and d["gather_matches_single_rank"] is True
     assert d["config"]["genes_total"] == 10_000
     assert [r["genes"] for r in d["per_rank"]] == [3334, 3333, 3333]
@@ -81,8 +83,8 @@ def test_bench_three_ranks_uneven_strong_shards():
 def test_command_line_two_ranks_share_the_gpu(exampledir, tmp_path, extra):
     """`python -m scoary_amd` under torch.distributed.run with two ranks on the one GPU
     (SCOARY_SHARE_GPU=1, SCOARY_DIST_BACKEND=gloo): every rank parses one byte range of the
-    gene table, takes one contiguous gene shard through the kernels, the per-gene records are
-    all-gathered, rank 0 writes -- and the result files are byte-identical to a single-process
+    gene table, takes one stride gene shard through the kernels, the per-gene records are
+    all-gathered and woven back into file order, rank 0 writes -- and the result files are byte-identical to a single-process
     run's (Tree.nwk included in default mode).  Reference analogue: scoary/methods.py:1076-1122."""
     inputs = ["-g", os.path.join(exampledir, "Gene_presence_absence.csv"),
               "-t", os.path.join(exampledir, "Tetracycline_resistance.csv")]
@@ -130,6 +132,50 @@ def test_bench_eight_ranks_cfg4_strong_split():
     assert all(r["exchange_bytes"] == 25_000 * 40 for r in pr)
     assert all(r["kernel_ms"]["k_permute_lists"] > 0 for r in pr)
     assert abs(d["value"] - 200_000 * 10_000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("partition", ["stride", "contiguous"])
+def test_bench_eight_ranks_frequency_sorted_genes(partition):
+    """Roary writes its table sorted by gene frequency, and the list kernel's cost
+    follows a gene's minority count.  cfg3 with its rows in that order (--gene-order sorted),
+    split 8 ways: the stride domains (the reference's own partition, scoary/methods.py:1076-1078)
+    give every rank the same list work to within 1 %; the contiguous equal-count blocks of rounds
+    1-5 are > 1.4x apart (kept as --partition contiguous, the A/B).  Either way the gathered blocks
+    equal rank 0's recomputation shard by shard AND, woven back into gene order, one run over the
+    whole sorted matrix."""
+    d = _bench(["--scaling", "strong", "--no-cpu-baseline", "--gene-order", "sorted", "--partition", partition],
+               ranks=8, config="cfg3", steps=2)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["gather_matches_single_rank"] is True
+    assert d["config"]["gene_order"] == "sorted" and d["config"]["gene_partition"].startswith(partition)
+    pr = d["per_rank"]
+    assert [r["genes"] for r in pr] == [6250] * 8
+    work = [r["list_entries"] for r in pr]
+    spread = max(work) / (sum(work) / 8.0)
+    if partition == "stride":
+        assert spread <= 1.01
+    else:
+        assert spread > 1.4
+
+
+def test_bench_two_ranks_strong_curve_next_to_the_weak_line():
+    """`scaling_strong`: next to the weak line, the same process group times the
+    strong split of cfg3 (50 000 genes) and cfg4 (200 000 variants) over its ranks -- exchange
+    included, a launch-bound shard replayed from a hipGraph -- so the driver's 1 / 2 / 4 / 8 runs
+    yield the strong curve of SURVEY 8e as well."""
+    d = _bench(["--scaling", "weak", "--no-cpu-baseline", "--strong-extra", "on"], ranks=2, config="cfg2", steps=2)
+    ss = d["scaling_strong"]
+    for cfg, G, T in (("cfg3", 50_000, 10), ("cfg4", 200_000, 1)):
+        e = ss[cfg]
+        assert e["n_gpus"] == 2 and e["rccl_ranks"] == 2 and e["genes_per_gpu"] == [G // 2, G // 2]
+        assert e["gene_partition"] == "stride" and e["steps"] == 2
+        assert abs(e["value"] - G * T * 10_000 / (e["ms_per_step"] * 1e-3)) < 1e-6 * e["value"]
+        assert [r["rank"] for r in e["per_rank"]] == [0, 1]
+        for r in e["per_rank"]:
+            assert r["kernel_ms"]["k_permute_lists"] > 0 and r["exchange_exposed_ms"] is not None
+            assert r["ms_per_step"] <= e["ms_per_step"] * (1 + 1e-9)
+        work = [r["list_entries"] for r in e["per_rank"]]
+        assert max(work) / (sum(work) / 2.0) < 1.02
+    assert ss["cfg3"]["hip_graph"] is False and ss["cfg4"]["hip_graph"] is False     # 2.5e9 / 1e9 tests per rank
 
 
 def test_bench_eight_ranks_cfg4_label_tile_shards():
@@ -199,6 +245,24 @@ def test_bench_one_rank_through_rccl(scaling):
     assert d["config"]["exchange"].startswith("rccl gather")
     assert d["per_rank"][0]["exchange_bytes"] == 10_000 * 40
     assert d["per_rank"][0]["exchange_exposed_ms"] is not None
+    # cfg2 is launch-bound: the sharded rank replays its local step (record packing included) from
+    # a hipGraph, the gather stays outside (round 6)
+    assert d["config"]["hip_graph"] is True and d["config"]["hip_graph_auto"] is True
+
+
+def test_bench_rank_of_eight_cfg4_through_rccl_replays_a_graph():
+    """One rank of cfg4's 8-way split (25 000 variants) under torch.distributed.run through real
+    RCCL: 2.5e8 tests per step, launch-bound -- the local step runs as a hipGraph replay with the
+    records packed inside it (two graphs, alternating record buffers), the gather outside; the
+    gathered records equal an eager single-rank run's."""
+    out = _torchrun(1, [os.path.join(ROOT, "bench.py"), "--exercise-exchange", "--backend", "nccl",
+                        "--verify-gather", "--config", "cfg4", "--genes", "25000", "--scaling", "strong",
+                        "--steps", "20", "--warmup", "3", "--no-cpu-baseline"], _clean_env())
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["rccl_ranks"] == 1 and d["gather_matches_single_rank"] is True
+    assert d["config"]["hip_graph"] is True and d["config"]["genes_per_gpu"] == 25_000
+    assert d["per_rank"][0]["exchange_exposed_ms"] is not None and d["ms_per_step"] < 1.0
 
 
 def test_command_line_one_rank_through_rccl(exampledir, tmp_path):
@@ -224,8 +288,8 @@ def test_command_line_one_rank_through_rccl(exampledir, tmp_path):
 
 def test_command_line_eight_ranks_share_the_gpu(exampledir, tmp_path):
     """The command line at the node's full width: eight ranks under torch.distributed.run on the one
-    GPU (gloo), each parsing one byte range of the gene table and taking one of eight gene shards
-    (9 001 rows: uneven) through the kernels; result files and Tree.nwk byte-identical to one process."""
+    GPU (gloo), each parsing one byte range of the gene table and taking one of eight stride gene
+    shards (9 001 frequency-sorted rows: uneven) through the kernels; result files and Tree.nwk byte-identical to one process."""
     inputs = ["-g", os.path.join(exampledir, "Gene_presence_absence.csv"),
               "-t", os.path.join(exampledir, "Tetracycline_resistance.csv"),
               "-e", "100", "--seed", "11", "--no-time", "-u", "-c", "I", "EPW", "-p", "0.05", "0.5"]
