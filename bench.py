@@ -716,8 +716,9 @@ def small_kernel_rooflines(args, G, N, T, n_mask_classes, kernel_ms):
 
 
 def k1_cold_report(eng, args, G=125_000, N=10_000, copies=8, rounds=3):
-    """K1 as an HBM stream: k_counts on cfg5's per-GPU shard shape with T = 1 and
-    T = 4, over `copies` different matrices launched in rotation.  One tiled matrix is 160 MB, eight are
+    """K1 as an HBM stream: k_counts on cfg5's per-GPU shard shape with T = 1 ... 50
+    traits (round 6: the whole sweep, to locate where the kernel leaves the HBM roofline for the AND +
+    popcount one), over `copies` different matrices launched in rotation.  One tiled matrix is 160 MB, eight are
     1.28 GB: when a matrix comes round again, 1.1 GB of other matrices have gone through the 256 MiB
     Infinity Cache since its last use, so every launch reads HBM.  The content does not enter the timing
     (random bits, made on the device).  The same kernel on ONE matrix back to back rides along as `warm`."""
@@ -735,7 +736,7 @@ def k1_cold_report(eng, args, G=125_000, N=10_000, copies=8, rounds=3):
                     % (G, N, copies, Qp * Gp * 16 / 1e6),
            "measured_copy_peak_gbs": copy_gbs, "hbm_peak_gbs": HBM_PEAK_GBS, "runs": []}
     rng = np.random.default_rng(11)
-    for T in (1, 4):
+    for T in (1, 2, 4, 8, 16, 32, 50):
         traits = synth.make_traits(T, N, rng)
         trv = eng.vecrows(pack_bits_rows((traits == 1).astype(np.uint8)), N)
         mkv = eng.vecrows(pack_bits_rows((traits != 2).astype(np.uint8)), N)
@@ -757,14 +758,27 @@ def k1_cold_report(eng, args, G=125_000, N=10_000, copies=8, rounds=3):
             return sum(ms) / len(ms), ms[len(ms) // 2]
         cold_mean, cold_med = timed(mats * rounds)
         warm_mean, warm_med = timed([mats[0]] * (copies * rounds))
+        # the two floors of this launch: the B1 bytes at the HBM peak, and 2 lane-ops (AND, popcount-accumulate)
+        # per 32 isolates and (gene, vector) at the measured rate of that op pair; vectors = T label rows + one
+        # validity row per pass (no missing values here: one mask class)
+        passes = -(-T // int(eng.lib.scoary_counts_traits_per_pass(T)))
+        ops = 2.0 * ((N + 31) // 32) * G * (T + passes)
+        hbm_floor, valu_floor = b1 / (HBM_PEAK_GBS * 1e9), ops / VALU_PEAK_AND_BCNT
         out["runs"].append({
             "traits": T, "bytes": b1, "bytes_formula": "8*W*G + 16*W*T + 16*G*T (SURVEY 8d B1)",
+            "passes_over_matrix": passes, "hbm_floor_ms": hbm_floor * 1e3, "valu_floor_ms": valu_floor * 1e3,
+            "bound": "hbm" if hbm_floor >= valu_floor else "valu",
+            "frac_of_bound": max(hbm_floor, valu_floor) / (cold_med * 1e-3),
             "cold_ms_mean": cold_mean, "cold_ms_median": cold_med,
             "gbs": b1 / (cold_med * 1e-3) / 1e9,
             "hbm_frac": b1 / (cold_med * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "frac_of_measured_copy_peak": b1 / (cold_med * 1e-3) / 1e9 / copy_gbs,
             "warm_ms_median": warm_med, "warm_gbs": b1 / (warm_med * 1e-3) / 1e9,
             "launches": copies * rounds})
+    hb = [r["traits"] for r in out["runs"] if r["bound"] == "hbm"]
+    out["crossover"] = ("HBM floor above the AND + popcount floor up to T = %s traits on this shape (B1 at 8 TB/s against "
+                        "2 lane-ops per 32 isolates and vector at %.1e lane-ops/s)" % (max(hb) if hb else 0,
+                                                                                    VALU_PEAK_AND_BCNT))
     return out
 
 
@@ -845,6 +859,7 @@ def strong_split_case(torch, dist, eng, args, cfg, world, rank, local_rank, shar
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    host_issue_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)
     exposed_ms = None
     if exchange:
         last.record()
@@ -872,7 +887,7 @@ def strong_split_case(torch, dist, eng, args, cfg, world, rank, local_rank, shar
         dt = float(tmax.item())
         per_rank = sdist.all_gather_objects({
             "rank": rank, "genes": G, "list_entries": list_entries, "ms_per_step": dt_own / args.steps * 1e3,
-            "kernel_ms": kernel_ms, "exchange_exposed_ms": exposed_ms,
+            "kernel_ms": kernel_ms, "exchange_exposed_ms": exposed_ms, "host_issue_ms_per_step": host_issue_ms,
             "exchange_bytes": T * G * sdist.REC_WORDS * 4})
         rccl_ranks = exchange.check(T, (traits != 2).sum(1))
         if rank == 0 and exchange.kind == "gather" and rccl_ranks != world:
@@ -887,7 +902,7 @@ def strong_split_case(torch, dist, eng, args, cfg, world, rank, local_rank, shar
             "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
             "genes_per_gpu": part.lengths(), "gene_partition": part.kind, "gene_order": args.gene_order,
             "hip_graph": bool(graphs), "kernel_ms": kernel_ms, "exchange_exposed_ms": exposed_ms,
-            "rccl_ranks": rccl_ranks, "per_rank": per_rank}
+            "host_issue_ms_per_step": host_issue_ms, "rccl_ranks": rccl_ranks, "per_rank": per_rank}
 
 
 def dry_exchange(args, world, rank):
@@ -1060,6 +1075,9 @@ def main():
     for i in range(args.steps):
         step()
         ev[i + 1].record()
+    # how long the HOST took to issue the steps (launches, graph replays, the exchange's submit): when this
+    # is close to the whole timed region the run is bound by the interpreter, not by the GPU
+    host_issue_ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)
     exposed_ms = None
     if exchange:
         # what the exchange step costs beyond the kernels: wall clock from the moment this
@@ -1160,7 +1178,7 @@ def main():
                 "ms_per_step_median": median_ms, "kernel_ms": kernel_ms,
                 # what the list kernel's cost follows: the minority entries of this rank's genes
                 "list_entries": int(np.minimum(ones, N - ones).sum()),
-                "exchange_exposed_ms": exposed_ms,
+                "exchange_exposed_ms": exposed_ms, "host_issue_ms_per_step": host_issue_ms,
                 "exchange_bytes": T * G * sdist.REC_WORDS * 4,
                 "label_tile_bytes_gathered": None if eng.label_shards is None
                 else eng.label_shards.bytes_gathered // max(args.steps + args.warmup, 1),
@@ -1241,6 +1259,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_median": median_ms,
+            "host_issue_ms_per_step": host_issue_ms,
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,

@@ -113,6 +113,31 @@ void scoary_lists_build(const uint64_t *rows64, int64_t G, int64_t N, int64_t ro
 int64_t scoary_vcf_convert(const char *vcf_path, int64_t offset, const char *out_path,
                            const char *types);
 
+/* ---- a9: the per-trait results file (StoreTraitResult, scoary/methods.py:1003-1197) -------------
+ * Writes `header` (the finished header line, newline included) and nrows rows to `path`.  A row is
+ * ntext text cells followed by nnum numeric cells, every cell wrapped in double quotes
+ * (methods.py:1052, :1195-1197), joined by `delimiter`, '\n' after the last cell.
+ *   text column c : the cell of row r is bytes [text_off[c][k], text_off[c][k+1]) of text_blob[c]
+ *                   with k = text_row[c][r] -- a column is a string table (e.g. the gene table's
+ *                   identifiers, built once per table) and an index per written row, so a trait's
+ *                   file costs no Python object per row;
+ *   numeric col c : value cols[c][num_row[r]]; kind[c] = 0: int64, printed as a decimal;
+ *                   kind[c] = 1: float64, printed as Python's repr(float) -- the shortest digits
+ *                   that round-trip, fixed notation while 1e-4 <= |x| < 1e16 (".0" appended to
+ *                   integers), else d.ddde[+-]XX with at least two exponent digits; "inf", "-inf",
+ *                   "nan" -- which is what str() of the reference's numpy.float64 / float cells
+ *                   gives.
+ * Rows are formatted by `threads` OpenMP threads (<= 0: all) in blocks and written in order.
+ * Returns the bytes written, or -1 if the file cannot be opened / written, -2 on a bad argument. */
+int64_t scoary_results_write(const char *path, char delimiter, const char *header, int64_t header_len,
+                             int64_t nrows, int32_t ntext, const char *const *text_blob,
+                             const int64_t *const *text_off, const int64_t *const *text_row,
+                             int32_t nnum, const int32_t *kind, const void *const *cols,
+                             const int64_t *num_row, int64_t threads);
+/* repr(float) of one value into buf (>= 32 bytes); returns the length (the formatter above, exposed
+ * so that it can be checked against the interpreter value by value). */
+int32_t scoary_format_float_repr(double x, char *buf);
+
 /* ---- UPGMA merge order (scoary/methods.py:640-707, scoary/classes.py:68-196) ------
  * D: n x n float64 distances, row-major, diagonal already forced to 1
  * (methods.py:636-638).  Runs the reference's merge loop -- quad tree of 2x2

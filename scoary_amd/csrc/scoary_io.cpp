@@ -14,6 +14,8 @@
 #include <omp.h>
 #endif
 #include <algorithm>
+#include <charconv>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -834,4 +836,145 @@ extern "C" int scoary_upgma_merges(const double* D, int64_t n, int32_t* merges) 
     size[(size_t)j] = 0.0;
   }
   return 0;
+}
+
+
+// ---- a9: results file writer (include/scoary_io.h) -----------------------------------------------
+namespace {
+// Python's repr(float): shortest round-trip digits (std::to_chars, scientific, no precision = shortest;
+// the same digit string as the interpreter's dtoa mode 0) laid out by float_repr_style 'short':
+// decpt = exponent + 1; exponent notation iff decpt <= -4 or decpt > 16 (CPython format_float_short, 'r').
+inline int format_repr(double x, char* out) {
+  if (std::isnan(x)) { std::memcpy(out, "nan", 3); return 3; }
+  if (std::isinf(x)) {
+    if (x < 0) { std::memcpy(out, "-inf", 4); return 4; }
+    std::memcpy(out, "inf", 3);
+    return 3;
+  }
+  char* o = out;
+  if (std::signbit(x)) { *o++ = '-'; x = -x; }
+  if (x == 0.0) { std::memcpy(o, "0.0", 3); return (int)(o - out) + 3; }
+  char sci[40];
+  const auto r = std::to_chars(sci, sci + sizeof sci, x, std::chars_format::scientific);
+  // sci = d[.ddd]e[+-]XX
+  char digits[24];
+  int nd = 0;
+  const char* p = sci;
+  digits[nd++] = *p++;
+  if (*p == '.') {
+    ++p;
+    while (*p != 'e') digits[nd++] = *p++;
+  }
+  ++p;                                               // 'e'
+  int ex = 0;
+  const bool neg = *p == '-';
+  ++p;                                               // sign (always present)
+  while (p < r.ptr) ex = ex * 10 + (*p++ - '0');
+  if (neg) ex = -ex;
+  const int decpt = ex + 1;
+  if (decpt <= -4 || decpt > 16) {                   // exponent notation
+    *o++ = digits[0];
+    if (nd > 1) {
+      *o++ = '.';
+      std::memcpy(o, digits + 1, nd - 1);
+      o += nd - 1;
+    }
+    *o++ = 'e';
+    int e = decpt - 1;
+    *o++ = e < 0 ? '-' : '+';
+    if (e < 0) e = -e;
+    char eb[8];
+    int ne = 0;
+    do { eb[ne++] = (char)('0' + e % 10); e /= 10; } while (e);
+    if (ne < 2) eb[ne++] = '0';
+    while (ne) *o++ = eb[--ne];
+  } else if (decpt <= 0) {                           // 0.000ddd
+    *o++ = '0';
+    *o++ = '.';
+    for (int k = 0; k < -decpt; ++k) *o++ = '0';
+    std::memcpy(o, digits, nd);
+    o += nd;
+  } else if (decpt >= nd) {                          // ddd000.0
+    std::memcpy(o, digits, nd);
+    o += nd;
+    for (int k = nd; k < decpt; ++k) *o++ = '0';
+    *o++ = '.';
+    *o++ = '0';
+  } else {                                           // dd.ddd
+    std::memcpy(o, digits, decpt);
+    o += decpt;
+    *o++ = '.';
+    std::memcpy(o, digits + decpt, nd - decpt);
+    o += nd - decpt;
+  }
+  return (int)(o - out);
+}
+inline int format_int(int64_t v, char* out) {
+  const auto r = std::to_chars(out, out + 24, v);
+  return (int)(r.ptr - out);
+}
+}  // namespace
+
+extern "C" int32_t scoary_format_float_repr(double x, char* buf) { return buf ? format_repr(x, buf) : -2; }
+
+extern "C" int64_t scoary_results_write(const char* path, char delimiter, const char* header,
+                                        int64_t header_len, int64_t nrows, int32_t ntext,
+                                        const char* const* text_blob, const int64_t* const* text_off,
+                                        const int64_t* const* text_row, int32_t nnum,
+                                        const int32_t* kind, const void* const* cols,
+                                        const int64_t* num_row, int64_t threads) {
+  if (!path || !header || header_len < 0 || nrows < 0 || ntext < 0 || nnum < 0 || ntext + nnum < 1 ||
+      (ntext && (!text_blob || !text_off || !text_row)) || (nnum && (!kind || !cols)) ||
+      (nrows && nnum && !num_row))
+    return -2;
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return -1;
+  int64_t written = 0;
+  bool ok = std::fwrite(header, 1, (size_t)header_len, f) == (size_t)header_len;
+  written += header_len;
+  const int64_t kBlock = 4096;                        // rows per formatting task
+  const int64_t nblocks = (nrows + kBlock - 1) / kBlock;
+  const int nth = (int)std::max<int64_t>(1, threads > 0 ? threads : omp_get_max_threads());
+  const int64_t kWindow = (int64_t)nth * 4;           // blocks formatted before they are written out
+  std::vector<std::string> buf((size_t)std::min<int64_t>(kWindow, std::max<int64_t>(nblocks, 1)));
+  for (int64_t b0 = 0; b0 < nblocks && ok; b0 += kWindow) {
+    const int64_t b1 = std::min(nblocks, b0 + kWindow);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nth)
+    for (int64_t b = b0; b < b1; ++b) {
+      std::string& s = buf[(size_t)(b - b0)];
+      s.clear();
+      char tmp[40];
+      const int64_t r1 = std::min(nrows, (b + 1) * kBlock);
+      for (int64_t r = b * kBlock; r < r1; ++r) {
+        bool first = true;
+        for (int c = 0; c < ntext; ++c) {
+          if (!first) s.push_back(delimiter);
+          first = false;
+          const int64_t k = text_row[c][r];
+          const int64_t a = text_off[c][k], e = text_off[c][k + 1];
+          s.push_back('"');
+          s.append(text_blob[c] + a, (size_t)(e - a));
+          s.push_back('"');
+        }
+        const int64_t nr = nnum ? num_row[r] : 0;
+        for (int c = 0; c < nnum; ++c) {
+          if (!first) s.push_back(delimiter);
+          first = false;
+          const int n = kind[c] == 0 ? format_int(static_cast<const int64_t*>(cols[c])[nr], tmp)
+                                     : format_repr(static_cast<const double*>(cols[c])[nr], tmp);
+          s.push_back('"');
+          s.append(tmp, (size_t)n);
+          s.push_back('"');
+        }
+        s.push_back('\n');
+      }
+    }
+    for (int64_t b = b0; b < b1 && ok; ++b) {
+      const std::string& s = buf[(size_t)(b - b0)];
+      ok = std::fwrite(s.data(), 1, s.size(), f) == s.size();
+      written += (int64_t)s.size();
+    }
+  }
+  if (std::fclose(f) != 0) ok = false;
+  return ok ? written : -1;
 }

@@ -53,6 +53,80 @@ def vcf_convert(vcf_path, offset, out_path, types=None):
     return int(L.scoary_vcf_convert(os.fsencode(vcf_path), int(offset), os.fsencode(out_path), t))
 
 
+def format_float_repr(x):
+    """repr(float) as the native results writer prints it (scoary_format_float_repr)."""
+    L = _load()
+    L.scoary_format_float_repr.argtypes = [ctypes.c_double, ctypes.c_char_p]
+    L.scoary_format_float_repr.restype = ctypes.c_int32
+    buf = ctypes.create_string_buffer(40)
+    n = L.scoary_format_float_repr(float(x), buf)
+    return buf.raw[:n].decode()
+
+
+class TextColumn:
+    """A string table for scoary_results_write: the UTF-8 bytes of the strings back to back and
+    their offsets.  Built once per gene table column (or per --collapse name list)."""
+
+    def __init__(self, strings):
+        enc = [str(x).encode("utf-8") for x in strings]
+        self.blob = b"".join(enc)
+        self.off = np.zeros(len(enc) + 1, dtype=np.int64)
+        if enc:
+            np.cumsum(np.fromiter((len(e) for e in enc), dtype=np.int64, count=len(enc)), out=self.off[1:])
+
+    def __len__(self):
+        return len(self.off) - 1
+
+
+def results_write(path, delimiter, header_line, text_cols, text_rows, num_cols, num_row, threads=0):
+    """Write a results file natively (scoary_results_write, include/scoary_io.h).
+    text_cols: TextColumn per text column; text_rows: int64 array per text column (string index per
+    written row); num_cols: numpy arrays, integer dtypes printed as decimals, floats as repr(float);
+    num_row: int64 array, the index into the numeric columns per written row.  Returns bytes written."""
+    L = _load()
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    L.scoary_results_write.argtypes = [ctypes.c_char_p, ctypes.c_char, ctypes.c_char_p, i64, i64, i32, vp, vp, vp,
+                                       i32, vp, vp, vp, i64]
+    L.scoary_results_write.restype = i64
+    nrows = int(len(num_row))
+    keep = []                                          # arrays that must stay alive across the call
+
+    def as_i64(a):
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        keep.append(a)
+        return a.ctypes.data
+    ntext = len(text_cols)
+    blobs = (ctypes.c_char_p * max(ntext, 1))(*[c.blob for c in text_cols])
+    offs = (vp * max(ntext, 1))(*[as_i64(c.off) for c in text_cols])
+    trows = (vp * max(ntext, 1))(*[as_i64(r) for r in text_rows])
+    for c, r in zip(text_cols, text_rows):
+        if len(r) != nrows or (nrows and (np.min(r) < 0 or np.max(r) >= len(c))):
+            raise ValueError("results_write: text row index out of range")
+    kinds, ptrs = [], []
+    for col in num_cols:
+        col = np.asarray(col)
+        if nrows and (np.min(num_row) < 0 or np.max(num_row) >= len(col)):
+            raise ValueError("results_write: numeric row index out of range")
+        if np.issubdtype(col.dtype, np.integer) or col.dtype == np.bool_:
+            kinds.append(0)
+            ptrs.append(as_i64(col))
+        else:
+            kinds.append(1)
+            a = np.ascontiguousarray(col, dtype=np.float64)
+            keep.append(a)
+            ptrs.append(a.ctypes.data)
+    nnum = len(num_cols)
+    kind_arr = np.asarray(kinds or [0], dtype=np.int32)
+    col_arr = (vp * max(nnum, 1))(*ptrs)
+    hdr = header_line.encode("utf-8")
+    n = L.scoary_results_write(os.fsencode(path), delimiter.encode("utf-8"), hdr, len(hdr), nrows, ntext,
+                               ctypes.cast(blobs, vp), ctypes.cast(offs, vp), ctypes.cast(trows, vp), nnum,
+                               kind_arr.ctypes.data, ctypes.cast(col_arr, vp), as_i64(num_row), int(threads))
+    if n < 0:
+        raise OSError("scoary_results_write(%s) failed: %d" % (path, n))
+    return int(n)
+
+
 def upgma_merges(D):
     """The reference's UPGMA merge loop on an (n, n) float64 distance matrix whose
     diagonal is already 1 (scoary_upgma_merges): (n-1, 2) int32 merged index pairs."""

@@ -90,10 +90,13 @@ def test_bench_json_contract(extra):
     # ... and K1 as an HBM stream (round 5): a working set the Infinity Cache cannot hold, in rotation
     cold = k1["cold"]
     assert cold["hbm_peak_gbs"] == 8000.0 and cold["measured_copy_peak_gbs"] > 500
-    assert [run["traits"] for run in cold["runs"]] == [1, 4]
+    assert [run["traits"] for run in cold["runs"]] == [1, 2, 4, 8, 16, 32, 50]
+    assert [run["passes_over_matrix"] for run in cold["runs"]] == [1, 1, 1, 1, 1, 1, 2]
+    assert cold["runs"][0]["bound"] == "hbm" and cold["runs"][-1]["bound"] == "valu" and "T = " in cold["crossover"]
     for run in cold["runs"]:
         assert run["bytes"] == 8 * 157 * 125_000 + 16 * 157 * run["traits"] + 16 * 125_000 * run["traits"]
         assert 0 < run["hbm_frac"] < 1 and run["launches"] == 24 and run["cold_ms_median"] >= run["warm_ms_median"] * 0.8
+        assert 0 < run["frac_of_bound"] <= 1.05
         assert abs(run["gbs"] - run["bytes"] / run["cold_ms_median"] / 1e6) < 1e-6 * run["gbs"]
     assert "cache-resident" in k1["note"]
     # the label generator timed by itself (inside a step it shares the chip with k_fisher)

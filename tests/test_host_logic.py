@@ -228,6 +228,73 @@ def test_cell_formatting_is_shortest_roundtrip():
     assert _fmt(np.float64(1.0)) == "1.0"
 
 
+def test_native_float_cells_equal_python_repr():
+    """The native results writer prints float cells as Python's repr(float) (= str() of the
+    reference's numpy.float64 cells): checked value by value on random bit patterns,
+    the decades around the fixed / exponent switch (1e-4, 1e16), subnormals, and the specials."""
+    from scoary_amd import io_native
+    rng = np.random.default_rng(7)
+    vals = [0.0, -0.0, 1.0, 72.5, 1e-4, 9.999e-5, 1e-5, 1e15, 1e16, 9999999999999998.0, 1e17, 0.1, 1 / 3,
+            5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, float("inf"), float("-inf"), float("nan"),
+            100.0, 88.23529411764706, 1.0862106610751687e-14, 2.5700921296104394e-219, 1e22, 1e23,
+            9007199254740993.0, 0.30000000000000004, 6.45209132679e-11]
+    vals += list(rng.integers(0, 2**64, 20000, dtype=np.uint64).view(np.float64))
+    vals += list(rng.random(5000)) + list(rng.random(5000) ** 30) + list(np.round(rng.random(5000) * 100, 3))
+    vals += list(10.0 ** rng.integers(-320, 308, 3000)) + [float(i) for i in range(300)]
+    for v in vals:
+        assert io_native.format_float_repr(float(v)) == repr(float(v)), repr(float(v))
+
+
+@pytest.mark.parametrize("roary", [True, False])
+def test_native_results_writer_equals_the_python_writer(tmp_path, roary):
+    """StoreTraitResult's native row writer (scoary_results_write: string tables, index arrays and
+    numeric columns, formatted on all cores) against the general per-cell Python writer, byte for
+    byte: Roary identifiers and c0_|_c1_|_c2 identifiers, a filtered and re-ordered row selection,
+    inf / nan / 0.0 / tiny cells, with and without the pairwise columns; an empty selection writes
+    the header alone."""
+    from scoary_amd import methods as m
+    rng = np.random.default_rng(3)
+    G, N = 5000, 70
+    ids = ["gene_%d" % i for i in range(G)] if roary else ["chr%d_|_%d_|_id%d" % (i % 3, 1000 + i, i) for i in range(G)]
+    table = m.GeneTable(ids, ["nu%d" % (i % 7) if i % 5 else "" for i in range(G)],
+                        ['ann "%d", x' % i if i % 11 == 0 else "ann%d" % i for i in range(G)],
+                        ["s%d" % j for j in range(N)], rng.integers(0, 2**62, (G, 2), dtype=np.uint64), {})
+    rows_idx = np.sort(rng.choice(G, 4000, replace=False))
+    n = len(rows_idx)
+    odds = rng.random(n) * 50
+    odds[::17] = np.inf
+    odds[5::29] = np.nan
+    odds[3::31] = 0.0
+    cols = {"tpgp": rng.integers(0, 70, n).astype(np.int32), "tngp": rng.integers(0, 70, n).astype(np.int32),
+            "tpgn": rng.integers(0, 70, n).astype(np.int32), "tngn": rng.integers(0, 70, n).astype(np.int32),
+            "sens": np.round(rng.random(n) * 100, 2), "spes": rng.random(n) * 100, "OR": odds,
+            "p_v": rng.random(n) ** 40, "B_p": np.minimum(rng.random(n) ** 20 * 10, 1.0), "BH_p": rng.random(n),
+            "Empirical_p": (rng.integers(0, 1000, n) + 1.0) / 1001.0}
+    tr = m.TraitResults(None, None, None, cols, n, None, table=table, rows_idx=rows_idx)
+    fields = ["tpgp", "tngp", "tpgn", "tngn", "sens", "spes", "OR", "p_v", "B_p", "BH_p"]
+    header = '"a","b"\n'
+    for with_extra in (False, True):
+        sel_i = rng.permutation(n)[:2500]
+        sel_k = extra = None
+        f2 = fields + ["Empirical_p"]
+        if with_extra:
+            sel_k = np.arange(len(sel_i))[::-1].copy()
+            extra = {"max_total_pairs": rng.integers(0, 30, len(sel_i)), "max_propairs": rng.integers(0, 30, len(sel_i)),
+                     "max_antipairs": rng.integers(0, 30, len(sel_i)), "Pbest": rng.random(len(sel_i)) ** 9,
+                     "Pworst": rng.random(len(sel_i)), "Empirical_p": rng.random(len(sel_i))}
+            f2 = fields
+        a, b = str(tmp_path / "native.csv"), str(tmp_path / "python.csv")
+        assert m._write_rows_native(a, ",", header, tr, None, sel_i, sel_k, tr.cols, f2, extra, True, [])
+        m._write_rows_python(b, ",", header, tr, None, sel_i, sel_k, tr.cols, f2, extra, True, [])
+        assert open(a, "rb").read() == open(b, "rb").read()
+        assert open(a).read().count("\n") == 2501
+    assert m._write_rows_native(a, ";", header, tr, None, np.zeros(0, dtype=np.int64), None, tr.cols, fields, None,
+                                False, [])
+    assert open(a).read() == header
+    # --collapse units and grabbed input columns stay with the general writer
+    assert not m._write_rows_native(a, ",", header, tr, table, sel_i, None, tr.cols, fields, None, False, ["QC"])
+
+
 # -------------------------------------------------------------- vcf2scoary ---
 def test_vcf2scoary_matches_reference_output(exampledir, tmp_path):
     """tests/test_scoary_output.py:16-17,123-136 of the reference pins the first
@@ -464,9 +531,10 @@ def test_io_library_exports_every_declared_symbol():
     from scoary_amd import io_native
     with open(os.path.join(ROOT, "include", "scoary_io.h")) as f:
         src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(scoary_(?:gpa|lists|vcf|upgma)_[a-z_]+)\s*\(", src)))
+    names = sorted(set(re.findall(r"\b(scoary_(?:gpa|lists|vcf|upgma|results|format)_[a-z_]+)\s*\(", src)))
     lib = ctypes.CDLL(io_native.LIB_PATH)
-    assert len(names) == 19 and "scoary_vcf_convert" in names and "scoary_upgma_merges" in names
+    assert len(names) == 21 and "scoary_vcf_convert" in names and "scoary_upgma_merges" in names
+    assert "scoary_results_write" in names and "scoary_format_float_repr" in names
     for n in names:
         assert hasattr(lib, n), n
 

@@ -37,7 +37,11 @@ SHAPES = {   # G, N, T, P, gene kind: the BASELINE shapes, cfg4 / cfg5 with fewe
     "cfg3": (50_000, 2_000, 10, 10_000, "uniform"),
     "cfg4": (25_000, 5_000, 1, 10_000, "rare"),
     "cfg5": (7_500, 10_000, 50, 12_800, "uniform"),
+    # round 6: the segmented kernel (k_permute_seglists, N > 20479; 16-bit entries, ds_read_b64 of two-dword rows):
+    # `balanced` is balanced inside every isolate segment (each segment has its own sub-list)
+    "wide": (6_000, 50_000, 2, 1_024, "uniform"),
 }
+SEG_ROWS = 20352                                               # kSegRows (scoary_common.hpp)
 
 
 def gene_sets(G, N, C, kind, rng):
@@ -49,14 +53,16 @@ def gene_sets(G, N, C, kind, rng):
     L = np.minimum(L, (N // C) * C // 2 // C * C)
     rnd = np.zeros((G, N), dtype=np.uint8)
     bal = np.zeros((G, N), dtype=np.uint8)
-    per_class = [np.arange(c, N, C) for c in range(C)]
+    segs = [(a, min(N, a + SEG_ROWS)) for a in range(0, N, SEG_ROWS)] if N > 20479 else [(0, N)]
+    per_class = [[np.arange(a + (c - a) % C, b, C) for c in range(C)] for a, b in segs]
     for g in range(G):
         if L[g] == 0:
             continue
         rnd[g, rng.choice(N, size=L[g], replace=False)] = 1
-        k = L[g] // C
-        for c in range(C):
-            bal[g, rng.choice(per_class[c], size=k, replace=False)] = 1
+        for (a, b), pcs in zip(segs, per_class):
+            k = int(L[g] * (b - a) / N) // C                   # the same count in every class of the segment
+            for c in range(C):
+                bal[g, rng.choice(pcs[c], size=min(k, len(pcs[c])), replace=False)] = 1
     inv = flip[:, None].astype(np.uint8)                       # keep which value is the minority
     return rnd ^ inv, bal ^ inv
 
@@ -104,8 +110,9 @@ def main():
         trv, mkv = eng.vecrows(tb, N), eng.vecrows(mb, N)
         out = {}
         ref_r = None
+        k3 = eng.list_kernel_name(N)
         for variant, genes in (("random", rnd), ("balanced", bal), ("shuffled", rnd)):
-            if args.variant not in ("all", variant):
+            if args.variant not in ("all", variant) or (variant == "shuffled" and k3 != "k_permute_lists"):
                 continue
             gm = eng.pack_dense(genes)
             eng.build_lists(gm)
@@ -121,15 +128,15 @@ def main():
             for _ in range(args.steps):
                 eng.associate(gm, trv, mkv, permutations=P, seed=3, use_lists=True, workspace=ws)
             torch.cuda.synchronize()
-            ms = [eng.kernel_ms("k_permute_lists")]              # mean over the timed launches
+            ms = [eng.kernel_ms(k3)]                             # mean over the timed launches
             eng.set_timing(False)
             if variant == "random":
                 ref_r = ws.r.clone()
             elif variant == "shuffled" and ref_r is not None:      # the order never changes the counts
                 assert torch.equal(ref_r, ws.r), "shuffled lists changed r"
             out[variant] = sorted(ms)[len(ms) // 2]
-            print("%-5s %-9s G=%d N=%d T=%d P=%d C=%d entries=%d  k_permute_lists %.3f ms (mean of %d back-to-back steps)"
-                  % (name, variant, G, N, T, P, C, gm.lists.entries, out[variant], args.steps), flush=True)
+            print("%-5s %-9s G=%d N=%d T=%d P=%d C=%d entries=%d  %s %.3f ms (mean of %d back-to-back steps)"
+                  % (name, variant, G, N, T, P, C, gm.lists.entries, k3, out[variant], args.steps), flush=True)
             del ws, gm
         if "random" in out and "balanced" in out:
             print("%-5s remaining conflicts (hole fillers) cost %.2f %% of the kernel time" %

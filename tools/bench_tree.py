@@ -85,6 +85,30 @@ def main():
     dt = time.perf_counter() - t0
     out["oracle_tree_evaluations_per_s_1core"] = Ps / dt
     out["oracle_agrees"] = bool(np.array_equal(exo, ex[0, :Ps]) and tuple(obs[0]) == o)
+    # roofline objects (round 6).  Both kernels are integer-VALU work, as K1 / K3 are:
+    #   k_hamming: the K1 family -- 2 lane-ops (XOR, popcount-accumulate) per 32-bit word and isolate PAIR;
+    #     ceiling = the measured rate of that op pair (tools/valu_peak.hip: 4.1e13 lane-ops/s), and the
+    #     algorithmic bytes (bit matrix once + N^2 counts) against 8 TB/s;
+    #   k_tree_dp: lane = one (gene, permutation) tree evaluation, tips - 1 node merges of ~80 VALU ops
+    #     (two packed integer keys per state: adds and v_max); ceiling = the nominal SIMD peak, 78.6 T lane-ops/s.
+    # SQ_INSTS_VALU x 64 from the committed PMC pass (tools/round6_run.sh tree) replaces the op estimates.
+    W32 = (args.all_genes + 31) // 32
+    ham_ops = 2.0 * N * N * W32
+    ham_bytes = N * W32 * 4.0 + 4.0 * N * N
+    out["roofline_k_hamming"] = {
+        "bound": "valu (XOR + popcount-accumulate)", "lane_ops": ham_ops,
+        "achieved_lane_ops_per_s": ham_ops / (out["k_hamming_ms"] * 1e-3), "peak_lane_ops_per_s": 4.1e13,
+        "frac": ham_ops / (out["k_hamming_ms"] * 1e-3) / 4.1e13,
+        "frac_of_nominal_simd_peak": ham_ops / (out["k_hamming_ms"] * 1e-3) / (256 * 4 * 32 * 2.4e9),
+        "bytes": ham_bytes, "gbs": ham_bytes / (out["k_hamming_ms"] * 1e-3) / 1e9,
+        "hbm_frac": ham_bytes / (out["k_hamming_ms"] * 1e-3) / 1e9 / 8000.0}
+    merges = float(evals) * (N - 1)
+    out["roofline_k_tree_dp"] = {
+        "bound": "valu (node merges: integer add / max on packed keys)", "merges": merges,
+        "merges_per_s": merges / (out["k_tree_dp_ms"] * 1e-3),
+        "ops_per_merge_estimate": 80, "achieved_lane_ops_per_s_estimate": 80 * merges / (out["k_tree_dp_ms"] * 1e-3),
+        "peak_lane_ops_per_s": 256 * 4 * 32 * 2.4e9,
+        "frac_estimate": 80 * merges / (out["k_tree_dp_ms"] * 1e-3) / (256 * 4 * 32 * 2.4e9)}
     print(json.dumps(out))
 
 

@@ -11,7 +11,8 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # no sustained window, no telemetry thread: under the profiler they only add thousands of kernel records
-BENCH="python $REPO/bench.py --no-cpu-baseline --sustain-seconds 0 --telemetry-ms 0 $*"
+# ... and no K1 sweep / strong-scaling extras: they launch the same kernels on OTHER shapes, whose counters would be averaged in
+BENCH="python $REPO/bench.py --no-cpu-baseline --sustain-seconds 0 --telemetry-ms 0 --no-k1-cold --strong-extra off $*"
 # the kernel sources these counters belong to (bench.py refuses a summary whose hash differs)
 python -c "import sys; sys.path.insert(0, '$REPO'); import bench; print(bench.kernel_source_sha())" > "$OUT/kernel_source_sha256.txt"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1

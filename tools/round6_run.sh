@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box sessions collecting the round-6 evidence (outputs under gpurun_out/r06/).
-#   tools/round6_run.sh [part ...]     parts: tests bench balance rank8 e2e
+#   tools/round6_run.sh [part ...]     parts: tests bench balance rank8 e2e k1 xcd tree cfg5cli seg profiles
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r06
 mkdir -p $O
@@ -41,6 +41,58 @@ if has e2e; then
 python tools/e2e_vcf.py > $O/e2e_cli_cfg4_vcf.txt 2>&1
 python tools/e2e_synth.py --genes 50000 --isolates 2000 --traits 10 --permute 10000 > $O/e2e_cli_cfg3.txt 2>&1
 tail -25 $O/e2e_cli_cfg4_vcf.txt; tail -20 $O/e2e_cli_cfg3.txt
+fi
+if has k1; then
+# K1 as an HBM stream, T = 1 ... 50 (roofline_k1.cold), the round-5 kernel (_ab/r5.so: tools/build_alt.sh r5 <rev>) against
+# the double-buffered one, interleaved on one box
+for i in 1 2; do
+  for v in r5 new; do
+    lib=""; [ $v = r5 ] && lib="$PWD/_ab/r5.so"
+    SCOARY_HIP_LIB=$lib python bench.py --no-cpu-baseline --sustain-seconds 0 --strong-extra off --steps 5 --warmup 2 2>/dev/null \
+      | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); c = d['roofline_k1']['cold']
+print('$v pass $i: copy %.0f GB/s | ' % c['measured_copy_peak_gbs'] + ' | '.join('T=%d %.1f us %.2f TB/s (%.3f of 8, %s %.2f)' % (r['traits'], r['cold_ms_median'] * 1e3, r['gbs'] / 1e3, r['hbm_frac'], r.get('bound', '-'), r.get('frac_of_bound', 0)) for r in c['runs']))
+json.dump(c, open('$O/k1_stream_${v}_$i.json', 'w'))"
+  done
+done
+fi
+if has xcd; then
+bash tools/ab_xcd_map.sh > $O/ab_xcd_map_cfg5.txt 2>&1
+cat $O/ab_xcd_map_cfg5.txt
+fi
+if has tree; then
+for n in 2000 5000 10000; do
+  python tools/bench_tree.py --isolates $n > $O/bench_tree_$n.json 2> $O/bench_tree_$n.err
+  tail -c 1200 $O/bench_tree_$n.json; echo
+done
+( cd /tmp
+  rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/prof_tree/stats -o stats -- python $OLDPWD/tools/bench_tree.py --isolates 5000 > $OLDPWD/$O/prof_tree_stats.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OLDPWD/$O/prof_tree/pmc_sq -o sq -- python $OLDPWD/tools/bench_tree.py --isolates 5000 > $OLDPWD/$O/prof_tree_pmc.log 2>&1 )
+python tools/rocpd_summary.py $O/prof_tree profiles/r06_tree5000 tree5000 > $O/prof_tree_summary.log 2>&1
+find $O/prof_tree -type f ! -name '*.db' -delete; find $O/prof_tree -name '*.db' -size +20M -delete
+# default mode (pairwise-comparison tree stage) end to end on the cfg3-sized table
+python tools/e2e_synth.py --pairwise --genes 50000 --isolates 2000 --traits 10 --permute 1000 > $O/e2e_cli_cfg3_pairwise.txt 2>&1
+tail -30 $O/e2e_cli_cfg3_pairwise.txt
+fi
+if has cfg5cli; then
+python tools/e2e_cfg5_shard.py > $O/e2e_cli_cfg5_shard.txt 2>&1
+cat $O/e2e_cli_cfg5_shard.txt
+fi
+if has seg; then
+python tools/ab_conflicts.py --shapes wide > $O/ab_seg_conflicts.txt 2>&1
+cat $O/ab_seg_conflicts.txt
+for p in 1024 4096; do
+python bench.py --genes 20000 --isolates 50000 --traits 2 --permutations $p --no-cpu-baseline --strong-extra off > $O/bench_wide_50000_P$p.json 2>/dev/null
+done
+fi
+if has profiles; then
+bash tools/profile_configs.sh r06 cfg3 cfg4 cfg2 > $O/profile_configs.log 2>&1
+bash tools/profile_configs.sh r06 cfg5 > $O/profile_cfg5.log 2>&1
+bash tools/profile.sh r06_wide --genes 20000 --isolates 50000 --traits 2 --permutations 1024 > $O/profile_wide.log 2>&1
+python tools/rocpd_summary.py gpurun_out/prof_r06_wide profiles/r06_wide50000 wide50000 >> $O/profile_wide.log 2>&1
+find gpurun_out/prof_r06_wide gpurun_out/prof_r06* -type f ! -name '*.db' ! -name '*.txt' ! -name '*.log' -delete 2>/dev/null
+mkdir -p gpurun_out/profiles_r06; cp profiles/r06_* gpurun_out/profiles_r06/ 2>/dev/null
 fi
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json, sys
