@@ -18,7 +18,7 @@ fi
 if has balance; then
 python tools/shard_balance.py --config cfg3 --gene-order sorted > $O/shard_balance_cfg3_sorted.txt 2>&1
 python tools/shard_balance.py --config cfg3 --gene-order config > $O/shard_balance_cfg3_config_order.txt 2>&1
-python tools/shard_balance.py --exampledata tests/golden/exampledata/Gene_presence_absence.csv > $O/shard_balance_exampledata.txt 2>&1
+python tools/shard_balance.py --exampledata tests/golden/exampledata/Gene_presence_absence.csv.gz > $O/shard_balance_exampledata.txt 2>&1
 grep -h "^#\|max / mean\|partition\|=>" $O/shard_balance_*.txt
 # the 8-rank shared-GPU rehearsal on frequency-sorted genes, both partitions (functional + per_rank lines)
 for part in stride contiguous; do

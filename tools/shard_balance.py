@@ -36,7 +36,16 @@ def main():
     eng = AssociationEngine(0)
     if args.exampledata:
         from scoary_amd import methods as m
-        with open(args.exampledata, "r", newline=None) as f:
+        path = args.exampledata
+        if path.endswith(".gz"):                                  # the committed fixture (tests/golden/exampledata)
+            import gzip
+            import tempfile
+            tmp = tempfile.NamedTemporaryFile("w", suffix=".csv", delete=False, newline="")
+            with gzip.open(path, "rt", newline="") as f:
+                tmp.write(f.read())
+            tmp.close()
+            path = tmp.name
+        with open(path, "r", newline=None) as f:
             table = m.Csv_to_dic_Roary(f, ",", [], startcol=14)["Roarydic"]
         N = len(table.strains)
         base = np.unpackbits(table.rows64.view(np.uint8), axis=1, bitorder="little")[:, :N].copy()
