@@ -486,8 +486,12 @@ class Exchange:
             rec = sdist.pack_records(res["counts"], res["p"], res["odds"], res["r"])
         if self.kind == "gather":
             try:
+                # the blocks stay as they arrive ([rank][T][cap][10], GenePartition's layout): gene order
+                # is the READER's indexing (GenePartition.weave -- --verify-gather applies it to compare
+                # with a one-GPU run; the command line applies it once, on the host), as the reference
+                # weaves its workers' lists when it writes the results (scoary/methods.py:1115-1122)
                 _, finish = sdist.gather_genes(rec, self.total, dst=0, async_op=True,
-                                               recv=self.recv[self.step_no % 2], partition=self.part)
+                                               recv=self.recv[self.step_no % 2], partition=self.part, weave=False)
                 self.pending.append(finish)
             except (RuntimeError, NotImplementedError) as e:   # backend without gather
                 if self.rank == 0:

@@ -240,22 +240,15 @@ __global__ __launch_bounds__(1024) void k_counts(const uint4* __restrict__ tiled
     }
   };
   // U gene quads are requested before any of them is used: with few traits per pass there is
-  // little arithmetic per load and the stream lives on loads in flight (cfg4: T = 1).  Round 6: the
-  // NEXT U quads are requested before the current ones are used (double buffer), so a wavefront's
-  // arithmetic runs under its own loads as well -- with 4 traits the AND + popcount work of a pass
-  // (9.5 us at cfg5's shard shape) came on top of the 31 us stream instead of under it.
+  // little arithmetic per load and the stream lives on loads in flight (cfg4: T = 1)
   constexpr int U = TB <= 4 ? 4 : (TB <= 16 ? 2 : 1);
-  auto load_quads = [&](int q0, uint4 (&dst)[U]) {
+  for (int q0 = wave; q0 < Qp; q0 += nw * U) {
+    uint4 gws[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int q = q0 + nw * u;                          // wave-uniform
-      dst[u] = q < Qp ? tiled[(int64_t)q * Gp + g] : make_uint4(0u, 0u, 0u, 0u);
+      gws[u] = q < Qp ? tiled[(int64_t)q * Gp + g] : make_uint4(0u, 0u, 0u, 0u);
     }
-  };
-  uint4 gws[U], gnx[U];
-  load_quads(wave, gws);
-  for (int q0 = wave; q0 < Qp; q0 += nw * U) {
-    if (q0 + nw * U < Qp) load_quads(q0 + nw * U, gnx);   // wave-uniform
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int q = min(q0 + nw * u, Qp - 1);             // past the end: a zero gene quad adds nothing
@@ -279,8 +272,6 @@ __global__ __launch_bounds__(1024) void k_counts(const uint4* __restrict__ tiled
         }
       }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) gws[u] = gnx[u];
   }
 #pragma unroll
   for (int j = 0; j < TB; ++j) {                          // the quad slices of a gene meet in LDS

@@ -259,49 +259,31 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
                                                         const uint2* __restrict__ lcrit, int G,
                                                         int N, int64_t P, int ntiles,
                                                         int groups_per_block, int64_t lidx_bytes,
-                                                        uint16_t* __restrict__ partial, int npairs,
-                                                        int nchunks) {
+                                                        uint16_t* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) uint32_t tile_lds[];
   scoary_bank_defs();                // assembler symbols for the operand-ordering .if blocks
   constexpr int TW = NW * LPG;       // tile row, dwords
-  // Block -> ((trait, tile) pair, chunk of wave groups).  Two-dimensional grid (npairs == 0): pair =
-  // blockIdx.x runs fastest, chunk = blockIdx.y.  XCD-aware one-dimensional grid (npairs > 0, round 6,
-  // the one-lane-per-gene geometry): workgroups are dealt to the eight XCDs round-robin in launch
-  // order, so block b runs on XCD b % 8; XCD j takes one chunk of every row of eight -- in snake order,
-  // j, 15 - j, 16 + j, ...: the lists are sorted by length, a fixed column would give XCD 0 the longest
-  // chunk of every row -- and, inside a chunk, the pairs in order: every chunk of index lists is then
-  // fetched into ONE L2 instead of eight.
-  int bx, by;
-  if (npairs == 0) {
-    bx = blockIdx.x, by = blockIdx.y;
-  } else {
-    const int j = blockIdx.x & 7, m = blockIdx.x >> 3;
-    bx = m % npairs;
-    const int row = m / npairs;
-    by = 8 * row + ((row & 1) ? 7 - j : j);
-    if (by >= nchunks) return;       // the grid is padded to eight equal shares
-  }
   static_assert(NW == 4 || ((NW == 2 || NW == 1) && LPG == 1), "narrow rows: one lane per gene");
   constexpr int GPW = kWave / LPG;   // genes per wavefront
   // A block = one label tile (trait, 32*TW permutations) in LDS x one chunk of wave groups.
-  // the pair (trait, tile) runs fastest, so the ~num_cu blocks in flight walk the SAME
+  // blockIdx.x (trait, tile) runs fastest, so the ~num_cu blocks in flight walk the SAME
   // chunk of index lists against different tiles: a list byte comes from HBM once and
   // from L2 for everyone else.  (Round 2 built the alternative -- a block walking several
   // tiles and keeping its counts in a register, one store per (gene, trait): the lists are
   // then re-streamed once per tile by blocks that no longer share them, -4 % at the
   // headline config and -15 % on rare variants; profiles/r02_ab_tileloop.txt.)
-  const int t = bx / ntiles, tile = bx % ntiles;
+  const int t = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: loops over groups stay scalar
   const int col = lane % LPG;
   const int ngroups = (G + GPW - 1) / GPW;         // wave groups of GPW genes
-  const int q_lo = by * groups_per_block;
+  const int q_lo = blockIdx.y * groups_per_block;
   const int q_hi = min(ngroups, q_lo + groups_per_block);
   const uint32_t lane_off = (uint32_t)lane * 16u;   // 16-byte vectors: tile loads and index loads
   // per-(trait, tile) exceedance counts of every list slot: plain 16-bit stores, summed
   // over the tiles by k_lists_reduce (one device-scope atomicAdd per (gene, tile) cost a
   // 32-byte memory-side write each: 316 MB for a 2 MB result at the headline config)
-  uint16_t* out = partial + (int64_t)bx * ((int64_t)ngroups * GPW);
+  uint16_t* out = partial + (int64_t)blockIdx.x * ((int64_t)ngroups * GPW);
 
   // interleaved lists (piece = TW entries): the wavefront's 64 lanes read 64 consecutive
   // 16-byte index vectors per piece; lane l reads vector piece*64 + l of its group
@@ -338,7 +320,7 @@ __global__ __launch_bounds__(1024) void k_permute_lists(const uint32_t* __restri
   int q = q_lo + wave;
   Group cur = open_group(min(q, ngroups - 1));
   Ent ring[4] = {load_from(cur, 0), load_from(cur, 1), load_from(cur, 2), load_from(cur, 3)};
-  const uint32_t* src = tiles + (int64_t)bx * list_tile_dwords(N, TW);
+  const uint32_t* src = tiles + (int64_t)blockIdx.x * list_tile_dwords(N, TW);
   {
     // tile -> LDS by LDS-DMA (global_load_lds_dwordx4): a wavefront moves 64 x 16 B
     // per instruction straight into LDS (destination = M0 + 16*lane), no VGPR round trip
@@ -590,15 +572,6 @@ static int64_t list_chunk_bytes(int TW) {
 struct ListGeom {
   int64_t ntiles, ngroups, gs, gpb, chunks;
 };
-// SCOARY_LIST_XCD_MAP=1: the XCD-aware block map of k_permute_lists for the one-lane-per-gene
-// geometry (TW <= 4) when the launch has at least 16 chunks (same-box A/B, tools/ab_xcd_map.sh)
-static bool list_xcd_map(int TW, int64_t chunks) {
-  static const int env = [] {
-    const char* e = std::getenv("SCOARY_LIST_XCD_MAP");
-    return e ? std::atoi(e) : 0;
-  }();
-  return env == 1 && TW <= 4 && chunks >= 16;
-}
 static ListGeom list_geom(int num_cu, int64_t G, int64_t T, int64_t N, int64_t P, int64_t entries) {
   ListGeom g{};
   const int TW = list_tw(N), GPW = kWave / list_lpg(TW);
@@ -656,15 +629,11 @@ static int launch_permute_lists(scoary_handle h, hipStream_t s, const uint32_t* 
   }
   {
     KernelTimer kt(h, s, "k_permute_lists");
-    const int64_t npairs = T * g.ntiles;
-    const bool xcd = list_xcd_map(TW, g.chunks) && 8 * npairs * ((g.chunks + 7) / 8) <= 0x7fffffffLL;
-    const dim3 grid = xcd ? dim3((unsigned)(8 * npairs * ((g.chunks + 7) / 8)))
-                          : dim3((unsigned)npairs, (unsigned)g.chunks);
-    hipLaunchKernelGGL((k_permute_lists<list_lpg(TW), list_nw(TW), KC>), grid, dim3(1024), lds, s, d_tiles,
+    hipLaunchKernelGGL((k_permute_lists<list_lpg(TW), list_nw(TW), KC>),
+                       dim3((unsigned)(T * g.ntiles), (unsigned)g.chunks), dim3(1024), lds, s, d_tiles,
                        d_lidx, d_lstart, d_lngroups, reinterpret_cast<const uint2*>(d_lcrit), (int)G,
                        (int)N, P, (int)g.ntiles, (int)g.gpb,
-                       (entries + kListSlack) * (int64_t)sizeof(uint32_t), d_partial,
-                       xcd ? (int)npairs : 0, (int)g.chunks);
+                       (entries + kListSlack) * (int64_t)sizeof(uint32_t), d_partial);
   }
   {
     KernelTimer kt(h, s, "k_lists_reduce");

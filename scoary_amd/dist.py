@@ -192,11 +192,14 @@ def all_gather_genes(rec_local, G, group=None, partition=None):
     return part.weave(recv.view(world, T, cap, W))
 
 
-def gather_genes(rec_local, G, dst=0, group=None, async_op=False, recv=None, partition=None):
+def gather_genes(rec_local, G, dst=0, group=None, async_op=False, recv=None, partition=None, weave=True):
     """The path's one exchange step as a true gather: every rank sends its
     [T, Gs, W] block to ``dst`` only (1/world of an all_gather's traffic; over
     xGMI each sender uses its own link to dst).  Returns (work, finish) where
-    finish() -> the full [T, G, W] tensor in gene order on dst, None elsewhere."""
+    finish() -> the full [T, G, W] tensor in gene order on dst, None elsewhere.
+    ``weave=False``: finish() returns the gathered blocks [world, T, cap, W] as they arrived
+    (shard r in block r, GenePartition's layout) and the reader applies ``partition.weave``
+    when -- and if -- it wants gene order."""
     torch = _torch()
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -220,7 +223,7 @@ def gather_genes(rec_local, G, dst=0, group=None, async_op=False, recv=None, par
             work.wait()
         if rank != dst:
             return None
-        return part.weave(recv)
+        return part.weave(recv) if weave else recv
     return work, finish
 
 

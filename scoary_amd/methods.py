@@ -789,7 +789,8 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
     with _stage("results D2H"):
         # the stable p order for BH: numpy does 200 000 doubles in 25-40 ms, which beats the
         # first-use cost of torch's sort kernels in a fresh process (0.2-0.4 s of lazy code loading,
-        # profiles/r05_e2e_cli_*); from a few million (gene, trait) pairs on the device sort wins
+        # profiles/r05_e2e_cli_*); the traits' sorts also run on worker threads (Setup_results), so
+        # the device sort only wins from tens of millions of (gene, trait) pairs on
         p_order = _p_order_on_device(rec) if T * G >= DEVICE_SORT_MIN_PAIRS else None
         out = dist.numpy_records(rec)
         out["p_order"] = p_order
@@ -798,7 +799,8 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
     return out
 
 
-DEVICE_SORT_MIN_PAIRS = 4_000_000
+DEVICE_SORT_MIN_PAIRS = 32_000_000
+HOST_THREADS_MIN_PAIRS = 200_000        # (gene, trait) pairs from which the per-trait statistics use worker threads
 
 
 def _p_order_on_device(rec):
@@ -957,7 +959,7 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
     # interpreter lock: one worker thread per trait, as many as the process may use (50 traits x
     # 125 000 genes: 1.5 s one after the other)
     nthreads = min(len(names), _usable_cpus())
-    if nthreads > 1 and G * len(names) >= 200_000:
+    if nthreads > 1 and G * len(names) >= HOST_THREADS_MIN_PAIRS:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=nthreads) as pool:
             done = list(pool.map(one_trait, range(len(names))))      # in trait order; the first error is re-raised

@@ -201,6 +201,14 @@ def _gather_worker(rank, world, port, outq):
             _, finish = sd.gather_genes(full[:, part.index(rank)].contiguous(), G, dst=0, async_op=async_op,
                                         partition=part)
             outs.append(finish())
+    # weave=False: the blocks as they arrived; the reader weaves them (what bench.py's Exchange does)
+    part = sd.GenePartition(G, world)
+    _, finish = sd.gather_genes(full[:, part.index(rank)].contiguous(), G, dst=0, partition=part, weave=False)
+    raw = finish()
+    if rank == 0:
+        assert tuple(raw.shape) == (world, T, part.cap, sd.REC_WORDS) and torch.equal(part.weave(raw), full)
+    else:
+        assert raw is None
     outq.put((rank, [None if o is None else o.numpy() for o in outs]))
     dist.barrier()
     dist.destroy_process_group()

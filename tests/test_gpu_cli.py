@@ -506,6 +506,25 @@ def test_p_order_from_the_device_equals_numpy(exampledir, monkeypatch, collapse)
             assert np.array_equal(dev[trait].p_order, host[trait].p_order)
 
 
+@pytest.mark.parametrize("collapse", [False, True])
+def test_per_trait_statistics_on_worker_threads_equal_the_loop(exampledir, monkeypatch, collapse):
+    """Round 6: the per-trait host statistics (skip rule, B / BH, columns; scoary/methods.py:781-925)
+    of a large run go through a thread pool, one trait per worker.  Forced on for the example data:
+    the same rows, columns and p order as the plain loop, in trait order."""
+    from scoary_amd import methods as m
+    gd, td = _load(exampledir)
+    monkeypatch.setattr(m, "HOST_THREADS_MIN_PAIRS", 1 << 60)
+    loop = m.Setup_results(gd["Roarydic"], td, collapse)["Results"]
+    monkeypatch.setattr(m, "HOST_THREADS_MIN_PAIRS", 0)
+    monkeypatch.setattr(m, "_usable_cpus", lambda: 4)
+    pool = m.Setup_results(gd["Roarydic"], td, collapse)["Results"]
+    assert list(pool) == list(loop)
+    for trait in loop:
+        assert list(pool[trait]) == list(loop[trait]) and pool[trait].number_of_tests == loop[trait].number_of_tests
+        for k in ("p_v", "B_p", "BH_p", "tpgp", "tngn", "sens", "spes", "OR"):
+            assert np.array_equal(pool[trait].column(k), loop[trait].column(k), equal_nan=True), (trait, k)
+
+
 def test_cli_vcf_pipeline_every_row_vs_oracle(tmp_path):
     """BASELINE configs[3] as it is literally defined -- "VCF-derived" -- at 20 000 sites x 1000
     isolates: a synthetic haploid VCF (rare variants, ~3 % multi-allelic sites, a few missing

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box sessions collecting the round-6 evidence (outputs under gpurun_out/r06/).
-#   tools/round6_run.sh [part ...]     parts: tests bench balance rank8 e2e k1 xcd tree cfg5cli seg profiles
+#   tools/round6_run.sh [part ...]     parts: tests bench balance rank8 e2e k1 xcd tree treepmc pairwise cfg5cli seg profiles
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r06
 mkdir -p $O
@@ -66,11 +66,15 @@ for n in 2000 5000 10000; do
   python tools/bench_tree.py --isolates $n > $O/bench_tree_$n.json 2> $O/bench_tree_$n.err
   tail -c 1200 $O/bench_tree_$n.json; echo
 done
+fi
+if has treepmc; then
 ( cd /tmp
   rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/prof_tree/stats -o stats -- python $OLDPWD/tools/bench_tree.py --isolates 5000 > $OLDPWD/$O/prof_tree_stats.log 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OLDPWD/$O/prof_tree/pmc_sq -o sq -- python $OLDPWD/tools/bench_tree.py --isolates 5000 > $OLDPWD/$O/prof_tree_pmc.log 2>&1 )
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-include-regex "k_hamming|k_tree_dp" -d $OLDPWD/$O/prof_tree/pmc_sq -o sq -- python $OLDPWD/tools/bench_tree.py --isolates 5000 --kernels-only > $OLDPWD/$O/prof_tree_pmc.log 2>&1 )
 python tools/rocpd_summary.py $O/prof_tree profiles/r06_tree5000 tree5000 > $O/prof_tree_summary.log 2>&1
 find $O/prof_tree -type f ! -name '*.db' -delete; find $O/prof_tree -name '*.db' -size +20M -delete
+fi
+if has pairwise; then
 # default mode (pairwise-comparison tree stage) end to end on the cfg3-sized table
 python tools/e2e_synth.py --pairwise --genes 50000 --isolates 2000 --traits 10 --permute 1000 > $O/e2e_cli_cfg3_pairwise.txt 2>&1
 tail -30 $O/e2e_cli_cfg3_pairwise.txt
