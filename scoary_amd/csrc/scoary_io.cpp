@@ -934,7 +934,10 @@ extern "C" int64_t scoary_results_write(const char* path, char delimiter, const 
   written += header_len;
   const int64_t kBlock = 4096;                        // rows per formatting task
   const int64_t nblocks = (nrows + kBlock - 1) / kBlock;
-  const int nth = (int)std::max<int64_t>(1, threads > 0 ? threads : omp_get_max_threads());
+  // never more threads than blocks of rows: a 6 000-row file is two blocks, and a team of
+  // omp_get_max_threads() (the HOST's CPU count inside a container granted 16) only spins
+  const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(threads > 0 ? threads : omp_get_max_threads(),
+                                                              std::max<int64_t>(nblocks, 1)));
   const int64_t kWindow = (int64_t)nth * 4;           // blocks formatted before they are written out
   std::vector<std::string> buf((size_t)std::min<int64_t>(kWindow, std::max<int64_t>(nblocks, 1)));
   for (int64_t b0 = 0; b0 < nblocks && ok; b0 += kWindow) {

@@ -1075,13 +1075,35 @@ CUT_FIELD = {"I": "p_v", "B": "B_p", "BH": "BH_p", "PW": "Plowest", "EPW": "Pbot
 def StoreResults(Results, max_hits, cutoffs, upgmatree, GTC, Prunedic, outdir, permutations,
                  num_threads, no_pairwise, genedic, extracolstoprint, firstcolnames, time="",
                  delimiter=",", seed=DEFAULT_SEED):
-    for Trait in Results:
+    def one(Trait, writer_threads=0):
+        StoreTraitResult(Results[Trait], Trait, max_hits, cutoffs, upgmatree, GTC, Prunedic,
+                         outdir, permutations, num_threads, no_pairwise, genedic,
+                         extracolstoprint, firstcolnames, time, delimiter, seed=seed,
+                         writer_threads=writer_threads)
+    traits = list(Results)
+    pairs = sum(len(Results[t]) for t in traits)
+    nthreads = min(len(traits), _usable_cpus())
+    if no_pairwise and nthreads > 1 and pairs >= HOST_THREADS_MIN_PAIRS:
+        # --no_pairwise: a trait's file is sorting, filtering and formatting its own columns (numpy and
+        # the native writer, both outside the interpreter lock) -- one worker thread per trait.  The
+        # pairwise stage keeps the loop: it drives the GPU and logs its progress trait by trait.
+        for Trait in traits:
+            sys.stdout.write("\n")
+            log.info("Storing results: " + Trait)
+        from concurrent.futures import ThreadPoolExecutor
+        with _stage("result files (sort, filter, pairwise stage, write)"):
+            for Trait in traits:                     # the gene table's string columns: once, before the workers
+                tr = Results[Trait]
+                if isinstance(tr, TraitResults) and tr._table is not None:
+                    _csv_text_columns(tr._table)
+            with ThreadPoolExecutor(max_workers=nthreads) as pool:
+                list(pool.map(lambda t: one(t, writer_threads=1), traits))   # the files are the parallel axis
+        return
+    for Trait in traits:
         sys.stdout.write("\n")
         log.info("Storing results: " + Trait)
         with _stage("result files (sort, filter, pairwise stage, write)"):
-            StoreTraitResult(Results[Trait], Trait, max_hits, cutoffs, upgmatree, GTC, Prunedic,
-                             outdir, permutations, num_threads, no_pairwise, genedic,
-                             extracolstoprint, firstcolnames, time, delimiter, seed=seed)
+            one(Trait)
 
 
 def decideifbreak(cutoffs, currentgene):
@@ -1194,7 +1216,7 @@ def _csv_text_columns(table):
 
 
 def _write_rows_native(fname, delimiter, header_line, Trait, table, sel_i, sel_k, colget, fields, extra, with_emp,
-                       extracolstoprint):
+                       extracolstoprint, threads=0):
     """The rows of one results file through the native writer (scoary_results_write: string tables +
     index arrays + numeric columns, formatted by all cores) -- a -p 1.0 run of 50 traits x 125 000
     genes writes six million rows, 15-30 us each through the per-cell Python loop.  Returns False
@@ -1221,7 +1243,7 @@ def _write_rows_native(fname, delimiter, header_line, Trait, table, sel_i, sel_k
     if extracolstoprint:
         return False
     io_native.results_write(fname, delimiter, header_line, text_cols, text_rows, num,
-                            np.arange(len(sel_i), dtype=np.int64))
+                            np.arange(len(sel_i), dtype=np.int64), threads=threads or _usable_cpus())
     return True
 
 
@@ -1258,7 +1280,7 @@ def _write_rows_python(fname, delimiter, header_line, Trait, table, sel_i, sel_k
 
 def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Prunedic, outdir,
                      permutations, num_threads, no_pairwise, genedic, extracolstoprint,
-                     firstcolnames, time="", delimiter=",", seed=DEFAULT_SEED):
+                     firstcolnames, time="", delimiter=",", seed=DEFAULT_SEED, writer_threads=0):
     """Write ``<outdir><Trait><time>.results.csv`` (methods.py:1003-1197):
     header, rows sorted (stable) by the reference's key, every active cutoff
     applied, every cell double-quoted.  Without ``no_pairwise`` the
@@ -1352,7 +1374,7 @@ def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Pruned
     sel_k = None if extra is None else np.fromiter((r[1] for r in rows), dtype=np.int64, count=len(rows))
     header_line = delimiter.join('"' + c + '"' for c in columns) + "\n"
     if not _write_rows_native(fname, delimiter, header_line, Trait, table, sel_i, sel_k, colget, fields, extra,
-                              with_emp, extracolstoprint):
+                              with_emp, extracolstoprint, threads=writer_threads):
         _write_rows_python(fname, delimiter, header_line, Trait, table, sel_i, sel_k, colget, fields, extra,
                            with_emp, extracolstoprint)
     return fname

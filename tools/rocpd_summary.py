@@ -44,8 +44,10 @@ def main():
                 top = rows[0][0]
                 durs = [d / 1e3 for (d,) in c.execute(
                     "select duration from kernels where name = ? order by start", (top,))]
-                f.write("# %s per launch, us: %s\n" % (short(top)[:34],
-                                                       " ".join("%.1f" % d for d in durs)))
+                shown = durs[:40]
+                f.write("# %s per launch, us%s: %s\n" % (short(top)[:34],
+                                                        "" if len(durs) <= 40 else " (first 40 of %d)" % len(durs),
+                                                        " ".join("%.1f" % d for d in shown)))
         c.close()
     pmc = {}
     for sub, db in (("pmc_fetch", "fetch_results.db"), ("pmc_write", "write_results.db"),
