@@ -236,7 +236,8 @@ def test_bench_one_rank_through_rccl(scaling):
     rank 0's record checks -- everything the 8-GPU run does except a second device."""
     out = _torchrun(1, [os.path.join(ROOT, "bench.py"), "--exercise-exchange", "--backend", "nccl",
                         "--verify-gather", "--config", "cfg2", "--scaling", scaling, "--steps", "4",
-                        "--warmup", "1", "--no-cpu-baseline"], _clean_env())
+                        "--warmup", "1", "--no-cpu-baseline"] +
+                    (["--strong-extra", "on"] if scaling == "weak" else []), _clean_env())
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -248,6 +249,14 @@ def test_bench_one_rank_through_rccl(scaling):
     # cfg2 is launch-bound: the sharded rank replays its local step (record packing included) from
     # a hipGraph, the gather stays outside (round 6)
     assert d["config"]["hip_graph"] is True and d["config"]["hip_graph_auto"] is True
+    if scaling == "weak":
+        # the strong-curve entries of the multi-GPU line through the same RCCL group (one rank here)
+        for cfg, G in (("cfg3", 50_000), ("cfg4", 200_000)):
+            e = d["scaling_strong"][cfg]
+            assert e["n_gpus"] == 1 and e["rccl_ranks"] == 1 and e["genes_per_gpu"] == [G]
+            assert e["per_rank"][0]["exchange_exposed_ms"] is not None and e["value"] > 1e11
+    else:
+        assert d["scaling_strong"] is None
 
 
 def test_bench_rank_of_eight_cfg4_through_rccl_replays_a_graph():
