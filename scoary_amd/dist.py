@@ -324,6 +324,14 @@ def _initialized():
     return dist.is_available() and dist.is_initialized()
 
 
+def _initialized_safe():
+    """_initialized() without importing torch when nobody has yet (a plain single-process run)."""
+    import sys
+    if "torch" not in sys.modules:
+        return False
+    return _initialized()
+
+
 def associate_sharded(local_compute, G, group=None, kind=None):
     """Run ``local_compute(sel) -> int32 records [T, len(sel), REC_WORDS]`` on this rank's gene
     shard (``sel``: a slice of the gene axis, GenePartition.index) and gather the records of

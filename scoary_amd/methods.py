@@ -1558,6 +1558,7 @@ def main(**kwargs):
     log.addHandler(counts)
     log.info("==== Scoary started ====")
     log.info("Command: " + " ".join(sys.argv))
+    starter = None
     try:
         _validate(args, cutoffs)
         seed = getattr(args, "seed", DEFAULT_SEED)
@@ -1568,8 +1569,27 @@ def main(**kwargs):
         elif args.write_reduced:
             sys.exit("You cannot use the -w argument without specifying a subset (-r)")
         _stage.reset()
-        with _stage("import torch, HIP library, engine"):
-            get_engine()               # the first GPU call of the process: torch import, library load, context
+        # The first GPU call of the process -- torch import, library load, HIP context, warm-up: about a
+        # second -- and the read of the gene table need nothing from each other, and the native reader
+        # runs outside the interpreter lock: a single process starts the engine on a helper thread and
+        # joins it after the read (a 2.5 GB table reads in 0.6 s: the second shrinks to what the read
+        # does not cover).  Under torchrun the process group already imported torch and picked the device.
+        if world == 1 and not dist._initialized_safe() and os.environ.get("SCOARY_OVERLAP_STARTUP", "1") == "1":
+            import threading
+            started = {}
+
+            def _start_engine():
+                t0 = _time.perf_counter()
+                try:
+                    get_engine()
+                except BaseException as e:          # re-raised on the main thread at the join
+                    started["error"] = e
+                started["seconds"] = _time.perf_counter() - t0
+            starter = threading.Thread(target=_start_engine, name="scoary-engine-start", daemon=True)
+            starter.start()
+        else:
+            with _stage("import torch, HIP library, engine"):
+                get_engine()
         with open(args.genes, "r", newline=None) as genes, \
                 open(args.traits, "r", newline=None) as traits:
             log.info("Reading gene presence absence file")
@@ -1578,6 +1598,13 @@ def main(**kwargs):
                 gd = Csv_to_dic_Roary(genes, args.delimiter, grab, startcol=int(args.start_col) - 1,
                                       allowed_isolates=allowed, writereducedset=args.write_reduced,
                                       time=stamp, outdir=args.outdir)
+            if starter is not None:
+                with _stage("engine start not covered by the read"):
+                    starter.join()
+                _stage.seconds["import torch, HIP library, engine (helper thread, under the read)"] = \
+                    started.get("seconds", 0.0)
+                if "error" in started:
+                    raise started["error"]
             genedic, strains = gd["Roarydic"], gd["Strains"]
             upgmatree = None
             if args.newicktree is None and not args.no_pairwise:
@@ -1635,11 +1662,17 @@ def main(**kwargs):
         log.info("Checked a total of %d genes for associations to %d trait(s). Total time "
                  "used: %d seconds." % (len(genedic), len(traitsdic), int(_time.time() - start)))
     except SystemExit as e:
+        if starter is not None:
+            starter.join(120)          # never tear the interpreter down under a thread that is inside HIP start-up
         log.exception("CRITICAL:")
         for hnd in (logfile, console, counts):
             log.removeHandler(hnd)
         dist.shutdown()
         sys.exit(e.code)
+    except BaseException:
+        if starter is not None:
+            starter.join(120)
+        raise
     if counts.n.get("CRITICAL", 0):
         log.info("Scoary finished successfully, but with CRITICAL ERRORS. Please check your log file.")
     elif counts.n.get("ERROR", 0):
