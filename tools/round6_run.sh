@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box sessions collecting the round-6 evidence (outputs under gpurun_out/r06/).
-#   tools/round6_run.sh [part ...]     parts: tests bench balance rank8 e2e k1 xcd tree treepmc pairwise cfg5cli seg profiles
+#   tools/round6_run.sh [part ...]     parts: tests bench balance rank8 e2e k1 xcd tree treepmc pairwise cfg5cli seg profiles timeline soak
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r06
 mkdir -p $O
@@ -97,6 +97,24 @@ bash tools/profile.sh r06_wide --genes 20000 --isolates 50000 --traits 2 --permu
 python tools/rocpd_summary.py gpurun_out/prof_r06_wide profiles/r06_wide50000 wide50000 >> $O/profile_wide.log 2>&1
 find gpurun_out/prof_r06_wide gpurun_out/prof_r06* -type f ! -name '*.db' ! -name '*.txt' ! -name '*.log' -delete 2>/dev/null
 mkdir -p gpurun_out/profiles_r06; cp profiles/r06_* gpurun_out/profiles_r06/ 2>/dev/null
+fi
+if has timeline; then
+# kernel timeline of a rank of cfg4's 8-way split: single process (graph replay) against the sharded rank (graph replay +
+# record packing + RCCL gather), a few steps from the middle of the timed region
+( cd /tmp
+  rocprofv3 --kernel-trace -d $OLDPWD/$O/tl_single -o tl -- python $OLDPWD/bench.py --config cfg4 --genes 25000 --no-cpu-baseline --no-k1-cold --sustain-seconds 0 --telemetry-ms 0 > /dev/null 2>&1
+  RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29531 rocprofv3 --kernel-trace -d $OLDPWD/$O/tl_sharded -o tl -- python $OLDPWD/bench.py --exercise-exchange --config cfg4 --genes 25000 --scaling strong --no-cpu-baseline --no-k1-cold --sustain-seconds 0 --telemetry-ms 0 > /dev/null 2>&1 )
+python tools/step_timeline.py $O/tl_single > $O/timeline_cfg4_rank_of_8.txt 2>&1
+python tools/step_timeline.py $O/tl_sharded >> $O/timeline_cfg4_rank_of_8.txt 2>&1
+rm -rf $O/tl_single $O/tl_sharded
+cat $O/timeline_cfg4_rank_of_8.txt
+fi
+if has soak; then
+for t in lists tiles listbuild seglists counts; do
+  timeout 200 python tools/stress_$t.py 600 > $O/stress_$t.log 2>&1
+  echo "$t rc=$? $(tail -1 $O/stress_$t.log) ($(grep -c ' ok$' $O/stress_$t.log) ok)" >> $O/stress_soak.txt
+done
+cat $O/stress_soak.txt
 fi
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json, sys
