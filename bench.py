@@ -1318,6 +1318,14 @@ def main():
                                                "clock) / 32768: what the kernel issues per clock if the timed region "
                                                "already ran at the sustained clock")
         out["sustained"] = sustained
+        # (the driver's record keeps `roofline` and `config` whole and only the NAMES of other keys:
+        # the sustained window and the strong-curve entries ride along inside them, in short form)
+        out["roofline"]["sustained"] = None if sustained is None else {
+            k: sustained.get(k) for k in ("value", "ms_per_step", "seconds", "steps", "sclk_mhz_mean",
+                                          "socket_power_w_mean", "ops_per_clock_frac")}
+        out["config"]["scaling_strong"] = None if scaling_strong is None else {
+            k: {f: v.get(f) for f in ("n_gpus", "value", "ms_per_step", "hip_graph", "rccl_ranks", "genes_per_gpu")}
+            for k, v in scaling_strong.items() if isinstance(v, dict)}
         out["kernel_ms_isolated"] = iso            # five back-to-back launches of the kernel alone
         out["kernel_ms_note"] = ("kernel_ms: hipEvent durations inside the timed steps -- there the label generator "
                                  "(k_perm_generate_tiles) runs on a side stream WHILE k_fisher runs on the main one, so "

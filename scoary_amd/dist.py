@@ -119,11 +119,16 @@ def unpack_records(rec):
 
 
 def is_distributed():
-    try:
-        import torch.distributed as dist
-    except ImportError:
+    """A process group with more than one rank exists.  Looks at sys.modules instead of importing:
+    no group can exist if torch.distributed was never imported, and a command-line process imports
+    torch on a helper thread while the main thread reads the gene table (methods.main) -- an import
+    of torch.distributed from here would then deadlock against it (the importer detects that and
+    raises inside torch's C++ start-up)."""
+    import sys
+    td = sys.modules.get("torch.distributed")
+    if td is None or not hasattr(td, "is_initialized") or not hasattr(td, "get_world_size"):
         return False
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
 
 
 def world_rank():
@@ -219,7 +224,9 @@ def gather_genes(rec_local, G, dst=0, group=None, async_op=False, recv=None, par
     work = dist.gather(send, parts, dst=dst, group=group, async_op=async_op)
 
     def finish():
-        if work is not None and async_op:
+        # a gather that has already completed needs no stream-level wait (work.wait() would put a barrier
+        # on the compute stream in front of the next step: ~20 us per step on a launch-bound shard)
+        if work is not None and async_op and not work.is_completed():
             work.wait()
         if rank != dst:
             return None

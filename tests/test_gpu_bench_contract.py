@@ -143,6 +143,12 @@ def test_bench_headline_line_explains_itself():
     assert c4["n_gpus"] == 1 and c4["genes_per_gpu"] == [200_000] and c4["per_rank"] is None
     assert abs(c4["value"] - 200_000 * 10_000 / (c4["ms_per_step"] * 1e-3)) < 1e-6 * c4["value"]
     assert c4["value"] > 1e11 and c4["kernel_ms"]["k_permute_lists"] > 0
+    # short forms inside the objects the driver's record keeps whole
+    assert d["config"]["scaling_strong"]["cfg4"]["value"] == c4["value"]
+    assert d["config"]["scaling_strong"]["cfg3"]["n_gpus"] == 1
+    assert (d["roofline"]["sustained"] is None) == (d["sustained"] is None)
+    if d["sustained"] is not None:
+        assert d["roofline"]["sustained"]["value"] == d["sustained"]["value"]
     if tel["source"] is None:
         pytest.skip("this box exposes no clock / power source (amdsmi, hwmon): nothing to check")
     assert tel["samples"] >= 10                              # >= 10 samples inside the timed region

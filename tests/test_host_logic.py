@@ -61,6 +61,27 @@ def test_no_gpu_means_loud_failure():
         AssociationEngine()
 
 
+def test_command_line_without_a_gpu_fails_loudly_from_the_helper_thread(exampledir, tmp_path):
+    """The command line starts the engine (torch import, HIP context) on a helper thread while the main
+    thread reads the gene table.  Without a GPU that start fails: the error must come back on the main
+    thread as a clean non-zero exit naming the cause -- no CPU fallback, and no crash of the interpreter
+    (round 6: an `import torch.distributed` on the main thread deadlocked against the helper's
+    `import torch`; the importer's _DeadlockError surfaced inside torch's C++ start-up as
+    `terminate called after throwing an instance of 'python_error'`)."""
+    import subprocess
+    import sys
+    if __import__("torch").cuda.is_available():
+        pytest.skip("a GPU is visible: the start succeeds")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-m", "scoary_amd", "-g", os.path.join(exampledir, "Gene_presence_absence.csv"),
+                          "-t", os.path.join(exampledir, "Tetracycline_resistance.csv"), "--no_pairwise",
+                          "-o", str(tmp_path / "out")], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    text = out.stdout + out.stderr
+    assert out.returncode not in (0, -6, 134), text[-2000:]
+    assert "no GPU visible" in text and "terminate called" not in text
+    assert not [f for f in os.listdir(tmp_path / "out") if f.endswith(".results.csv")]
+
+
 def test_product_package_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "scoary_amd")):
         for fn in files:
