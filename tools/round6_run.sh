@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box sessions collecting the round-6 evidence (outputs under gpurun_out/r06/).
-#   tools/round6_run.sh [part ...]     parts: tests bench balance rank8 e2e k1 xcd tree treepmc pairwise cfg5cli seg profiles timeline soak
+#   tools/round6_run.sh [part ...]     parts: tests bench driver balance rank8 e2e k1 xcd tree treepmc pairwise cfg5cli seg profiles timeline soak
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r06
 mkdir -p $O
@@ -14,6 +14,14 @@ fi
 if has bench; then
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_cfg3_driver_command.json 2> $O/bench_cfg3_driver_command.err
 tail -c 600 $O/bench_cfg3_driver_command.err
+fi
+if has driver; then
+# the driver's command, twice, with its wall clock (the default line now also times cfg4 for scaling_strong)
+for i in 1 2; do
+  SECONDS=0
+  python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_cfg3_driver_command_$i.json 2> $O/bench_cfg3_driver_command_$i.err
+  echo "driver command run $i: wall ${SECONDS} s"
+done
 fi
 if has balance; then
 python tools/shard_balance.py --config cfg3 --gene-order sorted > $O/shard_balance_cfg3_sorted.txt 2>&1
