@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box sessions collecting the round-6 evidence (outputs under gpurun_out/r06/).
-#   tools/round6_run.sh [part ...]     parts: tests bench driver balance rank8 e2e k1 xcd tree treepmc pairwise cfg5cli seg profiles timeline soak
+#   tools/round6_run.sh [part ...]     parts: tests bench driver balance rank8 e2e k1 xcd tree treepmc pairwise cfg5cli seg profiles timeline soak curve
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r06
 mkdir -p $O
@@ -116,6 +116,11 @@ python tools/step_timeline.py $O/tl_single > $O/timeline_cfg4_rank_of_8.txt 2>&1
 python tools/step_timeline.py $O/tl_sharded >> $O/timeline_cfg4_rank_of_8.txt 2>&1
 rm -rf $O/tl_single $O/tl_sharded
 cat $O/timeline_cfg4_rank_of_8.txt
+fi
+if has curve; then
+python tools/strong_curve.py > $O/strong_curve.txt 2>&1
+python tools/strong_curve.py --configs cfg3 --gene-order sorted > $O/strong_curve_cfg3_sorted.txt 2>&1
+grep -v "^JSON" $O/strong_curve.txt $O/strong_curve_cfg3_sorted.txt
 fi
 if has soak; then
 for t in lists tiles listbuild seglists counts; do
