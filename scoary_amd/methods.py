@@ -1224,7 +1224,7 @@ def _write_rows_native(fname, delimiter, header_line, Trait, table, sel_i, sel_k
     library)."""
     from . import io_native
     if (not io_native.available() or os.environ.get("SCOARY_PY_WRITER") == "1" or len(delimiter) != 1
-            or Trait.members is not None or Trait._table is None or Trait._rows_idx is None):
+            or not delimiter.isascii() or Trait.members is not None or Trait._table is None or Trait._rows_idx is None):
         return False
     src = Trait._table
     text = _csv_text_columns(src)
