@@ -241,7 +241,9 @@ __global__ __launch_bounds__(1024) void k_counts(const uint4* __restrict__ tiled
   };
   // U gene quads are requested before any of them is used: with few traits per pass there is
   // little arithmetic per load and the stream lives on loads in flight (cfg4: T = 1)
-  constexpr int U = TB <= 4 ? 4 : (TB <= 16 ? 2 : 1);
+  // (round 6, cold stream on 125 000 x 10 000: two quads in flight per wavefront beat four at T = 4 -- 34.2 against
+  // 35.1 us -- and are within 1 % at T = 1 / 2; eight, or a double buffer, are slower: profiles/r06_k1_*.txt)
+  constexpr int U = TB <= 16 ? 2 : 1;
   for (int q0 = wave; q0 < Qp; q0 += nw * U) {
     uint4 gws[U];
 #pragma unroll
@@ -717,6 +719,11 @@ static int launch_counts(scoary_handle h, hipStream_t s, const uint32_t* d_tiled
   const int64_t base = Gp / kWave * L.passes, want = (int64_t)h->num_cu * 4 * 8;
   int qs = 1;
   while (qs < 16 && base * qs < want && 4 * qs <= Qp) qs *= 2;
+  // Round 6: on the cold stream (125 000 x 10 000, 1954 blocks: 4 wavefronts each are 7816 and just miss the target)
+  // blocks of 4 wavefronts beat blocks of 8 at every T but 16 -- T = 4: 34.2 against 38.1 us = 0.60 against 0.54 of
+  // 8 TB/s, T = 32: 107 against 117 us -- and blocks of 2 or 16 lose (profiles/r06_k1_launch_geometry_ab.txt): where
+  // four already give 6 wavefronts per SIMD, four it is (the 12- / 16-trait instances keep the larger blocks).
+  if (qs > 4 && L.tb != 12 && L.tb != 16 && base * 4 >= (int64_t)h->num_cu * 4 * 6) qs = 4;
   const dim3 grid((unsigned)(Gp / kWave), (unsigned)L.passes), block((unsigned)(kWave * qs));
   KernelTimer kt(h, s, "k_counts");
 #define COUNTS(TBV)                                                                                   \
