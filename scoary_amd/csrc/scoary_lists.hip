@@ -593,7 +593,13 @@ static ListGeom list_geom(int num_cu, int64_t G, int64_t T, int64_t N, int64_t P
   // enough blocks for >= 16 rounds over the CUs, and gene chunks whose index lists
   // (~2 MB) stay in an XCD's 4 MB L2 while the (trait, tile) blocks of the chunk run;
   // each chunk a multiple of 16 wave groups (one per wavefront)
-  int64_t chunks = ((int64_t)num_cu * 16 + g.ntiles * T - 1) / (g.ntiles * T);
+  // (SCOARY_LIST_ROUNDS = 1..64 replaces the 16 for same-box A/B runs, tools/ab_rounds_small.sh)
+  static const long env_rounds = [] {
+    const char* e = std::getenv("SCOARY_LIST_ROUNDS");
+    const long v = e ? std::strtol(e, nullptr, 10) : 0;
+    return (v >= 1 && v <= 64) ? v : 16L;
+  }();
+  int64_t chunks = ((int64_t)num_cu * env_rounds + g.ntiles * T - 1) / (g.ntiles * T);
   const int64_t chunk_bytes = list_chunk_bytes(TW);
   const int64_t by_l2 = (entries * 4 + chunk_bytes - 1) / chunk_bytes;
   if (chunks < by_l2) chunks = by_l2;

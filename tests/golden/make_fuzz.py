@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Randomised differential corpus: small inputs with the awkward shapes a drop-in has to survive,
+run through the REAL reference command line (imported from /root/reference, as make_golden.py does).
+
+    python tests/golden/make_fuzz.py            # rewrites tests/golden/fuzz_corpus.json.gz
+
+Every case = the text of a gene presence/absence table, a traits table (and maybe a restrict-to
+list), the flags, and what the reference did with them: the result CSVs (file name -> text), the
+UPGMA tree if one was asked for, or the message it exited with.  Data only; the GPU test
+(tests/test_gpu_fuzz.py) feeds the same files and flags to ``python -m scoary_amd``'s main().
+
+What the generator varies (seeded; the case list is a pure function of SEED):
+  * Roary-format tables (14 metadata columns) and plain tables (-s 4 ... ), ',' and ';' delimiters;
+  * 4 .. 70 isolates, 1 .. 150 genes; uniform, rare, U-shaped and clade-structured genes; core and
+    absent genes (the skip rule), duplicated patterns and complements (--collapse), repeated gene
+    identifiers (the later row wins, scoary/methods.py:452);
+  * every spelling of an absent cell ("", "0", "-"), quoted cells, cells with a leading blank
+    (the reader's skipinitialspace);
+  * 1 .. 4 traits; the top-left cell empty or "Name"; every spelling of a missing value; isolates
+    in another order, isolates missing from the traits file, isolates the gene table does not have;
+    traits with all values equal, with one positive, with everything missing but a few;
+  * flags: --no_pairwise or the pairwise stage (-u), -c subsets with one or matching -p lists,
+    -m, --collapse, -r (+ -w), --include_input_columns, --threads;
+  * inputs the reference refuses (sys.exit with a message): kept with the message.
+Cases on which the reference itself raises anything but SystemExit are dropped (counted in the
+manifest entry): there is no behaviour to be compatible with.
+"""
+import contextlib
+import csv
+import gzip
+import io
+import json
+import os
+import shutil
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+SEED = 20261001
+NCASES = 160
+
+sys.path.insert(0, REF)
+import scipy.stats as ss  # noqa: E402
+
+if not hasattr(ss, "binom_test"):       # removed in SciPy >= 1.12, still called at methods.py:1267
+    ss.binom_test = lambda x, n, p: ss.binomtest(int(x), int(n), p).pvalue
+
+warnings.filterwarnings("ignore")
+import scoary.methods as rm  # noqa: E402
+
+META = ["Gene", "Non-unique Gene name", "Annotation", "No. isolates", "No. sequences",
+        "Avg sequences per isolate", "Genome Fragment", "Order within Fragment",
+        "Accessory Fragment", "Accessory Order with Fragment", "QC", "Min group size nuc",
+        "Max group size nuc", "Avg group size nuc"]
+
+
+def gene_matrix(rng, G, N):
+    kind = rng.choice(["uniform", "rare", "ushaped", "clade"])
+    if kind == "uniform":
+        f = rng.uniform(0.05, 0.95, size=(G, 1))
+    elif kind == "rare":
+        f = rng.beta(0.3, 3.0, size=(G, 1))
+    elif kind == "ushaped":
+        f = rng.beta(0.2, 0.2, size=(G, 1))
+    else:
+        k = int(rng.integers(2, 5))
+        clade = np.sort(rng.integers(0, k, size=N))
+        f = np.clip(rng.beta(0.4, 0.4, size=(G, 1)) + rng.normal(0, 0.3, size=(G, k))[:, clade], 0, 1)
+    m = rng.random((G, N)) < f
+    # the rows the skip rule, --collapse and the tie handling look at
+    for _ in range(int(rng.integers(0, 4))):
+        a, b = rng.integers(0, G, size=2)
+        m[a] = m[b]
+    if G > 3 and rng.random() < 0.5:
+        a, b = rng.integers(0, G, size=2)
+        m[a] = ~m[b]
+    if rng.random() < 0.5:
+        m[rng.integers(0, G)] = True
+    if rng.random() < 0.5:
+        m[rng.integers(0, G)] = False
+    return m, str(kind)
+
+
+def write_table(rows, delimiter, quote_all=False):
+    buf = io.StringIO()
+    w = csv.writer(buf, delimiter=delimiter, lineterminator="\n",
+                   quoting=csv.QUOTE_ALL if quote_all else csv.QUOTE_MINIMAL)
+    w.writerows(rows)
+    return buf.getvalue()
+
+
+def make_case(rng, k):
+    N = int(rng.choice([4, 5, 7, 12, 20, 33, 48, 64, 65, 70]))
+    G = int(rng.choice([1, 2, 5, 17, 40, 40, 90, 90, 150]))
+    roary = rng.random() < 0.7
+    delimiter = ";" if rng.random() < 0.2 else ","
+    m, kind = gene_matrix(rng, G, N)
+    iso = ["iso%02d" % i if rng.random() < 0.8 else "s_%d.x" % i for i in range(N)]
+    absent = ["", "0", "-"]
+    nmeta = 14 if roary else int(rng.integers(3, 7))
+    header = (META if roary else ["locus", "alias", "note", "x1", "x2", "x3"][:nmeta]) + iso
+    names = ["g%04d" % g for g in range(G)]
+    for _ in range(int(rng.integers(0, 3))):             # repeated identifiers: the later row wins
+        if G > 2:
+            a, b = rng.integers(0, G, size=2)
+            names[a] = names[b]
+    lead_blank = rng.random() < 0.3
+    rows = [header]
+    for g in range(G):
+        meta = [names[g], ("nm%d" % g) if g % 3 else "", "protein, putative %d" % g if g % 4 else "hyp %d" % g]
+        meta += [str(int(m[g].sum()))] * (nmeta - 3)
+        cells = []
+        for i in range(N):
+            if m[g, i]:
+                c = "p%d" % g if rng.random() < 0.9 else "1"
+            else:
+                c = absent[int(rng.integers(0, 3))]
+            if lead_blank and c and rng.random() < 0.1:
+                c = " " + c                               # skipinitialspace strips it: still present
+            cells.append(c)
+        rows.append(meta + cells)
+    gpa = write_table(rows, delimiter, quote_all=rng.random() < 0.25)
+
+    T = int(rng.choice([1, 1, 2, 3, 4]))
+    topleft = "" if rng.random() < 0.7 else "Name"
+    tnames = ["trait%d" % t if rng.random() < 0.8 else "res (%d)" % t for t in range(T)]
+    missing = ["NA", "-", ".", " ", ""]
+    tv = np.empty((T, N), dtype=object)
+    for t in range(T):
+        style = rng.choice(["random", "random", "gene", "gene", "rare", "constant", "one", "mostly_missing"])
+        if style == "gene" and G > 0:
+            v = m[rng.integers(0, G)] ^ (rng.random(N) < 0.1)
+        elif style == "rare":
+            v = rng.random(N) < 0.1
+        elif style == "constant":
+            v = np.full(N, rng.random() < 0.5)
+        elif style == "one":
+            v = np.zeros(N, dtype=bool)
+            v[rng.integers(0, N)] = True
+        else:
+            v = rng.random(N) < rng.uniform(0.2, 0.8)
+        tv[t] = [str(int(x)) for x in v]
+        pm = 0.6 if style == "mostly_missing" else (0.1 if rng.random() < 0.4 else 0.0)
+        for i in range(N):
+            if rng.random() < pm:
+                tv[t, i] = missing[int(rng.integers(0, 5))]
+    order = rng.permutation(N) if rng.random() < 0.5 else np.arange(N)
+    drop = set(rng.choice(N, size=int(rng.integers(1, max(2, N // 6))), replace=False).tolist()) \
+        if rng.random() < 0.3 else set()
+    trows = [[topleft] + tnames]
+    for i in order:
+        if int(i) in drop:
+            continue
+        trows.append([iso[i]] + [tv[t, i] for t in range(T)])
+    if rng.random() < 0.04:                               # isolates the gene table does not have: refused
+        for j in range(int(rng.integers(1, 4))):
+            trows.insert(int(rng.integers(1, len(trows) + 1)),
+                         ["extra_%d" % j] + [str(int(rng.random() < 0.5)) for _ in range(T)])
+    bad = None
+    r = rng.random()
+    if r < 0.04:                                          # inputs the reference refuses
+        trows[min(2, len(trows) - 1)][1] = "2"
+        bad = "value"
+    elif r < 0.07:
+        trows[0][0] = "isolate"
+        bad = "topleft"
+    traits = write_table(trows, delimiter)
+
+    argv = []
+    if not roary:
+        argv += ["-s", str(nmeta + 1)]
+    elif rng.random() < 0.1:
+        argv += ["-s", "15"]
+    if delimiter != ",":
+        argv += ["--delimiter", delimiter]
+    pairwise = rng.random() < 0.3 and N >= 5
+    corr_pool = ["I", "B", "BH"] + (["PW", "EPW"] if pairwise else [])
+    if rng.random() < 0.6:
+        nc = int(rng.integers(1, len(corr_pool) + 1))
+        corr = [str(c) for c in rng.choice(corr_pool, size=nc, replace=False)]
+        argv += ["-c"] + corr
+    else:
+        corr = ["I"]
+    pvals = [1.0, 0.9, 0.5, 0.2, 0.05]
+    if rng.random() < 0.5:
+        argv += ["-p", str(pvals[int(rng.integers(0, 5))])]
+    elif rng.random() < 0.6:
+        argv += ["-p"] + [str(pvals[int(rng.integers(0, 4))]) for _ in corr]
+    elif rng.random() < 0.1:
+        argv += ["-p", "0.5", "0.5", "0.5", "0.5", "0.5", "0.5", "0.5"]   # more cut-offs than methods: refused
+    if not pairwise:
+        argv += ["--no_pairwise"]
+    elif rng.random() < 0.7:
+        argv += ["-u"]
+    if rng.random() < 0.2:
+        argv += ["-m", str(int(rng.integers(1, 12)))]
+    if rng.random() < 0.25:
+        argv += ["--collapse"]
+    if rng.random() < 0.15:
+        argv += ["--threads", str(int(rng.integers(2, 4)))]
+    restrict = None
+    if rng.random() < 0.2 and N >= 7:
+        keep = [iso[i] for i in range(N) if rng.random() < 0.7]
+        if rng.random() < 0.3:
+            keep.append("not_an_isolate")
+        half = len(keep) // 2
+        restrict = ",".join(keep[:half]) + "\n" + ",".join(keep[half:]) + "\n" if rng.random() < 0.3 \
+            else ",".join(keep) + "\n"
+        argv += ["-r", "RESTRICT"]
+        if rng.random() < 0.4:
+            argv += ["-w"]
+    elif rng.random() < 0.03:
+        argv += ["-w"]                                    # -w without -r: refused
+    if roary and rng.random() < 0.15:
+        argv += ["--include_input_columns", str(rng.choice(["4", "4,6-7", "ALL", "5-6"]))]
+    return {"id": k, "kind": kind, "roary": bool(roary), "N": N, "G": G, "T": T, "bad": bad,
+            "gpa": gpa, "traits": traits, "restrict": restrict, "argv": argv}
+
+
+@contextlib.contextmanager
+def quiet():
+    old_out, old_err = sys.stdout, sys.stderr
+    sys.stdout = sys.stderr = io.StringIO()
+    try:
+        yield
+    finally:
+        sys.stdout, sys.stderr = old_out, old_err
+
+
+def run_reference(case):
+    tmp = tempfile.mkdtemp(prefix="fuzz_")
+    try:
+        paths = {}
+        for key in ("gpa", "traits", "restrict"):
+            if case[key] is not None:
+                paths[key] = os.path.join(tmp, key + ".csv")
+                with open(paths[key], "w", newline="") as f:
+                    f.write(case[key])
+        od = os.path.join(tmp, "out")
+        os.mkdir(od)
+        argv = ["-g", paths["gpa"], "-t", paths["traits"]] + \
+               [paths["restrict"] if a == "RESTRICT" else a for a in case["argv"]] + ["-o", od, "--no-time"]
+        old = sys.argv
+        sys.argv = ["scoary.py"] + argv
+        # the reference keeps its log handlers and call counters in module state
+        for hdl in list(rm.log.handlers):
+            rm.log.removeHandler(hdl)
+        status, message = "ok", None
+        try:
+            with quiet():
+                try:
+                    rm.main()
+                except SystemExit as e:
+                    if e.code not in (0, None):
+                        status, message = "exit", str(e.code)
+        except BaseException as e:      # the reference's own crash: nothing to be compatible with
+            return {"status": "crash", "message": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            sys.argv = old
+        out = {"status": status, "message": message, "files": {}, "tree": None, "reduced": None}
+        if status == "ok":
+            for fn in sorted(os.listdir(od)):
+                p = os.path.join(od, fn)
+                if fn.endswith(".results.csv"):
+                    with open(p, newline="") as f:
+                        out["files"][fn] = f.read()
+                elif fn == "Tree.nwk":
+                    with open(p) as f:
+                        out["tree"] = f.read()
+                elif fn == "gene_presence_absence_reduced.csv":
+                    with open(p, newline="") as f:
+                        out["reduced"] = f.read()
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def main():
+    rng = np.random.default_rng(SEED)
+    cases, crashed = [], []
+    k = 0
+    while len(cases) < NCASES and k < 4 * NCASES:
+        case = make_case(rng, k)
+        k += 1
+        ref = run_reference(case)
+        if ref["status"] == "crash":
+            crashed.append({"id": case["id"], "message": ref["message"][:200]})
+            continue
+        case["ref"] = ref
+        cases.append(case)
+    doc = {"seed": SEED, "generated": k, "kept": len(cases), "reference_crashes": crashed, "cases": cases}
+    path = os.path.join(HERE, "fuzz_corpus.json.gz")
+    with open(path, "wb") as raw:
+        with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, filename="") as g:
+            g.write(json.dumps(doc, sort_keys=True).encode())
+    n_ok = sum(c["ref"]["status"] == "ok" for c in cases)
+    print("%d cases kept of %d generated (%d ok, %d refused by the reference, %d reference crashes dropped); %d bytes"
+          % (len(cases), k, n_ok, len(cases) - n_ok, len(crashed), os.path.getsize(path)))
+    for c in crashed[:20]:
+        print("  dropped", c)
+
+
+if __name__ == "__main__":
+    main()

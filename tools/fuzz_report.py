@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""All cases of tests/golden/fuzz_corpus.json.gz through the command line on this GPU, every difference from the
+reference's record listed (the pytest module stops at the first under -x).   python tools/fuzz_report.py [out.txt]"""
+import io
+import os
+import sys
+import tempfile
+import traceback
+import contextlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_fuzz as tf  # noqa: E402
+
+
+def main():
+    out = open(sys.argv[1], "w") if len(sys.argv) > 1 else sys.stdout
+    bad = 0
+    for case in tf.CORPUS["cases"]:
+        tmp = tempfile.mkdtemp(prefix="fuzzrun_")
+        sink = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+                got = tf.run_case(case, tmp)
+            diffs = tf.compare_case(case, got)
+        except BaseException:
+            diffs = ["our command line raised: " + traceback.format_exc().strip().splitlines()[-1]
+                     + " @ " + " | ".join(l.strip() for l in traceback.format_exc().strip().splitlines()[-7:-1])]
+        if diffs:
+            bad += 1
+            print("case %3d  N=%-3d G=%-3d T=%d roary=%-5s ref=%s  argv: %s" % (
+                case["id"], case["N"], case["G"], case["T"], case["roary"], case["ref"]["status"],
+                " ".join(case["argv"])), file=out)
+            for d in diffs:
+                print("      " + d[:600], file=out)
+    print("%d of %d cases differ from the reference" % (bad, len(tf.CORPUS["cases"])), file=out)
+    out.flush()
+
+
+if __name__ == "__main__":
+    main()
