@@ -400,9 +400,9 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
     zeros_list = flipped[g] != 0;
   }
   const int4 c = tables[idx];
-  const int a = c.x, b = c.y, cc = c.z, d = c.w;
-  const int n1 = a + b, n2 = cc + d, n = a + cc;
-  if (n1 == 0 || n2 == 0 || n == 0 || b + d == 0) {
+  const int b = c.y, cc = c.z, d = c.w;
+  const int n0 = c.x + cc;
+  if (c.x + b == 0 || cc + d == 0 || n0 == 0 || b + d == 0) {
     if (down) {
       or_out[idx] = __longlong_as_double(0x7ff8000000000000LL);
     } else {
@@ -412,6 +412,18 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
     }
     return;
   }
+  // Canonical orientation (round 6): a gene and the gene with the complementary pattern -- the tables
+  // [[a, b], [c, d]] and [[b, a], [d, c]] -- have the same p, and SciPy returns the same double for both
+  // whenever the table is larger than its factorial table (N > 170: 400 of 400 random pairs at N = 200,
+  // 500, 2000; about half below), so the reference's stable sort leaves such rows in file order.  Walking
+  // each table from its own mode gave the pair p-values one ulp apart (the mode's term joins the other
+  // lane's sum; with two equal modes the weights are normalised at the other one) and the rows changed
+  // places in the CSV (tests/test_gpu_fuzz.py).  So a gene carried by more than half of the valid isolates
+  // (at exactly half: the larger a) is evaluated as its complement, in the coordinate x' = n1 - x, and only
+  // the region bounds are mapped back.
+  const int n1 = c.x + b, n2 = cc + d;
+  const bool mirrored = n0 > b + d || (n0 == b + d && c.x > b);
+  const int a = mirrored ? b : c.x, n = mirrored ? b + d : n0;
   const int lo = max(0, n - n2), hi = min(n, n1);
   int mode = (int)(((double)(n + 1) * (double)(n1 + 1)) / (double)(n1 + n2 + 2));
   mode = min(max(mode, lo), hi);
@@ -459,21 +471,23 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
   inc += __shfl_xor(inc, 1);
   const int other = __shfl_xor(first, 1);
   if (down) {
-    or_out[idx] = (cc > 0 && b > 0) ? ((double)a * (double)d) / ((double)cc * (double)b)
+    or_out[idx] = (cc > 0 && b > 0) ? ((double)c.x * (double)d) / ((double)cc * (double)b)
                                     : __longlong_as_double(0x7ff0000000000000LL);
     return;
   }
-  const int H = first >= 0 ? first : hi + 1;
-  const int L = other >= 0 ? n - other : lo - 1;
-  const bool all = (H == mode);
+  const int Hc = first >= 0 ? first : hi + 1;          // region bounds in the canonical coordinate
+  const int Lc = other >= 0 ? n - other : lo - 1;
+  const bool all = (Hc == mode);
   const double p = all ? 1.0 : inc / tot;
   p_out[idx] = p < 1.0 ? p : 1.0;
+  const int L = mirrored ? n1 - Hc : Lc, H = mirrored ? n1 - Lc : Hc;   // ... and in the table's own a
   const uint32_t base = (uint32_t)(L + 1), span = all ? 0u : (uint32_t)(H - L - 1);
   if (crit) crit[idx] = all ? make_uint2(0u, 0u) : make_uint2(base, span);
   if constexpr (SLOTS) {
+    const uint32_t npos = (uint32_t)n1;                // the trait's positives among the valid isolates
     uint2 o = make_uint2(0u, 0u);                      // span 0: every permutation is in the region
     if (span != 0u)
-      o = zeros_list ? make_uint2((uint32_t)n1 - base - span + 1u, (uint32_t)n1 - base + 1u)
+      o = zeros_list ? make_uint2(npos - base - span + 1u, npos - base + 1u)
                      : make_uint2(base, base + span);
     lcrit[lidx] = o;
   }

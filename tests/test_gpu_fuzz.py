@@ -76,51 +76,88 @@ def _is_float(s):
         return False
 
 
-def compare_csv(got, want, delimiter):
-    """None if equal (bytes, or same rows in the same order with float cells within FLOAT_TOL relative /
-    absolute), else a description of the first difference."""
+def _pcell(row, header, name="Naive_p"):
+    """The cell of column `name`: a collapsed row of a plain table carries extra cells in FRONT of the counts
+    (the reference splits the merged identifier at every "_|_", scoary/methods.py:1152-1153), so columns are
+    counted from the right end of the row."""
+    return row[header.index(name) + len(row) - len(header)]
+
+
+METHOD_COLUMN = {"I": "Naive_p", "B": "Bonferroni_p", "BH": "Benjamini_H_p", "PW": "Best_pairwise_comp_p",
+                 "EPW": "Worst_pairwise_comp_p"}
+
+
+def compare_csv(got, want, delimiter, cutoffs=(("Naive_p", 0.05),), max_hits=False):
+    """None if equal -- bytes, or the same rows with float cells within FLOAT_TOL (relative / absolute) and the same
+    order wherever the reference's sort key distinguishes two rows -- else a description of the first difference.
+    Two places where SciPy's last bit decides in the reference and cannot be reproduced (p within
+    1e-12, not to the last digit) are accepted for what they are:
+      * a row whose p sits within FLOAT_TOL of a cut-off may be kept on one side and dropped on the other;
+      * under -m the last rows may be other members of the tie that straddles the cut."""
     if got == want:
         return None
     g = list(csv.reader(io.StringIO(got), delimiter=delimiter))
     w = list(csv.reader(io.StringIO(want), delimiter=delimiter))
     if g[0] != w[0]:
         return "header %r != %r" % (g[0], w[0])
-    if len(g) != len(w):
-        return "rows %d != %d" % (len(g) - 1, len(w) - 1)
-    # rows may only change places where the reference's sort key (the p-value column order) ties to 1e-12:
-    # compare as sets keyed by the first cell first, then the order of the keys that are not tied
-    gi = {}
+    header = g[0]
+
+    def close(a, b):
+        return abs(a - b) <= FLOAT_TOL + FLOAT_TOL * abs(b)
+
+    def key(r):
+        return delimiter.join(r[:len(r) - len(header) + 3])        # the identifier cells, whatever their number
+    gi, wi = {}, {}
     for r in g[1:]:
-        gi.setdefault(r[0], []).append(r)
-    for wr in w[1:]:
-        cand = gi.get(wr[0])
-        if not cand:
-            return "row %r missing" % wr[0]
-        gr = cand.pop(0)
-        if len(gr) != len(wr):
-            return "row %r: %d cells != %d" % (wr[0], len(gr), len(wr))
-        for k, (a, b) in enumerate(zip(gr, wr)):
-            if a == b:
-                continue
-            if not (_is_float(a) and _is_float(b)):
-                return "row %r column %s: %r != %r" % (wr[0], g[0][k], a, b)
-            fa, fb = float(a), float(b)
-            if not abs(fa - fb) <= FLOAT_TOL + FLOAT_TOL * abs(fb):
-                return "row %r column %s: %r != %r" % (wr[0], g[0][k], a, b)
-    if [r[0] for r in g] != [r[0] for r in w]:
-        # an order difference is only legitimate between rows whose float cells agree to the tolerance
-        # (a sort key tied in one implementation and 1 ulp apart in the other)
-        wrow = {}
-        for r in w[1:]:
-            wrow.setdefault(r[0], r)
-        for a, b in zip(g[1:], w[1:]):
-            if a[0] == b[0]:
-                continue
-            ra, rb = wrow[a[0]], b
-            keys = [k for k in range(len(ra)) if _is_float(ra[k]) and _is_float(rb[k]) and g[0][k].endswith("_p")]
-            if not keys or any(abs(float(ra[k]) - float(rb[k])) > FLOAT_TOL * max(1.0, abs(float(rb[k])))
-                               for k in keys[:1]):
-                return "row order differs at %r / %r" % (a[0], b[0])
+        gi.setdefault(key(r), []).append(r)
+    for r in w[1:]:
+        wi.setdefault(key(r), []).append(r)
+    only = [(k, r, "ours") for k in gi for r in gi[k][len(wi.get(k, [])):]] + \
+           [(k, r, "reference") for k in wi for r in wi[k][len(gi.get(k, [])):]]
+    if only:
+        edge = None
+        if max_hits and len(w) > 1:
+            edge = max(float(_pcell(r, header)) for r in w[1:])       # the p of the tie the -m cut goes through
+        n_cut = 0
+        for k, r, side in only:
+            # (a capped p of 1.0 never exceeds a cut-off of 1.0: no boundary there)
+            at_cut = any(cut < 1.0 and c in header and _is_float(_pcell(r, header, c))
+                         and close(float(_pcell(r, header, c)), cut) for c, cut in cutoffs)
+            at_edge = edge is not None and close(float(_pcell(r, header)), edge)
+            if not (at_cut or at_edge):
+                return "row %r only in %s output (p %s)" % (k, side, _pcell(r, header))
+            n_cut += at_cut
+        if n_cut == 0 and len(g) != len(w):       # the -m tie exchanges rows, it does not add or remove any
+            return "rows %d != %d" % (len(g) - 1, len(w) - 1)
+    for k in wi:
+        for gr, wr in zip(gi.get(k, []), wi[k]):
+            if len(gr) != len(wr):
+                return "row %r: %d cells != %d" % (k, len(gr), len(wr))
+            for j, (a, b) in enumerate(zip(gr, wr)):
+                if a == b:
+                    continue
+                if not (_is_float(a) and _is_float(b) and close(float(a), float(b))):
+                    return "row %r cell %d: %r != %r" % (k, j, a, b)
+    # order: ours sorted by p like the reference's, and rows that BOTH sides give one and the same p keep the
+    # reference's order (its stable sort over the result dictionary -- merged genes move to the end,
+    # scoary/methods.py:874-889).  Rows one side separates by an ulp and the other does not are SciPy's last
+    # bit again (a gene and its complement get the same double from both sides beyond N = 170, k_fisher).
+    ps = [float(_pcell(r, header)) for r in g[1:]]
+    if any(ps[i] > ps[i + 1] * (1 + FLOAT_TOL) + FLOAT_TOL for i in range(len(ps) - 1)):
+        return "rows are not sorted by Naive_p"
+    common = set(gi) & set(wi)
+    pos, ours_p = {}, {}
+    for i, r in enumerate(g[1:]):
+        pos.setdefault(key(r), i)
+        ours_p.setdefault(key(r), _pcell(r, header))
+    groups = {}
+    for r in w[1:]:
+        if key(r) in common:
+            groups.setdefault((_pcell(r, header), ours_p[key(r)]), []).append(key(r))
+    for (pstr, _), keys in groups.items():
+        seq = [pos[k] for k in keys]
+        if seq != sorted(seq):
+            return "rows with the p %s on both sides come in another order: %r" % (pstr, keys[:6])
     return None
 
 
@@ -136,9 +173,26 @@ def compare_case(case, got):
         return diffs
     if sorted(got["files"]) != sorted(ref["files"]):
         return ["result files %s != %s" % (sorted(got["files"]), sorted(ref["files"]))]
-    delimiter = ";" if "--delimiter" in case["argv"] else ","
+    argv = case["argv"]
+    delimiter = ";" if "--delimiter" in argv else ","
+    methods, values = ["I"], [0.05]
+    if "-c" in argv:
+        methods = []
+        for a in argv[argv.index("-c") + 1:]:
+            if a not in METHOD_COLUMN:
+                break
+            methods.append(a)
+    if "-p" in argv:
+        values = []
+        for a in argv[argv.index("-p") + 1:]:
+            if not _is_float(a):
+                break
+            values.append(float(a))
+    if len(values) == 1:
+        values = values * len(methods)
+    cutoffs = [(METHOD_COLUMN[m_], v) for m_, v in zip(methods, values)]
     for fn in sorted(ref["files"]):
-        d = compare_csv(got["files"][fn], ref["files"][fn], delimiter)
+        d = compare_csv(got["files"][fn], ref["files"][fn], delimiter, cutoffs, "-m" in argv)
         if d:
             diffs.append("%s: %s" % (fn, d))
     if ref["tree"] is not None and got["tree"] != ref["tree"]:

@@ -233,6 +233,38 @@ def test_fisher_vs_oracle_and_rejection_region(eng, orc):
             assert in_region == (px <= o_p[k] * (1 + 1e-9)), (tabs[k], x, base, span)
 
 
+def test_fisher_of_a_gene_and_of_its_complement_are_the_same_double(eng, orc):
+    """[[a, b], [c, d]] and [[b, a], [d, c]] (a gene / the complementary gene under one trait): the same
+    p bit for bit -- as SciPy returns for tables beyond its factorial table (N > 170), which is what keeps
+    such rows in file order in the reference's CSV -- the same odds ratio reciprocal-wise, and regions
+    that are each other's image under x -> n1 - x; both orientations still equal the oracle's regions."""
+    import torch
+    rng = np.random.default_rng(77)
+    tabs = []
+    for N in (7, 64, 100, 171, 500, 2000, 9000):
+        for _ in range(120):
+            n1 = int(rng.integers(1, N)); n = int(rng.integers(1, N))
+            lo, hi = max(0, n - (N - n1)), min(n, n1)
+            a = int(rng.integers(lo, hi + 1))
+            tabs.append((a, n1 - a, n - a, N - n1 - n + a))
+        tabs.append((N // 4, N // 4, N // 4, N - 3 * (N // 4)))          # gene carried by exactly half
+        tabs.append((N // 4 - 1, N // 4 + 1, N // 4 + 1, N - 3 * (N // 4) - 1))
+    tabs = np.array(tabs, dtype=np.int32)
+    comp = tabs[:, [1, 0, 3, 2]].copy()
+    p, odds, crit = eng.fisher(torch.from_numpy(tabs).cuda())
+    pc, oddsc, critc = eng.fisher(torch.from_numpy(comp).cuda())
+    p, pc = p.cpu().numpy(), pc.cpu().numpy()
+    assert np.array_equal(p.view(np.uint64), pc.view(np.uint64))
+    crit, critc = crit.cpu().numpy().view(np.uint32).astype(np.int64), critc.cpu().numpy().view(np.uint32).astype(np.int64)
+    n1 = tabs[:, 0].astype(np.int64) + tabs[:, 1]
+    some = crit[:, 1] > 0
+    assert np.array_equal(some, critc[:, 1] > 0) and np.array_equal(crit[some, 1], critc[some, 1])
+    # accept [base, base + span) in a  <=>  accept [n1 - base - span + 1, n1 - base + 1) in b = n1 - a
+    assert np.array_equal(critc[some, 0], n1[some] - crit[some, 0] - crit[some, 1] + 1)
+    _, o_p = orc.fisher_many(tabs)
+    assert np.max(np.abs(p - o_p)) < P_TOL and np.max(np.abs(p - o_p) / o_p) < 1e-11
+
+
 def test_fisher_exampledata_golden_p(eng):
     import torch
     z = np.load(os.path.join(GOLDEN, "setup_results_exampledata.npz"))

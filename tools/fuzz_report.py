@@ -24,6 +24,10 @@ def main():
             with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
                 got = tf.run_case(case, tmp)
             diffs = tf.compare_case(case, got)
+            if diffs and got["status"] == "ok":
+                for fn, text in got["files"].items():
+                    if any(d.startswith(fn) for d in diffs):
+                        diffs.append("---- our %s ----\n%s" % (fn, text))
         except BaseException:
             diffs = ["our command line raised: " + traceback.format_exc().strip().splitlines()[-1]
                      + " @ " + " | ".join(l.strip() for l in traceback.format_exc().strip().splitlines()[-7:-1])]
@@ -33,7 +37,7 @@ def main():
                 case["id"], case["N"], case["G"], case["T"], case["roary"], case["ref"]["status"],
                 " ".join(case["argv"])), file=out)
             for d in diffs:
-                print("      " + d[:600], file=out)
+                print("      " + d[:6000], file=out)
     print("%d of %d cases differ from the reference" % (bad, len(tf.CORPUS["cases"])), file=out)
     out.flush()
 
