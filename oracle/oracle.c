@@ -217,6 +217,175 @@ static int hg_leq(const double *w, int64_t lo, int64_t n1, int64_t n2, int64_t n
     return hg_leq_exact(n1, n2, n, x, a);
 }
 
+/* ---- S3, N <= 170: scipy.stats.fisher_exact's own double ---------------------------------------
+ * What the reference calls at scoary/methods.py:854 is third-party arithmetic (SciPy 1.15.3 over
+ * Boost.Math).  For populations up to 170 -- max_factorial<double> -- Boost evaluates the hypergeometric
+ * pmf from its table of factorials (hypergeometric_pdf_factorial_imp) and the tails by the term recurrence
+ * of hypergeometric_cdf_imp, in plain double; scipy.stats.hypergeom clips them to [0, 1] and handles the
+ * ends of the support; fisher_exact adds the tail on the observed side to the tail beyond the point its
+ * _binary_search finds on the other side (scipy/stats/_stats_py.py).  Restated here operation by operation
+ * (published algorithms; none of that code is in /root/reference) and PINNED: equal to SciPy bit for bit on
+ * the 5189 tables with N <= 170 of tests/golden/fisher_grid.npz and on every p-value of the reference's
+ * exampledata run (tests/test_oracle_golden.py).  The reference's example data has N = 100.  Above 170 Boost
+ * factorises into primes and calls pow(): not restated, the set rule below is the p there (1e-12). */
+#define ORC_SCIPY_SMALL_N 170
+static const double orc_factorial[ORC_SCIPY_SMALL_N + 1] = {
+    1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0, 5040.0, 40320.0, 362880.0, 3628800.0, 39916800.0, 479001600.0,
+    6227020800.0, 87178291200.0, 1307674368000.0, 20922789888000.0, 355687428096000.0, 6402373705728000.0,
+    1.21645100408832e+17, 2.43290200817664e+18, 5.109094217170944e+19, 1.1240007277776077e+21, 2.585201673888498e+22,
+    6.204484017332394e+23, 1.5511210043330986e+25, 4.0329146112660565e+26, 1.0888869450418352e+28,
+    3.0488834461171387e+29, 8.841761993739702e+30, 2.6525285981219107e+32, 8.222838654177922e+33, 2.631308369336935e+35,
+    8.683317618811886e+36, 2.9523279903960416e+38, 1.0333147966386145e+40, 3.7199332678990125e+41,
+    1.3763753091226346e+43, 5.230226174666011e+44, 2.0397882081197444e+46, 8.159152832478977e+47, 3.345252661316381e+49,
+    1.40500611775288e+51, 6.041526306337383e+52, 2.658271574788449e+54, 1.1962222086548019e+56, 5.502622159812089e+57,
+    2.5862324151116818e+59, 1.2413915592536073e+61, 6.082818640342675e+62, 3.0414093201713376e+64,
+    1.5511187532873822e+66, 8.065817517094388e+67, 4.2748832840600255e+69, 2.308436973392414e+71, 1.2696403353658276e+73,
+    7.109985878048635e+74, 4.0526919504877214e+76, 2.3505613312828785e+78, 1.3868311854568984e+80,
+    8.32098711274139e+81, 5.075802138772248e+83, 3.146997326038794e+85, 1.98260831540444e+87, 1.2688693218588417e+89,
+    8.247650592082472e+90, 5.443449390774431e+92, 3.647111091818868e+94, 2.4800355424368305e+96, 1.711224524281413e+98,
+    1.1978571669969892e+100, 8.504785885678623e+101, 6.1234458376886085e+103, 4.4701154615126844e+105,
+    3.307885441519386e+107, 2.48091408113954e+109, 1.8854947016660504e+111, 1.4518309202828587e+113,
+    1.1324281178206297e+115, 8.946182130782976e+116, 7.156945704626381e+118, 5.797126020747368e+120,
+    4.753643337012842e+122, 3.945523969720659e+124, 3.314240134565353e+126, 2.81710411438055e+128,
+    2.4227095383672734e+130, 2.107757298379528e+132, 1.8548264225739844e+134, 1.650795516090846e+136,
+    1.4857159644817615e+138, 1.352001527678403e+140, 1.2438414054641308e+142, 1.1567725070816416e+144,
+    1.087366156656743e+146, 1.032997848823906e+148, 9.916779348709496e+149, 9.619275968248212e+151,
+    9.426890448883248e+153, 9.332621544394415e+155, 9.332621544394415e+157, 9.42594775983836e+159,
+    9.614466715035127e+161, 9.90290071648618e+163, 1.0299016745145628e+166, 1.081396758240291e+168,
+    1.1462805637347084e+170, 1.226520203196138e+172, 1.324641819451829e+174, 1.4438595832024937e+176,
+    1.588245541522743e+178, 1.7629525510902446e+180, 1.974506857221074e+182, 2.2311927486598138e+184,
+    2.5435597334721877e+186, 2.925093693493016e+188, 3.393108684451898e+190, 3.969937160808721e+192,
+    4.684525849754291e+194, 5.574585761207606e+196, 6.689502913449127e+198, 8.094298525273444e+200,
+    9.875044200833601e+202, 1.214630436702533e+205, 1.506141741511141e+207, 1.882677176888926e+209,
+    2.372173242880047e+211, 3.0126600184576594e+213, 3.856204823625804e+215, 4.974504222477287e+217,
+    6.466855489220474e+219, 8.47158069087882e+221, 1.1182486511960043e+224, 1.4872707060906857e+226,
+    1.9929427461615188e+228, 2.6904727073180504e+230, 3.659042881952549e+232, 5.012888748274992e+234,
+    6.917786472619489e+236, 9.615723196941089e+238, 1.3462012475717526e+241, 1.898143759076171e+243,
+    2.695364137888163e+245, 3.854370717180073e+247, 5.5502938327393044e+249, 8.047926057471992e+251,
+    1.1749972043909107e+254, 1.727245890454639e+256, 2.5563239178728654e+258, 3.80892263763057e+260,
+    5.713383956445855e+262, 8.62720977423324e+264, 1.3113358856834524e+267, 2.0063439050956823e+269,
+    3.0897696138473508e+271, 4.789142901463394e+273, 7.471062926282894e+275, 1.1729568794264145e+278,
+    1.853271869493735e+280, 2.9467022724950384e+282, 4.7147236359920616e+284, 7.590705053947219e+286,
+    1.2296942187394494e+289, 2.0044015765453026e+291, 3.287218585534296e+293, 5.423910666131589e+295,
+    9.003691705778438e+297, 1.503616514864999e+300, 2.5260757449731984e+302, 4.269068009004705e+304,
+    7.257415615307999e+306};
+
+/* pmf of x successes in n draws, r successes among N items */
+static double bm_hypergeometric_pdf(int64_t x, int64_t r, int64_t n, int64_t N)
+{
+    const double up[3] = {orc_factorial[r], orc_factorial[N - n], orc_factorial[N - r]};
+    const double down[5] = {orc_factorial[N], orc_factorial[x], orc_factorial[n - x],
+                            orc_factorial[r - x], orc_factorial[N - n - r + x]};
+    double value = orc_factorial[n];
+    int iu = 0, id = 0;
+    while (iu < 3 || id < 5) {
+        for (; id < 5 && (value >= 1 || iu >= 3); ++id)
+            value /= down[id];
+        for (; iu < 3 && (value <= 1 || id >= 5); ++iu)
+            value *= up[iu];
+    }
+    return value;
+}
+/* P(X <= x) (complement == 0) or P(X > x) (complement == 1) */
+static double bm_hypergeometric_cdf(int64_t x, int64_t r, int64_t n, int64_t N, int complement)
+{
+    const double eps = 2.220446049250313e-16;
+    double mode = floor((double)(r + 1) * (double)(n + 1) / (double)(N + 2));
+    double acc = 0, term;
+    if ((double)x < mode) {
+        int64_t floor_x = n + r - N > 0 ? n + r - N : 0;
+        acc = term = bm_hypergeometric_pdf(x, r, n, N);
+        while (term > (complement ? 1.0 : acc) * eps) {
+            term = (double)x * (double)((N + x) - n - r) * term /
+                   ((double)(1 + n - x) * (double)(1 + r - x));
+            acc += term;
+            if (x == floor_x)
+                break;
+            --x;
+        }
+    } else {
+        int64_t cap = r < n ? r : n;
+        complement = !complement;
+        if (x != cap) {
+            ++x;
+            acc = term = bm_hypergeometric_pdf(x, r, n, N);
+            while (x <= cap && term > (complement ? 1.0 : acc) * eps) {
+                term = (double)(n - x) * (double)(r - x) * term /
+                       ((double)(x + 1) * (double)((N + x + 1) - n - r));
+                acc += term;
+                ++x;
+            }
+        }
+    }
+    return complement ? 1 - acc : acc;
+}
+static double clip01(double v) { return v < 0 ? 0 : (v > 1 ? 1 : v); }
+/* scipy.stats.hypergeom.pmf / cdf / sf (k, M, n, N): M items, n good, N drawn */
+static double sp_pmf(int64_t k, int64_t M, int64_t n, int64_t N)
+{
+    int64_t a = N - (M - n) > 0 ? N - (M - n) : 0, b = n < N ? n : N;
+    return (k < a || k > b) ? 0.0 : clip01(bm_hypergeometric_pdf(k, n, N, M));
+}
+static double sp_cdf(int64_t k, int64_t M, int64_t n, int64_t N)
+{
+    int64_t a = N - (M - n) > 0 ? N - (M - n) : 0, b = n < N ? n : N;
+    if (k < a) return 0.0;
+    if (k >= b) return 1.0;
+    return clip01(bm_hypergeometric_cdf(k, n, N, M, 0));
+}
+static double sp_sf(int64_t k, int64_t M, int64_t n, int64_t N)
+{
+    int64_t a = N - (M - n) > 0 ? N - (M - n) : 0, b = n < N ? n : N;
+    if (k < a) return 1.0;
+    if (k >= b) return 0.0;
+    return clip01(bm_hypergeometric_cdf(k, n, N, M, 1));
+}
+/* fisher_exact(..., alternative='two-sided') of [[a, b], [c, d]], non-degenerate margins */
+static double scipy_fisher_two_sided(int64_t a, int64_t b, int64_t c, int64_t d)
+{
+    const int64_t n1 = a + b, n2 = c + d, n = a + c, M = n1 + n2;
+    const int64_t mode = (int64_t)((double)((n + 1) * (n1 + 1)) / (double)(n1 + n2 + 2));
+    const double pexact = sp_pmf(a, M, n1, n), pmode = sp_pmf(mode, M, n1, n);
+    const double gamma = 1 + 1e-14;
+    if (fabs(pexact - pmode) / fmax(pexact, pmode) <= 1e-14)
+        return 1.0;
+    /* _binary_search(f, d, lo, hi): f ascending on [lo, hi] */
+    const int lower_side = a < mode;
+    const double s = lower_side ? -1.0 : 1.0, dval = s * (pexact * gamma);
+    double first;
+    int64_t lo, hi, guess = 0;
+    int found = 0;
+    if (lower_side) {
+        first = sp_cdf(a, M, n1, n);
+        if (sp_pmf(n, M, n1, n) > pexact * gamma)
+            return first;
+        lo = mode;
+        hi = n;
+    } else {
+        first = sp_sf(a - 1, M, n1, n);
+        if (sp_pmf(0, M, n1, n) > pexact * gamma)
+            return first;
+        lo = 0;
+        hi = mode;
+    }
+    while (lo < hi && !found) {
+        int64_t mid = lo + (hi - lo) / 2;
+        double midval = s * sp_pmf(mid, M, n1, n);
+        if (midval < dval)
+            lo = mid + 1;
+        else if (midval > dval)
+            hi = mid - 1;
+        else {
+            guess = mid;
+            found = 1;
+        }
+    }
+    if (!found)
+        guess = s * sp_pmf(lo, M, n1, n) <= dval ? lo : lo - 1;
+    double p = first + (lower_side ? sp_sf(guess, M, n1, n) : sp_cdf(guess, M, n1, n));
+    return p < 1.0 ? p : 1.0;
+}
+
 /* Two-sided Fisher exact p and sample odds ratio of [[a, b], [c, d]]
  * (= [[tpgp, tpgn], [tngp, tngn]], methods.py:842-845). */
 void orc_fisher(int64_t a, int64_t b, int64_t c, int64_t d, double *p_out,
@@ -230,6 +399,10 @@ void orc_fisher(int64_t a, int64_t b, int64_t c, int64_t d, double *p_out,
     }
     *or_out = (c > 0 && b > 0) ? ((double)a * (double)d) / ((double)c * (double)b)
                                : INFINITY;
+    if (n1 + n2 <= ORC_SCIPY_SMALL_N) {          /* SciPy's own double (above) */
+        *p_out = scipy_fisher_two_sided(a, b, c, d);
+        return;
+    }
     int64_t cap = (n < n1 ? n : n1) + 2;
     double *w = (double *)malloc((size_t)cap * sizeof(double));
     int64_t len, lo = hg_weights(n1, n2, n, w, &len);

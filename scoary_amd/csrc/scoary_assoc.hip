@@ -362,6 +362,143 @@ __device__ __forceinline__ bool hg_tie(int n1, int n2, int n, int x, int a) {
   return hg_leq_dd(n1, n2, n, x, a);
 }
 
+// ---- spec S3, N <= 170: SciPy's own double ------------------------------------------------
+// Up to 170 valid isolates scipy.stats.fisher_exact (1.15.3; the arithmetic behind scoary/methods.py:854)
+// evaluates the hypergeometric pmf from a table of factorials and the tails by a term recurrence
+// (Boost.Math: hypergeometric_pdf_factorial_imp / hypergeometric_cdf_imp), all in plain fp64 -- few enough
+// operations to be restated one by one, so for such tables the p-value written to the CSV is the reference's
+// to the last bit (checked against SciPy itself: every table up to N = 18 and 30 000 random ones up to 170,
+// tests/golden/fisher_grid.npz and the exampledata goldens; N = 100 is the reference's own example).  Above
+// 170 Boost switches to a prime factorisation with pow() -- not restated; there the walk above is the p,
+// within 1e-12 (measured 3e-15) of SciPy's.  The rejection region always comes from the walk (exact rule).
+constexpr int kSciPySmallN = 170;
+__constant__ double kFactorial[kSciPySmallN + 1] = {
+    1.0, 1.0, 2.0, 6.0, 24.0, 120.0, 720.0, 5040.0, 40320.0, 362880.0, 3628800.0, 39916800.0, 479001600.0,
+    6227020800.0, 87178291200.0, 1307674368000.0, 20922789888000.0, 355687428096000.0, 6402373705728000.0,
+    1.21645100408832e+17, 2.43290200817664e+18, 5.109094217170944e+19, 1.1240007277776077e+21, 2.585201673888498e+22,
+    6.204484017332394e+23, 1.5511210043330986e+25, 4.0329146112660565e+26, 1.0888869450418352e+28, 3.0488834461171387e+29,
+    8.841761993739702e+30, 2.6525285981219107e+32, 8.222838654177922e+33, 2.631308369336935e+35, 8.683317618811886e+36,
+    2.9523279903960416e+38, 1.0333147966386145e+40, 3.7199332678990125e+41, 1.3763753091226346e+43, 5.230226174666011e+44,
+    2.0397882081197444e+46, 8.159152832478977e+47, 3.345252661316381e+49, 1.40500611775288e+51, 6.041526306337383e+52,
+    2.658271574788449e+54, 1.1962222086548019e+56, 5.502622159812089e+57, 2.5862324151116818e+59, 1.2413915592536073e+61,
+    6.082818640342675e+62, 3.0414093201713376e+64, 1.5511187532873822e+66, 8.065817517094388e+67, 4.2748832840600255e+69,
+    2.308436973392414e+71, 1.2696403353658276e+73, 7.109985878048635e+74, 4.0526919504877214e+76, 2.3505613312828785e+78,
+    1.3868311854568984e+80, 8.32098711274139e+81, 5.075802138772248e+83, 3.146997326038794e+85, 1.98260831540444e+87,
+    1.2688693218588417e+89, 8.247650592082472e+90, 5.443449390774431e+92, 3.647111091818868e+94, 2.4800355424368305e+96,
+    1.711224524281413e+98, 1.1978571669969892e+100, 8.504785885678623e+101, 6.1234458376886085e+103, 4.4701154615126844e+105,
+    3.307885441519386e+107, 2.48091408113954e+109, 1.8854947016660504e+111, 1.4518309202828587e+113, 1.1324281178206297e+115,
+    8.946182130782976e+116, 7.156945704626381e+118, 5.797126020747368e+120, 4.753643337012842e+122, 3.945523969720659e+124,
+    3.314240134565353e+126, 2.81710411438055e+128, 2.4227095383672734e+130, 2.107757298379528e+132, 1.8548264225739844e+134,
+    1.650795516090846e+136, 1.4857159644817615e+138, 1.352001527678403e+140, 1.2438414054641308e+142, 1.1567725070816416e+144,
+    1.087366156656743e+146, 1.032997848823906e+148, 9.916779348709496e+149, 9.619275968248212e+151, 9.426890448883248e+153,
+    9.332621544394415e+155, 9.332621544394415e+157, 9.42594775983836e+159, 9.614466715035127e+161, 9.90290071648618e+163,
+    1.0299016745145628e+166, 1.081396758240291e+168, 1.1462805637347084e+170, 1.226520203196138e+172, 1.324641819451829e+174,
+    1.4438595832024937e+176, 1.588245541522743e+178, 1.7629525510902446e+180, 1.974506857221074e+182, 2.2311927486598138e+184,
+    2.5435597334721877e+186, 2.925093693493016e+188, 3.393108684451898e+190, 3.969937160808721e+192, 4.684525849754291e+194,
+    5.574585761207606e+196, 6.689502913449127e+198, 8.094298525273444e+200, 9.875044200833601e+202, 1.214630436702533e+205,
+    1.506141741511141e+207, 1.882677176888926e+209, 2.372173242880047e+211, 3.0126600184576594e+213, 3.856204823625804e+215,
+    4.974504222477287e+217, 6.466855489220474e+219, 8.47158069087882e+221, 1.1182486511960043e+224, 1.4872707060906857e+226,
+    1.9929427461615188e+228, 2.6904727073180504e+230, 3.659042881952549e+232, 5.012888748274992e+234, 6.917786472619489e+236,
+    9.615723196941089e+238, 1.3462012475717526e+241, 1.898143759076171e+243, 2.695364137888163e+245, 3.854370717180073e+247,
+    5.5502938327393044e+249, 8.047926057471992e+251, 1.1749972043909107e+254, 1.727245890454639e+256, 2.5563239178728654e+258,
+    3.80892263763057e+260, 5.713383956445855e+262, 8.62720977423324e+264, 1.3113358856834524e+267, 2.0063439050956823e+269,
+    3.0897696138473508e+271, 4.789142901463394e+273, 7.471062926282894e+275, 1.1729568794264145e+278, 1.853271869493735e+280,
+    2.9467022724950384e+282, 4.7147236359920616e+284, 7.590705053947219e+286, 1.2296942187394494e+289,
+    2.0044015765453026e+291, 3.287218585534296e+293, 5.423910666131589e+295, 9.003691705778438e+297, 1.503616514864999e+300,
+    2.5260757449731984e+302, 4.269068009004705e+304, 7.257415615307999e+306};
+// Boost's pmf of x successes among n draws from N items of which r are successes: the quotient of
+// factorials multiplied up and divided down so that the running value stays near 1
+__device__ __noinline__ double bm_pdf(int x, int r, int n, int N) {
+  double v = kFactorial[n];
+  int i = 0, j = 0;
+  while (i < 3 || j < 5) {
+    while (j < 5 && (v >= 1.0 || i >= 3)) {
+      v /= kFactorial[j == 0 ? N : j == 1 ? x : j == 2 ? n - x : j == 3 ? r - x : N - n - r + x];
+      ++j;
+    }
+    while (i < 3 && (v <= 1.0 || j >= 5)) {
+      v *= kFactorial[i == 0 ? r : i == 1 ? N - n : N - r];
+      ++i;
+    }
+  }
+  return v;
+}
+// Boost's lower tail P(X <= x) (upper == false) or upper tail P(X > x) (true): terms added from x
+// towards the nearer end of the support until they no longer count, the far side as 1 - sum
+__device__ __noinline__ double bm_tail(int x, int r, int n, int N, bool upper) {
+  constexpr double kEps = 2.220446049250313e-16;
+  const double mode = floor((double)(r + 1) * (double)(n + 1) / (double)(N + 2));
+  double sum = 0.0;
+  bool invert = upper;
+  if ((double)x < mode) {
+    sum = bm_pdf(x, r, n, N);
+    double term = sum;
+    const int lower = max(0, n + r - N);
+    while (term > (invert ? 1.0 : sum) * kEps) {
+      term = (double)x * (double)(N + x - n - r) * term / ((double)(1 + n - x) * (double)(1 + r - x));
+      sum += term;
+      if (x == lower) break;
+      --x;
+    }
+  } else {
+    invert = !invert;
+    const int top = min(r, n);
+    if (x != top) {
+      ++x;
+      sum = bm_pdf(x, r, n, N);
+      double term = sum;
+      while (x <= top && term > (invert ? 1.0 : sum) * kEps) {
+        term = (double)(n - x) * (double)(r - x) * term / ((double)(x + 1) * (double)(N + x + 1 - n - r));
+        sum += term;
+        ++x;
+      }
+    }
+  }
+  return invert ? 1.0 - sum : sum;
+}
+// scipy.stats.hypergeom's pmf / cdf / sf around them (support checks, clip to [0, 1]) and fisher_exact's
+// two-sided rule (scipy/stats/_stats_py.py): the tail on the observed side plus the tail beyond the point
+// a binary search over the pmf finds on the other side
+struct SciPyHypergeom {
+  int M, good, draws, lo, hi;
+  __device__ SciPyHypergeom(int M_, int good_, int draws_)
+      : M(M_), good(good_), draws(draws_), lo(max(draws_ - (M_ - good_), 0)), hi(min(good_, draws_)) {}
+  __device__ static double clip(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+  __device__ double pmf(int k) const { return (k < lo || k > hi) ? 0.0 : clip(bm_pdf(k, good, draws, M)); }
+  __device__ double cdf(int k) const { return k < lo ? 0.0 : (k >= hi ? 1.0 : clip(bm_tail(k, good, draws, M, false))); }
+  __device__ double sf(int k) const { return k < lo ? 1.0 : (k >= hi ? 0.0 : clip(bm_tail(k, good, draws, M, true))); }
+};
+__device__ __noinline__ double scipy_small_p(int a, int b, int c, int d) {
+  const int n1 = a + b, n2 = c + d, n = a + c;
+  const SciPyHypergeom h(n1 + n2, n1, n);
+  const int mode = (int)(((double)(n + 1) * (double)(n1 + 1)) / (double)(n1 + n2 + 2));
+  const double pexact = h.pmf(a), pmode = h.pmf(mode);
+  if (fabs(pexact - pmode) / fmax(pexact, pmode) <= 1e-14) return 1.0;
+  const double target = pexact * kGamma;
+  // _binary_search(f, target, lo, hi) on f = -pmf (a < mode: the descending side) or pmf (ascending side)
+  const bool below = a < mode;
+  if (below ? h.pmf(n) > target : h.pmf(0) > target) return below ? h.cdf(a) : h.sf(a - 1);
+  const double sign = below ? -1.0 : 1.0, want = sign * target;
+  int lo = below ? mode : 0, hi = below ? n : mode, guess;
+  bool hit = false;
+  while (lo < hi) {
+    const int mid = lo + (hi - lo) / 2;
+    const double f = sign * h.pmf(mid);
+    if (f < want) {
+      lo = mid + 1;
+    } else if (f > want) {
+      hi = mid - 1;
+    } else {
+      guess = mid;
+      hit = true;
+      break;
+    }
+  }
+  if (!hit) guess = sign * h.pmf(lo) <= want ? lo : lo - 1;
+  const double p = below ? h.cdf(a) + h.sf(guess) : h.sf(a - 1) + h.cdf(guess);
+  return p < 1.0 ? p : 1.0;
+}
+
 // A lane PAIR per table: the even lane sums the weights from the mode upwards, the odd lane
 // those below the mode.  A downward walk is an upward walk in the mirrored coordinates
 // x' = n - x with the two margins swapped -- the oracle's downward step
@@ -478,7 +615,8 @@ __global__ __launch_bounds__(64) void k_fisher(const int4* __restrict__ tables, 
   const int Hc = first >= 0 ? first : hi + 1;          // region bounds in the canonical coordinate
   const int Lc = other >= 0 ? n - other : lo - 1;
   const bool all = (Hc == mode);
-  const double p = all ? 1.0 : inc / tot;
+  double p = all ? 1.0 : inc / tot;
+  if (n1 + n2 <= kSciPySmallN) p = scipy_small_p(c.x, b, cc, d);   // the reference's own double (above)
   p_out[idx] = p < 1.0 ? p : 1.0;
   const int L = mirrored ? n1 - Hc : Lc, H = mirrored ? n1 - Lc : Hc;   // ... and in the table's own a
   const uint32_t base = (uint32_t)(L + 1), span = all ? 0u : (uint32_t)(H - L - 1);

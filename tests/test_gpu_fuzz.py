@@ -203,6 +203,9 @@ def compare_case(case, got):
         values = values * len(methods)
     cutoffs = [(METHOD_COLUMN[m_], v) for m_, v in zip(methods, values)]
     for fn in sorted(ref["files"]):
+        if case["N"] <= 170 and got["files"][fn] != ref["files"][fn]:
+            # at most 170 isolates: k_fisher returns SciPy's own double (spec S3), so the file is the reference's
+            diffs.append("%s: not byte-identical although N <= 170" % fn)
         d = compare_csv(got["files"][fn], ref["files"][fn], delimiter, cutoffs, "-m" in argv,
                         woven="--threads" in argv and "--no_pairwise" not in argv,
                         by_pairs="--no_pairwise" not in argv and not {"I", "B", "BH"} & set(methods))

@@ -233,6 +233,42 @@ def test_fisher_vs_oracle_and_rejection_region(eng, orc):
             assert in_region == (px <= o_p[k] * (1 + 1e-9)), (tabs[k], x, base, span)
 
 
+def test_fisher_small_populations_equal_scipy_bit_for_bit(eng, orc):
+    """N <= 170: k_fisher returns SciPy's own double (spec S3; the golden grid and the reference's exampledata
+    p-values directly, every table up to N = 14 and random ones up to 170 through the pinned oracle); the
+    region is still the exact rule's."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "fisher_grid.npz"))
+    tabs, gp = z["tables"].astype(np.int32), z["p"]
+    small = tabs.sum(1) <= 170
+    p, _, _ = eng.fisher(torch.from_numpy(tabs[small]).cuda())
+    assert np.array_equal(p.cpu().numpy().view(np.uint64), gp[small].view(np.uint64))
+    for f, nt in (("setup_results_exampledata.npz", 2), ("setup_results_collapse.npz", 1),
+                  ("setup_results_restrict.npz", 2), ("setup_results_vcf.npz", 1)):
+        g = np.load(os.path.join(GOLDEN, f))
+        for ti in range(nt):
+            c = g["t%d_counts" % ti].astype(np.int32)
+            p, _, _ = eng.fisher(torch.from_numpy(c).cuda(), want_crit=False)
+            assert np.array_equal(p.cpu().numpy().view(np.uint64), g["t%d_p_v" % ti].view(np.uint64)), (f, ti)
+    rng = np.random.default_rng(171)
+    tabs = [(a, n1 - a, n - a, N - n1 - n + a) for N in range(2, 15) for n1 in range(1, N) for n in range(1, N)
+            for a in range(max(0, n - (N - n1)), min(n, n1) + 1)]
+    for N in (15, 33, 64, 101, 150, 169, 170):
+        for _ in range(400):
+            n1 = int(rng.integers(1, N)); n = int(rng.integers(1, N))
+            a = int(rng.integers(max(0, n - (N - n1)), min(n, n1) + 1))
+            tabs.append((a, n1 - a, n - a, N - n1 - n + a))
+    tabs = np.array(tabs, dtype=np.int32)
+    p, _, crit = eng.fisher(torch.from_numpy(tabs).cuda())
+    _, o_p = orc.fisher_many(tabs)
+    assert np.array_equal(p.cpu().numpy().view(np.uint64), o_p.view(np.uint64))
+    # N = 171 is the first population on the other side: the walk's p, within the tolerance
+    t171 = np.array([(30, 40, 50, 51), (1, 69, 99, 2), (35, 35, 50, 51)], dtype=np.int32)
+    p, _, _ = eng.fisher(torch.from_numpy(t171).cuda())
+    _, o_p = orc.fisher_many(t171)
+    assert np.max(np.abs(p.cpu().numpy() - o_p) / o_p) < 1e-11
+
+
 def test_fisher_of_a_gene_and_of_its_complement_are_the_same_double(eng, orc):
     """[[a, b], [c, d]] and [[b, a], [d, c]] (a gene / the complementary gene under one trait): the same
     p bit for bit -- as SciPy returns for tables beyond its factorial table (N > 170), which is what keeps
@@ -241,7 +277,7 @@ def test_fisher_of_a_gene_and_of_its_complement_are_the_same_double(eng, orc):
     import torch
     rng = np.random.default_rng(77)
     tabs = []
-    for N in (7, 64, 100, 171, 500, 2000, 9000):
+    for N in (171, 300, 500, 2000, 9000):               # (up to 170 the p is SciPy's, mirror noise included)
         for _ in range(120):
             n1 = int(rng.integers(1, N)); n = int(rng.integers(1, N))
             lo, hi = max(0, n - (N - n1)), min(n, n1)
