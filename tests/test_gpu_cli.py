@@ -654,3 +654,42 @@ def test_cli_wide_table_takes_the_segmented_list_path(tmp_path, caplog):
             assert abs(float(d[col["Naive_p"]]) - p[g]) <= 1e-12 + 1e-11 * p[g]
             assert d[col["Empirical_p"]] == repr((float(r[g, t]) + 1.0) / (P + 1.0))
         assert seen == set(keep)
+
+
+def test_small_population_result_files_are_the_references_bytes(exampledir, synth2dir, tmp_path):
+    """Up to 170 valid isolates k_fisher returns SciPy's own double (spec S3), so every file the reference wrote for
+    its example data (N = 100; -r: 46) and for the second data set (N = 52) comes out of our command line BYTE FOR
+    BYTE -- p-values, their corrections, the order of tied rows, the pairwise columns, the tree: --no_pairwise (four
+    flag sets), the pairwise stage (three), --collapse, -r / -w / --include_input_columns, ';' and -m."""
+    ex = _inputs(exampledir)
+    runs = [(ex + ["--no_pairwise", "-p", "1.0"], "csv_no_pairwise"),
+            (ex + ["--no_pairwise"], "csv_no_pairwise_default"),
+            (ex + ["--no_pairwise", "--collapse", "-c", "I", "BH", "-p", "0.05", "0.01", "-m", "50"],
+             "csv_no_pairwise_collapse_bh"),
+            (ex + ["--no_pairwise", "-r", os.path.join(exampledir, "Restrict_to.csv")], "csv_no_pairwise_restrict"),
+            (ex + ["-u"], "csv_pairwise_default"),
+            (ex + ["-c", "I", "EPW", "-p", "0.05", "0.05"], "csv_pairwise_epw"),
+            (ex + ["-c", "BH", "PW", "-p", "0.9", "0.05", "-m", "300"], "csv_pairwise_bh_pw")]
+    s2 = ["-g", os.path.join(synth2dir, "gpa.csv"), "-t", os.path.join(synth2dir, "traits.csv")]
+    restrict = os.path.join(synth2dir, "restrict.csv")
+    with open(restrict, "w") as f:
+        f.write(golden_text("synth2/restrict.csv.gz"))
+    for name in ("gpa_semi.csv", "traits_semi.csv"):
+        with open(os.path.join(synth2dir, name), "w", newline="") as f:
+            f.write(golden_text("synth2/%s.gz" % name))
+    runs += [(s2 + ["--no_pairwise", "-p", "1.0"], "synth2/no_pairwise"),
+             (s2 + ["--no_pairwise", "--collapse", "-c", "I", "B", "-p", "0.5", "1.0"], "synth2/collapse"),
+             (s2 + ["-u", "-c", "I", "EPW", "-p", "0.3", "1.0"], "synth2/pairwise"),
+             (s2 + ["--no_pairwise", "-p", "1.0", "-r", restrict, "-w", "--include_input_columns", "4,6-7"],
+              "synth2/restrict_w"),
+             (["-g", os.path.join(synth2dir, "gpa_semi.csv"), "-t", os.path.join(synth2dir, "traits_semi.csv"),
+               "--no_pairwise", "-p", "0.2", "--delimiter", ";", "-m", "40"], "synth2/semicolon")]
+    differing, files_checked = [], 0
+    for k, (argv, sub) in enumerate(runs):
+        files = run_cli(argv, tmp_path / ("run%d" % k))
+        assert files
+        for fn, text in files.items():
+            files_checked += 1
+            if text != golden_text("%s/%s.gz" % (sub, fn)):
+                differing.append("%s/%s" % (sub, fn))
+    assert not differing and files_checked >= 29, differing
