@@ -19,6 +19,7 @@ import argparse
 import csv
 import logging
 import os
+import re
 import sys
 import time as _time
 from collections.abc import Mapping
@@ -333,6 +334,15 @@ def _warm_up(eng):
 # ---------------------------------------------------------------------------
 # Readers
 # ---------------------------------------------------------------------------
+def _is_roary_file(path, delimiter):
+    """Does the table's header start with Roary's three columns (methods.py:373-376)?"""
+    try:
+        with open(path, "r") as f:
+            return next(csv.reader(f, skipinitialspace=True, delimiter=delimiter))[0:3] == ROARY_HEAD
+    except (OSError, StopIteration, UnicodeError):
+        return True
+
+
 def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolates=None,
                      writereducedset=False, time="", outdir="./"):
     """Read a Roary-style gene presence/absence table (methods.py:335-508).
@@ -381,9 +391,16 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
             if "startcol" in str(e):
                 sys.exit("The startcol (-s) you have specified does not seem to correspond to "
                          "any column in your gene presence/absence file.")
+            # the reference's two messages (methods.py:447-462): a data row too short to hold its
+            # identifier cells ends a Roary table with the first, a plain table with the second;
+            # the reader's own description of the row goes to the log, not into the message
+            log.debug("gene presence absence reader: %s" % e)
+            short = re.search(r"row \d+ has (\d+) cells", str(e))
+            if short and int(short.group(1)) < 3 and not _is_roary_file(path, delimiter):
+                sys.exit("CRITICAL: Could not properly assign column. Please report this bug.")
             sys.exit("CRITICAL: Could not read gene presence absence file. Verify that this "
                      "file is a proper Roary file using the specified delimiter (default is "
-                     "','). [%s]" % e)
+                     "',').")
     else:
         reader = csv.reader(genefile, skipinitialspace=True, delimiter=delimiter)
         header = next(reader)
@@ -445,6 +462,8 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
             meta = (q[nugcol], q[anncol])
             grabbed = [q[c] for c in grabcols]
         except IndexError:
+            if not roary:
+                sys.exit("CRITICAL: Could not properly assign column. Please report this bug.")
             sys.exit("CRITICAL: Could not read gene presence absence file. Verify that this "
                      "file is a proper Roary file using the specified delimiter (default is ',').")
         if ident in index:

@@ -22,6 +22,9 @@ What the generator varies (seeded; the case list is a pure function of SEED):
   * flags: --no_pairwise or the pairwise stage (-u), -c subsets with one or matching -p lists,
     -m, --collapse, -r (+ -w), --include_input_columns, --threads;
   * inputs the reference refuses (sys.exit with a message): kept with the message.
+Every case also records what the reference's two READERS (Csv_to_dic_Roary, Csv_to_dic) return for its tables
+written in five ways -- as they are, with Windows line ends, behind a byte-order mark, with a blank last line,
+without a final newline -- as digests (tests/test_readers_fuzz.py, no GPU needed: the readers are host code).
 Cases on which the reference itself raises anything but SystemExit are dropped (counted in the
 manifest entry): there is no behaviour to be compatible with.
 """
@@ -284,6 +287,98 @@ def run_reference(case):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+READER_VARIANTS = ("plain", "crlf", "bom", "trailing_blank", "no_final_newline")
+
+
+def reader_variant(text, variant):
+    """The same table as another file: Windows line ends, a byte-order mark, a blank last line, no final
+    newline.  (The command line opens its inputs in text mode with universal newlines, methods.py:192-193.)"""
+    if variant == "crlf":
+        return text.replace("\n", "\r\n")
+    if variant == "bom":
+        return "\ufeff" + text
+    if variant == "trailing_blank":
+        return text + "\n"
+    if variant == "no_final_newline":
+        return text.rstrip("\n")
+    return text
+
+
+def reader_args(case):
+    """(delimiter, startcol, grabcols, allowed isolates) as main() derives them from the flags."""
+    argv = case["argv"]
+    delimiter = ";" if "--delimiter" in argv else ","
+    startcol = (int(argv[argv.index("-s") + 1]) if "-s" in argv else 15) - 1
+    grab = []
+    if "--include_input_columns" in argv:
+        grab = rm.grabcoltype(argv[argv.index("--include_input_columns") + 1])
+        if grab == "ALL":
+            grab = [-999]
+    allowed = None
+    if case["restrict"]:
+        allowed = {iso: "all" for line in case["restrict"].splitlines(True) for iso in line.rstrip().split(",")}
+    return delimiter, startcol, grab, allowed
+
+
+def normalise_gene_table(res):
+    """What Csv_to_dic_Roary returns, as plain JSON-able data."""
+    g = res["Roarydic"]
+    return {"ids": list(g.keys()), "strains": list(res["Strains"]), "extracols": list(res["Extracols"]),
+            "first": list(res["Firstcolnames"]), "zom": [[int(x) for x in r] for r in res["Zero_ones_matrix"]],
+            "rows": {k: {a: (int(b) if not isinstance(b, str) else b) for a, b in dict(g[k]).items()}
+                     for k in g.keys()}}
+
+
+def digest(obj):
+    import hashlib
+    return hashlib.sha256(json.dumps(obj, sort_keys=True).encode()).hexdigest()[:24]
+
+
+def call_reader(fn, path, *a, **k):
+    """-> ("ok", value) | ("exit", message) | ("crash", exception name)"""
+    try:
+        with open(path, "r") as f, quiet():
+            return "ok", fn(f, *a, **k)
+    except SystemExit as e:
+        return "exit", str(e.code)
+    except BaseException as e:
+        return "crash", type(e).__name__
+
+
+def reader_records(case, methods_module):
+    """{variant: {"genes": digest | ["exit", message] | None, "traits": ...}} -- what the two readers of
+    `methods_module` (the reference's here; scoary_amd's in tests/test_readers_fuzz.py) make of the case's
+    tables written in each variant.  None = the reference itself crashed (nothing to compare)."""
+    delimiter, startcol, grab, allowed = reader_args(case)
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="fuzzrd_")
+    try:
+        for v in READER_VARIANTS:
+            pg, pt = os.path.join(tmp, v + "_g.csv"), os.path.join(tmp, v + "_t.csv")
+            with open(pg, "w", newline="", encoding="utf-8") as f:
+                f.write(reader_variant(case["gpa"], v))
+            with open(pt, "w", newline="", encoding="utf-8") as f:
+                f.write(reader_variant(case["traits"], v))
+            st, val = call_reader(methods_module.Csv_to_dic_Roary, pg, delimiter, list(grab), startcol=startcol,
+                                  allowed_isolates=allowed)
+            rec = {"genes": None, "traits": None}
+            if st == "ok":
+                table = normalise_gene_table(val)
+                rec["genes"] = digest(table)
+                st2, val2 = call_reader(methods_module.Csv_to_dic, pt, delimiter, allowed, table["strains"])
+                if st2 == "ok":
+                    rec["traits"] = digest([{k: dict(x) for k, x in dict(val2[0]).items()},
+                                            {k: list(x) for k, x in dict(val2[1]).items()}])
+                elif st2 == "exit":
+                    rec["traits"] = ["exit", val2]
+            elif st == "exit":
+                rec["genes"] = ["exit", val]
+            out[v] = rec
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def main():
     rng = np.random.default_rng(SEED)
     cases, crashed = [], []
@@ -296,6 +391,7 @@ def main():
             crashed.append({"id": case["id"], "message": ref["message"][:200]})
             continue
         case["ref"] = ref
+        case["readers"] = reader_records(case, rm)
         cases.append(case)
     doc = {"seed": SEED, "generated": k, "kept": len(cases), "reference_crashes": crashed, "cases": cases}
     path = os.path.join(HERE, "fuzz_corpus.json.gz")
