@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libscoary_io.so")
+# SCOARY_IO_LIB: another build of the same source (tools/sanitize_io.sh: AddressSanitizer / UBSan on the CPU)
+LIB_PATH = os.environ.get("SCOARY_IO_LIB") or os.path.join(_HERE, "csrc", "libscoary_io.so")
 _lib = None
 
 

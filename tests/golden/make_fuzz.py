@@ -43,8 +43,8 @@ import numpy as np
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-SEED = 20261001
-NCASES = 200
+SEED = int(os.environ.get("FUZZ_SEED", "20261001"))        # the committed corpus: the defaults
+NCASES = int(os.environ.get("FUZZ_NCASES", "200"))          # FUZZ_SEED / FUZZ_NCASES / FUZZ_OUT: one-off extra corpora
 
 sys.path.insert(0, REF)
 import scipy.stats as ss  # noqa: E402
@@ -394,7 +394,7 @@ def main():
         case["readers"] = reader_records(case, rm)
         cases.append(case)
     doc = {"seed": SEED, "generated": k, "kept": len(cases), "reference_crashes": crashed, "cases": cases}
-    path = os.path.join(HERE, "fuzz_corpus.json.gz")
+    path = os.environ.get("FUZZ_OUT") or os.path.join(HERE, "fuzz_corpus.json.gz")
     with open(path, "wb") as raw:
         with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, filename="") as g:
             g.write(json.dumps(doc, sort_keys=True).encode())

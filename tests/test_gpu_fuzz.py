@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 
 
 def load_corpus():
-    with gzip.open(os.path.join(GOLDEN, "fuzz_corpus.json.gz"), "rt") as f:
+    # SCOARY_FUZZ_CORPUS: another corpus of the same generator (tools/fuzz_report.py on one-off extra seeds)
+    with gzip.open(os.environ.get("SCOARY_FUZZ_CORPUS") or os.path.join(GOLDEN, "fuzz_corpus.json.gz"), "rt") as f:
         return json.load(f)
 
 
