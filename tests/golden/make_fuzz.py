@@ -43,8 +43,10 @@ import numpy as np
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-SEED = int(os.environ.get("FUZZ_SEED", "20261001"))        # the committed corpus: the defaults
-NCASES = int(os.environ.get("FUZZ_NCASES", "200"))          # FUZZ_SEED / FUZZ_NCASES / FUZZ_OUT: one-off extra corpora
+# the committed corpus: the defaults.  FUZZ_SEED / FUZZ_NCASES / FUZZ_NS / FUZZ_OUT: one-off extra corpora
+SEED = int(os.environ.get("FUZZ_SEED", "20261001"))
+NCASES = int(os.environ.get("FUZZ_NCASES", "200"))
+NS = [int(x) for x in os.environ.get("FUZZ_NS", "4,5,7,12,20,33,48,64,65,70,180,256,400").split(",")]   # isolates
 
 sys.path.insert(0, REF)
 import scipy.stats as ss  # noqa: E402
@@ -98,7 +100,7 @@ def write_table(rows, delimiter, quote_all=False):
 
 
 def make_case(rng, k):
-    N = int(rng.choice([4, 5, 7, 12, 20, 33, 48, 64, 65, 70, 180, 256, 400]))
+    N = int(rng.choice(NS))
     G = int(rng.choice([1, 2, 5, 17, 40, 40, 90, 90, 150]))
     if N > 170:
         # beyond SciPy's factorial table a gene and its complement get the SAME double (below: a coin flip),
@@ -381,7 +383,7 @@ def reader_records(case, methods_module):
 
 def main():
     rng = np.random.default_rng(SEED)
-    cases, crashed = [], []
+    cases, crashed, crash_cases = [], [], []
     k = 0
     while len(cases) < NCASES and k < 4 * NCASES:
         case = make_case(rng, k)
@@ -389,11 +391,16 @@ def main():
         ref = run_reference(case)
         if ref["status"] == "crash":
             crashed.append({"id": case["id"], "message": ref["message"][:200]})
+            if os.environ.get("FUZZ_KEEP_CRASHES") == "1":       # one-off corpora: what does OUR command line do there?
+                case["ref"] = ref
+                crash_cases.append(case)
             continue
         case["ref"] = ref
         case["readers"] = reader_records(case, rm)
         cases.append(case)
     doc = {"seed": SEED, "generated": k, "kept": len(cases), "reference_crashes": crashed, "cases": cases}
+    if crash_cases:
+        doc["crash_cases"] = crash_cases
     path = os.environ.get("FUZZ_OUT") or os.path.join(HERE, "fuzz_corpus.json.gz")
     with open(path, "wb") as raw:
         with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, filename="") as g:

@@ -39,6 +39,22 @@ def main():
             for d in diffs:
                 print("      " + d[:6000], file=out)
     print("%d of %d cases differ from the reference" % (bad, len(tf.CORPUS["cases"])), file=out)
+    # inputs on which the REFERENCE raises something other than SystemExit (kept by FUZZ_KEEP_CRASHES=1 corpora): there is
+    # no behaviour to match; listed is what this command line does with them (it must end, one way or the other)
+    tally = {}
+    for case in tf.CORPUS.get("crash_cases", []):
+        tmp = tempfile.mkdtemp(prefix="fuzzrun_")
+        sink = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+                got = tf.run_case(case, tmp)
+            what = "completes" if got["status"] == "ok" else "exits: " + str(got["message"])[:70]
+        except BaseException as e:
+            what = "raises " + type(e).__name__ + ": " + str(e)[:60]
+        key = (case["ref"]["message"][:60], what)
+        tally[key] = tally.get(key, 0) + 1
+    for (ref_msg, what), n in sorted(tally.items(), key=lambda kv: -kv[1]):
+        print("reference crashes with %-62s x %3d -> ours %s" % (ref_msg, n, what), file=out)
     out.flush()
 
 
