@@ -896,6 +896,9 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
         testable = ((c[:, 0] + c[:, 2]) != 0) & ((c[:, 1] + c[:, 3]) != 0)
         number_of_tests = G - int((~testable).sum())
         idx = np.nonzero(testable)[0]
+        if len(idx) == 0:
+            # (the reference falls over here too: IndexError from its empty sort list, scoary/methods.py:903-925)
+            raise IndexError("Trait %s has no testable genes" % trait)
         p_all, or_all = dev["p"][t], dev["odds"][t]
         emp = None
         if dev["r"] is not None:
@@ -947,8 +950,6 @@ def Setup_results(genedic, traitsdic, collapse, permutations=0, seed=DEFAULT_SEE
         with np.errstate(divide="ignore", invalid="ignore"):
             sens = np.where(num_pos > 0, cc[:, 0].astype(np.float64) / num_pos * 100, 0.0)
             spes = np.where(num_neg > 0, cc[:, 3].astype(np.float64) / num_neg * 100, 0.0)
-        if len(rows_idx) == 0:
-            raise IndexError("Trait %s has no testable genes" % trait)
         # stable ascending order of the testable genes' p: from the device if it came along
         p_order = dev["p_order"][t] if dev.get("p_order") is not None else None
         if not collapse:

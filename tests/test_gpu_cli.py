@@ -660,7 +660,7 @@ def test_small_population_result_files_are_the_references_bytes(exampledir, synt
     """Up to 170 valid isolates k_fisher returns SciPy's own double (spec S3), so every file the reference wrote for
     its example data (N = 100; -r: 46) and for the second data set (N = 52) comes out of our command line BYTE FOR
     BYTE -- p-values, their corrections, the order of tied rows, the pair counts: --no_pairwise (four flag sets),
-    the pairwise stage (three; its two binomial p columns to 1e-14, see below), --collapse, -r / -w /
+    the pairwise stage (three; its two binomial p columns are SciPy's doubles too), --collapse, -r / -w /
     --include_input_columns, ';' and -m."""
     ex = _inputs(exampledir)
     runs = [(ex + ["--no_pairwise", "-p", "1.0"], "csv_no_pairwise"),
@@ -692,21 +692,8 @@ def test_small_population_result_files_are_the_references_bytes(exampledir, synt
         for fn, text in files.items():
             files_checked += 1
             want = golden_text("%s/%s.gz" % (sub, fn))
-            if text == want:
-                continue
-            # The two pairwise p-value columns are exact binomial tails, dyadic rationals such as 9888 / 2^15 =
-            # 0.3017578125 -- which is what we print -- where SciPy's binomtest (incomplete-beta arithmetic behind
-            # the reference's ss.binom_test, scoary/methods.py:1267) returns 0.30175781249999994: those two cells
-            # are held to 1e-14 relative, every other byte of the pairwise files to equality.
-            g, w = text.split("\n"), want.split("\n")
-            ok = "pairwise" in sub and "no_pairwise" not in sub and len(g) == len(w)
-            for a, b in zip(g, w):
-                if not ok or a == b:
-                    continue
-                ca, cb = a.rsplit(",", 2), b.rsplit(",", 2)
-                ok = ca[0] == cb[0] and all(
-                    abs(float(x.strip('"')) - float(y.strip('"'))) <= 1e-14 * float(y.strip('"'))
-                    for x, y in zip(ca[1:], cb[1:]))
-            if not ok:
+            # (the two binomial p columns of the pairwise files included: tree.binom_two_sided restates the arithmetic
+            # behind the reference's ss.binom_test -- 0.30175781249999994 where the exact tail is 0.3017578125)
+            if text != want:
                 differing.append("%s/%s" % (sub, fn))
     assert not differing and files_checked >= 29, differing

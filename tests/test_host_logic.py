@@ -878,3 +878,36 @@ def test_usable_cpus_honours_affinity_and_cgroup_quota(monkeypatch):
     assert sb.usable_cpus() == 64
     monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "50000 100000\n"}))
     assert sb.usable_cpus() == 1                               # half a CPU still runs one worker
+
+
+# ------------------------------------------------- binomial test of the pairwise stage ---
+def test_binomial_p_is_scipys_double():
+    """The two binomial p columns of the pairwise stage (ss.binom_test(x, n, 0.5), scoary/methods.py:1267-1275):
+    tree._boost_binom_tail_half restates Boost's finite sum behind scipy.stats.binom.cdf / .sf -- equal to SciPy
+    bit for bit wherever it applies (every n <= 78, the tails beyond) --, and tree.binom_two_sided is
+    scipy.stats.binomtest(x, n, 0.5).pvalue to the last bit for every n <= 85 (tables of at most 170 isolates, whose
+    result files are held to the reference's bytes), within 1e-12 beyond (the exact dyadic tail there; SciPy's own
+    value is 1e-13 off it in the far tail of n = 1500)."""
+    import scipy.stats as ss
+    from scoary_amd import tree as T
+    covered = 0
+    for n in list(range(1, 131)) + [170, 233, 300]:
+        ks = np.arange(-1, n + 2)
+        cdf, sf = ss.binom.cdf(ks, n, 0.5), ss.binom.sf(ks, n, 0.5)
+        for j, k in enumerate(ks):
+            for upper, want in ((False, cdf[j]), (True, sf[j])):
+                got = T._boost_binom_tail_half(int(k), n, upper)
+                if got is not None:
+                    covered += 1
+                    assert got == want, (k, n, upper, repr(got), repr(float(want)))
+        if n <= 78:
+            assert all(T._boost_binom_tail_half(k, n, u) is not None for k in range(n + 1) for u in (False, True))
+    assert covered > 15000
+    assert T.binom_two_sided(5, 15) == 0.30175781249999994 and T.binom_two_sided(25, 25) == 5.960464477539063e-08
+    for n in range(1, 86):
+        for x in range(n + 1):
+            assert T.binom_two_sided(x, n) == ss.binomtest(x, n, 0.5).pvalue, (x, n)
+    for n in (86, 99, 128, 257, 1000, 1500):
+        for x in range(0, n + 1, 1 if n < 130 else 37):
+            want = ss.binomtest(x, n, 0.5).pvalue
+            assert abs(T.binom_two_sided(x, n) - want) <= 1e-12 * want, (x, n)

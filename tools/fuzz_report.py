@@ -51,6 +51,8 @@ def main():
             what = "completes" if got["status"] == "ok" else "exits: " + str(got["message"])[:70]
         except BaseException as e:
             what = "raises " + type(e).__name__ + ": " + str(e)[:60]
+            where = " | ".join(l.strip() for l in traceback.format_exc().strip().splitlines()[-9:-1] if "File" in l)
+            print("crash case %d (%s): %s @ %s" % (case["id"], " ".join(case["argv"]), what, where), file=out)
         key = (case["ref"]["message"][:60], what)
         tally[key] = tally.get(key, 0) + 1
     for (ref_msg, what), n in sorted(tally.items(), key=lambda kv: -kv[1]):

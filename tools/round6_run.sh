@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box sessions collecting the round-6 evidence (outputs under gpurun_out/r06/).
-#   tools/round6_run.sh [part ...]     parts: tests bench driver balance rank8 e2e k1 xcd tree treepmc pairwise cfg5cli seg profiles timeline soak curve
+#   tools/round6_run.sh [part ...]     parts: tests bench driver balance rank8 e2e k1 xcd tree treepmc pairwise cfg5cli seg profiles timeline soak curve fuzzextra longsoak
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r06
 mkdir -p $O
@@ -121,6 +121,24 @@ if has curve; then
 python tools/strong_curve.py > $O/strong_curve.txt 2>&1
 python tools/strong_curve.py --configs cfg3 --gene-order sorted > $O/strong_curve_cfg3_sorted.txt 2>&1
 grep -v "^JSON" $O/strong_curve.txt $O/strong_curve_cfg3_sorted.txt
+fi
+if has fuzzextra; then
+# one-off extra corpora of tests/golden/make_fuzz.py (other seeds, wider tables, the inputs the reference crashes on),
+# generated in the build container into _ab/fuzz/ (git-ignored; they travel with the snapshot)
+for c in _ab/fuzz/*.json.gz; do
+  n=$(basename $c .json.gz)
+  SCOARY_FUZZ_CORPUS=$PWD/$c timeout 900 python tools/fuzz_report.py $O/fuzz_$n.txt > $O/fuzz_$n.log 2>&1
+  echo "$n: $(grep 'cases differ' $O/fuzz_$n.txt)"
+  grep "^reference crashes" $O/fuzz_$n.txt | head -40
+done
+fi
+if has longsoak; then
+# new cases of the five randomised cross-checks (case numbers 600 ... : the generator is seeded by the case number)
+for t in lists tiles listbuild seglists counts; do
+  timeout ${SOAK_SECONDS:-240} python tools/stress_$t.py 100000 600 > $O/longsoak_$t.log 2>&1
+  echo "$t rc=$? (124 = stopped by the clock) cases $(grep -c ' ok$' $O/longsoak_$t.log) ok, $(grep -c MISMATCH $O/longsoak_$t.log) mismatching" >> $O/longsoak.txt
+done
+cat $O/longsoak.txt
 fi
 if has soak; then
 for t in lists tiles listbuild seglists counts; do

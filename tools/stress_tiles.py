@@ -1,7 +1,7 @@
 """Longer soak of tests/stress_cases.py::tiles_case on a GPU box (the first cases are what
 `pytest -m gpu` runs as tests/test_gpu_stress.py).
 
-    python tools/stress_tiles.py [cases]
+    python tools/stress_tiles.py [cases] [first case]
 """
 import os
 import sys
@@ -13,8 +13,9 @@ from scoary_amd.engine import AssociationEngine  # noqa: E402
 
 eng = AssociationEngine(0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # cases are seeded by their number: a later range = new cases
 bad = 0
-for case in range(cases):
+for case in range(first, first + cases):
     ok, what = sc.tiles_case(eng, case)
     bad += not ok
     print(case, what, "ok" if ok else "MISMATCH")
