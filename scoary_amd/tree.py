@@ -218,6 +218,11 @@ class TreeProgram:
         n = len(left)
         if n < 3:
             raise ValueError("a tree needs at least two tips")
+        unknown = [name[v] for v in range(n) if left[v] < 0 and name[v] not in index_of]
+        if unknown:
+            # (a degenerate UPGMA tree -- e.g. ONE variable gene -- carries an unnamed tip; the reference ends in
+            # binom_test(0, 0) there: "n must be an integer not less than 1")
+            raise ValueError("the tree has a tip that is no isolate of the gene table: %r" % (unknown[0],))
         size = [1] * n
         for v in range(n - 1, -1, -1):
             if left[v] >= 0:
