@@ -375,6 +375,7 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
     native = (io_native.available() and isinstance(path, str) and os.path.isfile(path)
               and len(delimiter) == 1 and delimiter not in ' "\r\n'
               and os.environ.get("SCOARY_PY_CSV") != "1"
+              and startcol >= 3          # a -s inside the identifier cells (or negative: Python's slices): the csv path
               and grabcols != [-999] and all(0 <= c < startcol for c in grabcols))
     rows_iter = None
     if native:
@@ -514,6 +515,13 @@ def Csv_to_dic_Roary(genefile, delimiter, grabcols, startcol=14, allowed_isolate
             take(q, r, present)
             all_rows.append(present)
         dense = np.array(dense_rows, dtype=np.uint8).reshape(len(ids), len(keep))
+        # A -s inside the identifier cells makes "Non-unique Gene name" / "Annotation" isolate columns, and in the
+        # reference's dictionary the isolate's 0 / 1 then REPLACES the text stored under that key (:449-481): the
+        # result files print it.  Same here (the last column of that name wins, as in a dict).
+        for key, texts in (("Non-unique Gene name", nugn), ("Annotation", ann)):
+            if key in kept_strains:
+                c = len(kept_strains) - 1 - kept_strains[::-1].index(key)
+                texts[:] = [str(int(v)) for v in dense[:, c]]
         table = GeneTable(ids, nugn, ann, kept_strains, pack_bits_rows(dense), extra)
         file_rows64 = pack_bits_rows(np.array(all_rows, dtype=np.uint8).reshape(len(all_rows), len(keep)))
     if opened is not None:
@@ -1323,7 +1331,8 @@ def StoreTraitResult(Trait, Traitname, max_hits, cutoffs, upgmatree, GTC, Pruned
         Trait = _trait_results_from_dict(Trait)
 
     n = len(Trait)
-    num_results = n if max_hits is None else min(max_hits, n)
+    # (-m 0 or a negative -m: no rows, as the reference's xrange(num_results), :1024 / :1143)
+    num_results = n if max_hits is None else max(0, min(max_hits, n))
     pcol = np.asarray(Trait.column("p_v"), dtype=np.float64)
     order = getattr(Trait, "p_order", None)
     if order is not None and len(order) == n and n > 1:
@@ -1416,7 +1425,7 @@ def StoreUPGMAtreeToFile(upgmatree, outdir, time=""):
     from .tree import newick_text
     name = str(outdir + ("Tree%s.nwk" % time))
     with open(name, "w") as f:
-        f.write(newick_text(upgmatree))
+        f.write(newick_text(upgmatree) if upgmatree is not None else "None;")
     log.info("Wrote the UPGMA tree to file: %s" % name)
     return name
 
@@ -1443,16 +1452,18 @@ def grabcoltype(string):
         return []
     cols = []
     for part in string.split(","):
-        try:
-            if "-" in part:
-                a, b = part.split("-")
-                if not int(b) > int(a):
+        if "-" in part:
+            try:
+                ab = part.split("-")
+                if not int(ab[1]) > int(ab[0]):
                     raise ValueError(part)
-                cols += list(range(int(a), int(b)))
-            else:
-                cols.append(int(part))
-        except (ValueError, TypeError):
-            sys.exit("Could not understand --include_input_columns argument %s" % part)
+                cols += list(range(int(ab[0]), int(ab[1])))
+            except (ValueError, TypeError, IndexError):
+                sys.exit("Could not understand --include_input_columns argument %s" % part)
+        else:
+            # a word where a number belongs is a ValueError here as in the reference (which only catches TypeError,
+            # :1537-1541): argparse turns it into its own "invalid grabcoltype value" error, exit status 2
+            cols.append(int(part))
     cols = [c - 1 for c in cols if c - 1 not in (0, 1, 2)]
     if not all(c > 1 for c in cols):
         sys.exit("Could not understand --include_input_columns argument. Make sure all "
@@ -1665,7 +1676,8 @@ def main(**kwargs):
                             permutations=args.permute if args.no_pairwise else 0, seed=seed,
                             early_abort=getattr(args, "permute_early_abort", False))
         t_stats = _time.time()
-        if args.upgma_tree and upgmatree is not None and rank == 0:
+        if args.upgma_tree and rank == 0:
+            # (with --no_pairwise there is no tree and the reference writes str(None) + ";", :277-280, :741-751)
             StoreUPGMAtreeToFile(upgmatree, args.outdir, time=stamp)
         if rank == 0:           # every rank holds the gathered results; one writes
             StoreResults(res["Results"], args.max_hits, cutoffs, upgmatree,

@@ -180,6 +180,8 @@ def compare_case(case, got):
     if got["status"] != ref["status"]:
         return ["status %s (%s) != reference %s (%s)" % (got["status"], got["message"], ref["status"], ref["message"])]
     if ref["status"] == "exit":
+        if "--citation" in case["argv"]:
+            return diffs              # both print a citation and leave; the text is this build's own
         if got["message"] != ref["message"]:
             diffs.append("exit message %r != %r" % (got["message"], ref["message"]))
         return diffs
