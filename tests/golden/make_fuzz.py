@@ -43,10 +43,14 @@ import numpy as np
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-# the committed corpus: the defaults.  FUZZ_SEED / FUZZ_NCASES / FUZZ_NS / FUZZ_OUT: one-off extra corpora
+# The committed corpora: a plain run writes fuzz_corpus.json.gz (SEED, 200 cases, NS) and fuzz_args_corpus.json.gz (the
+# flag surface: ARGS_SEED, 200 odd command lines on small tables).  FUZZ_SEED / FUZZ_NCASES / FUZZ_NS / FUZZ_ARGMUT=1 /
+# FUZZ_KEEP_CRASHES=1 / FUZZ_OUT: ONE one-off extra corpus instead (tools/round6_run.sh fuzzextra).
 SEED = int(os.environ.get("FUZZ_SEED", "20261001"))
 NCASES = int(os.environ.get("FUZZ_NCASES", "200"))
 NS = [int(x) for x in os.environ.get("FUZZ_NS", "4,5,7,12,20,33,48,64,65,70,180,256,400").split(",")]   # isolates
+ARGS_SEED, ARGS_NS = 20261002, [4, 7, 12, 20, 33, 48, 70]
+ARGMUT = os.environ.get("FUZZ_ARGMUT") == "1"          # set per corpus by build()
 
 sys.path.insert(0, REF)
 import scipy.stats as ss  # noqa: E402
@@ -227,7 +231,7 @@ def make_case(rng, k):
         argv += ["-w"]                                    # -w without -r: refused
     if roary and rng.random() < 0.15:
         argv += ["--include_input_columns", str(rng.choice(["4", "4,6-7", "ALL", "5-6"]))]
-    if os.environ.get("FUZZ_ARGMUT") == "1":               # one-off corpora: the flag surface (validation, exits)
+    if ARGMUT:                                             # the flag surface (validation, exits)
         argv = mutate_argv(rng, argv)
     return {"id": k, "kind": kind, "roary": bool(roary), "N": N, "G": G, "T": T, "bad": bad,
             "gpa": gpa, "traits": traits, "restrict": restrict, "argv": argv}
@@ -422,36 +426,48 @@ def reader_records(case, methods_module):
     return out
 
 
-def main():
-    rng = np.random.default_rng(SEED)
+def build(seed, ncases, ns, argmut, path, keep_crashes=False):
+    global NS, ARGMUT
+    NS, ARGMUT = list(ns), bool(argmut)
+    rng = np.random.default_rng(seed)
     cases, crashed, crash_cases = [], [], []
     k = 0
-    while len(cases) < NCASES and k < 4 * NCASES:
+    while len(cases) < ncases and k < 4 * ncases:
         case = make_case(rng, k)
         k += 1
         ref = run_reference(case)
         if ref["status"] == "crash":
             crashed.append({"id": case["id"], "message": ref["message"][:200]})
-            if os.environ.get("FUZZ_KEEP_CRASHES") == "1":       # one-off corpora: what does OUR command line do there?
+            if keep_crashes:                              # one-off corpora: what does OUR command line do there?
                 case["ref"] = ref
                 crash_cases.append(case)
             continue
         case["ref"] = ref
         # (odd command lines: reader_args would trip over the very flags under test; the readers have their corpus)
-        case["readers"] = reader_records(case, rm) if os.environ.get("FUZZ_ARGMUT") != "1" else {}
+        case["readers"] = reader_records(case, rm) if not argmut else {}
         cases.append(case)
-    doc = {"seed": SEED, "generated": k, "kept": len(cases), "reference_crashes": crashed, "cases": cases}
+    doc = {"seed": seed, "generated": k, "kept": len(cases), "reference_crashes": crashed, "cases": cases}
     if crash_cases:
         doc["crash_cases"] = crash_cases
-    path = os.environ.get("FUZZ_OUT") or os.path.join(HERE, "fuzz_corpus.json.gz")
     with open(path, "wb") as raw:
         with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, filename="") as g:
             g.write(json.dumps(doc, sort_keys=True).encode())
     n_ok = sum(c["ref"]["status"] == "ok" for c in cases)
-    print("%d cases kept of %d generated (%d ok, %d refused by the reference, %d reference crashes dropped); %d bytes"
-          % (len(cases), k, n_ok, len(cases) - n_ok, len(crashed), os.path.getsize(path)))
+    print("%s: %d cases kept of %d generated (%d ok, %d refused by the reference, %d reference crashes dropped); %d bytes"
+          % (os.path.basename(path), len(cases), k, n_ok, len(cases) - n_ok, len(crashed), os.path.getsize(path)))
     for c in crashed[:20]:
         print("  dropped", c)
+
+
+def main():
+    one_off = any(os.environ.get(k) for k in ("FUZZ_SEED", "FUZZ_NCASES", "FUZZ_NS", "FUZZ_ARGMUT", "FUZZ_OUT",
+                                              "FUZZ_KEEP_CRASHES"))
+    if one_off:
+        build(SEED, NCASES, NS, ARGMUT, os.environ.get("FUZZ_OUT") or os.path.join(HERE, "fuzz_corpus.json.gz"),
+              keep_crashes=os.environ.get("FUZZ_KEEP_CRASHES") == "1")
+        return
+    build(SEED, NCASES, NS, False, os.path.join(HERE, "fuzz_corpus.json.gz"))
+    build(ARGS_SEED, 200, ARGS_NS, True, os.path.join(HERE, "fuzz_args_corpus.json.gz"))
 
 
 if __name__ == "__main__":

@@ -26,6 +26,17 @@ def load_corpus():
 
 
 CORPUS = load_corpus()
+
+
+def load_args_corpus():
+    """The flag-surface corpus (make_fuzz.py's second file): 200 small tables under odd command lines -- values out of
+    range, words where numbers belong, repeated and contradictory flags, a -s inside the identifier cells -- and what
+    the reference made of each: mostly the message it left with."""
+    with gzip.open(os.path.join(GOLDEN, "fuzz_args_corpus.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+ARGS_CORPUS = load_args_corpus()
 FLOAT_TOL = 1e-12
 
 
@@ -235,6 +246,29 @@ def test_fuzz_case_vs_reference(k, tmp_path):
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a visible MI355X")
     case = CORPUS["cases"][k]
+    got = run_case(case, str(tmp_path))
+    diffs = compare_case(case, got)
+    assert not diffs, "case %d %s (N=%d G=%d T=%d roary=%s): %s" % (
+        case["id"], " ".join(case["argv"]), case["N"], case["G"], case["T"], case["roary"], "; ".join(diffs))
+
+
+def test_args_corpus_is_what_the_generator_promises():
+    cases = ARGS_CORPUS["cases"]
+    assert ARGS_CORPUS["kept"] == len(cases) >= 190
+    refused = [c for c in cases if c["ref"]["status"] == "exit"]
+    assert len(refused) >= 120 and len(cases) - len(refused) >= 30
+    assert len({c["ref"]["message"] for c in refused}) >= 12              # many different ways of being refused
+
+
+@pytest.mark.parametrize("k", range(len(ARGS_CORPUS["cases"])),
+                         ids=lambda k: "args%03d" % ARGS_CORPUS["cases"][k]["id"])
+def test_odd_command_line_vs_reference(k, tmp_path):
+    """The flag surface: the same outcome as the reference's command line -- its exit message (argparse's status 2
+    included), or its files."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X")
+    case = ARGS_CORPUS["cases"][k]
     got = run_case(case, str(tmp_path))
     diffs = compare_case(case, got)
     assert not diffs, "case %d %s (N=%d G=%d T=%d roary=%s): %s" % (
