@@ -51,6 +51,7 @@ NCASES = int(os.environ.get("FUZZ_NCASES", "200"))
 NS = [int(x) for x in os.environ.get("FUZZ_NS", "4,5,7,12,20,33,48,64,65,70,180,256,400").split(",")]   # isolates
 ARGS_SEED, ARGS_NS = 20261002, [4, 7, 12, 20, 33, 48, 70]
 ARGMUT = os.environ.get("FUZZ_ARGMUT") == "1"          # set per corpus by build()
+ODD_NAMES = os.environ.get("FUZZ_ODD_NAMES") == "1"    # one-off: non-ASCII / quoted / delimiter-holding isolate and gene names
 
 sys.path.insert(0, REF)
 import scipy.stats as ss  # noqa: E402
@@ -123,9 +124,16 @@ def make_case(rng, k):
             a, b = rng.integers(0, G, size=2)
             names[a] = names[b]
     lead_blank = rng.random() < 0.3
+    if ODD_NAMES:        # one-off corpora (no random draws: the committed corpora stay what they are)
+        iso = ["isol\u00e9 %d" % i if i % 5 == 0 else "\u540d%d" % i if i % 7 == 0 else "st,%d" % i if i % 11 == 0
+               else 'q"%d' % i if i % 13 == 0 else x for i, x in enumerate(iso)]
+        header = header[:nmeta] + iso
+        names = ["g\u00e9ne_%d" % g if g % 6 == 0 else x for g, x in enumerate(names)]
     rows = [header]
     for g in range(G):
         meta = [names[g], ("nm%d" % g) if g % 3 else "", "protein, putative %d" % g if g % 4 else "hyp %d" % g]
+        if ODD_NAMES and g % 5 == 1:
+            meta[2] = '\u00b5-protein "%d", 5\' end; x' % g
         meta += [str(int(m[g].sum()))] * (nmeta - 3)
         cells = []
         for i in range(N):
@@ -142,6 +150,8 @@ def make_case(rng, k):
     T = int(rng.choice([1, 1, 2, 3, 4]))
     topleft = "" if rng.random() < 0.7 else "Name"
     tnames = ["trait%d" % t if rng.random() < 0.8 else "res (%d)" % t for t in range(T)]
+    if ODD_NAMES:
+        tnames = ["r\u00e9sistance, (%d)" % t if t % 2 == 0 else x for t, x in enumerate(tnames)]
     missing = ["NA", "-", ".", " ", ""]
     tv = np.empty((T, N), dtype=object)
     for t in range(T):
@@ -461,7 +471,7 @@ def build(seed, ncases, ns, argmut, path, keep_crashes=False):
 
 def main():
     one_off = any(os.environ.get(k) for k in ("FUZZ_SEED", "FUZZ_NCASES", "FUZZ_NS", "FUZZ_ARGMUT", "FUZZ_OUT",
-                                              "FUZZ_KEEP_CRASHES"))
+                                              "FUZZ_KEEP_CRASHES", "FUZZ_ODD_NAMES"))
     if one_off:
         build(SEED, NCASES, NS, ARGMUT, os.environ.get("FUZZ_OUT") or os.path.join(HERE, "fuzz_corpus.json.gz"),
               keep_crashes=os.environ.get("FUZZ_KEEP_CRASHES") == "1")
