@@ -1196,10 +1196,11 @@ def _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC, Prunedic, 
     extra["max_propairs"] = obs[:, 1].astype(np.int64)
     extra["max_antipairs"] = obs[:, 2].astype(np.int64)
     memo = {}
+    small = len(table.strains) <= 170      # files held to the reference's bytes: SciPy may be asked (tree.binom_two_sided)
 
     def bt(x, n):
         if (x, n) not in memo:
-            memo[(x, n)] = T.binom_two_sided(x, n)
+            memo[(x, n)] = T.binom_two_sided(x, n, ask_scipy=small)
         return memo[(x, n)]
     for k in range(len(keep)):
         tot, pro, anti = (int(v) for v in obs[k])
@@ -1214,8 +1215,7 @@ def _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC, Prunedic, 
         log.info("Performing %d label permutations of the pairwise-comparison statistic for "
                  "%d genes on the GPU" % (permutations, len(keep)))
         exceed = stage.permute(rows64, obs, permutations)
-        for k in range(len(keep)):
-            extra["Empirical_p"][k] = T.empirical_p_sequential(exceed[k])
+        extra["Empirical_p"] = T.empirical_p_sequential_many(exceed)
     return keep, ranks, extra
 
 

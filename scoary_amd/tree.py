@@ -387,27 +387,39 @@ def _boost_binom_tail_half(k, n, upper):
         invert = not invert
     if b >= 40 or a + b - 1 > 1021:
         return None
-    kk = a - 1
-    nn = b + kk
-    result = 0.5 ** nn
-    term = result
-    i = nn - 1
-    while i > kk:
-        term *= ((i + 1) * 0.5) / ((nn - i) * 0.5)
-        result += term
-        i -= 1
+    # binomial_ccdf(nn, kk) with nn = a + b - 1 = n, kk = a - 1: the sum runs from i = n - 1 down to kk + 1, b - 1 terms,
+    # and its terms do not depend on kk -- the partial sums of one pass per n serve every k (same operations, same order)
+    sums = _CCDF_SUMS.get(n)
+    if sums is None:
+        if len(_CCDF_SUMS) > 4096:
+            _CCDF_SUMS.clear()
+        result = 0.5 ** n
+        term = result
+        sums = [result]
+        i = n - 1
+        while i > 0 and len(sums) < 40:
+            term *= ((i + 1) * 0.5) / ((n - i) * 0.5)
+            result += term
+            sums.append(result)
+            i -= 1
+        _CCDF_SUMS[n] = sums
+    result = sums[b - 1]
     v = 1.0 - result if invert else result
     return min(max(v, 0.0), 1.0)             # rv_discrete.cdf / .sf clip to [0, 1]
 
 
-def binom_two_sided(x, n):
+_CCDF_SUMS = {}
+
+
+def binom_two_sided(x, n, ask_scipy=True):
     """ss.binom_test(x, n, 0.5) (scoary/methods.py:1267-1275; scipy.stats.binomtest(...).pvalue since SciPy 1.12).
     At p = 1/2 the pmf is symmetric and SciPy's search for the far-side bound always lands on the mirror image of x
     (a ratio of neighbouring terms is never within its 1e-7 of 1), so the value is min(1, cdf(k) + sf(n - k - 1)) with
     k = min(x, n - x), 1 when x == n / 2.  Where SciPy's own arithmetic is restated (_boost_binom_tail_half: every n up
     to 78, the tails beyond) the result is SciPy's double -- the bytes the reference prints; for the few central (x, n)
     with 79 <= n <= 85 (tables of at most 170 isolates, whose result files are held to the reference's bytes) SciPy is
-    asked; otherwise the exact dyadic tail 2 P(X <= k), rounded once (SciPy's value is within 4e-14 of it up to
+    asked (``ask_scipy``: the caller says whether this run is one of those -- importing scipy.stats costs 0.4 s);
+    otherwise the exact dyadic tail 2 P(X <= k), rounded once (SciPy's value is within 4e-14 of it up to
     n = 400, 1e-13 in the far tail at n = 1500)."""
     x, n = int(x), int(n)
     if 2 * x == n:
@@ -416,7 +428,7 @@ def binom_two_sided(x, n):
     lo, hi = _boost_binom_tail_half(k, n, False), _boost_binom_tail_half(n - k - 1, n, True)
     if lo is not None and hi is not None:
         return min(1.0, lo + hi)
-    if n <= 85:
+    if n <= 85 and ask_scipy:
         try:
             import scipy.stats as ss
             if hasattr(ss, "binomtest"):
@@ -445,29 +457,101 @@ _BINOM_PREFIX = {}
 _ABORT_CACHE = {}
 
 
+def _abort_thresholds_scipy(i):
+    """Smallest r with 1 - binom.cdf(r, i, 0.1) < 0.05 for every i of the int64 array ``i``, with SciPy's binom.cdf
+    exactly as the reference evaluates it (candidates bracketed by the 0.95 quantile)."""
+    import scipy.stats as ss
+    big = np.iinfo(np.int64).max
+    r0 = ss.binom.ppf(0.95, i, 0.1).astype(np.int64)
+    best = np.full(i.shape, big, dtype=np.int64)
+    for d in (3, 2, 1, 0, -1, -2, -3):          # descending: smallest r wins last
+        r = np.maximum(r0 + d, 0)
+        ok = (1 - ss.binom.cdf(r, i, 0.1)) < 0.05
+        best = np.where(ok, r, best)
+    # guard the bracketing assumption: below `best` the test must fail
+    below = np.maximum(best - 1, 0)
+    bad = (best > 0) & ((1 - ss.binom.cdf(below, i, 0.1)) < 0.05)
+    if bad.any() or (best == big).any():
+        for k in np.nonzero(bad | (best == big))[0]:
+            rr = np.arange(0, i[k] + 1)
+            hit = np.nonzero((1 - ss.binom.cdf(rr, i[k], 0.1)) < 0.05)[0]
+            best[k] = hit[0] if hit.size else big
+    return best
+
+
+def _lgamma(x):
+    """log Gamma(x) for float64 arrays x >= 1, to ~1e-14 (absolute below 1, relative above): shifted to x + 16, then Stirling's series."""
+    x = np.asarray(x, dtype=np.float64)
+    shift = np.zeros_like(x)
+    y = x.copy()
+    for _ in range(16):
+        shift += np.log(y)
+        y += 1.0
+    inv = 1.0 / y
+    inv2 = inv * inv
+    series = inv * (1.0 / 12 - inv2 * (1.0 / 360 - inv2 * (1.0 / 1260 - inv2 * (1.0 / 1680))))
+    return (y - 0.5) * np.log(y) - y + 0.9189385332046727 + series - shift
+
+
+def _abort_thresholds_direct(i):
+    """The same thresholds without SciPy (importing scipy.stats costs 0.4 s of a 2.7 s run): the upper tail
+    P(X > r), X ~ Binomial(i, 0.1), summed term by term from a window around the 0.95 quantile (pmf at the window's
+    top from log-gamma, then the ratio recurrence both ways; ~1e-13 relative).  Returns (thresholds, undecided):
+    ``undecided`` marks the i whose deciding tail is within 1e-9 of 0.05 or whose window does not bracket the
+    answer -- the caller asks SciPy for those, so the last bit of ITS cdf decides as it does in the reference."""
+    i = np.asarray(i, dtype=np.int64)
+    fi = i.astype(np.float64)
+    r_lo = np.maximum(np.floor(0.1 * fi + 1.645 * 0.3 * np.sqrt(fi)).astype(np.int64) - 4, 0)
+    span = 9                                              # candidates r_lo .. r_lo + span - 1
+    js = np.minimum(r_lo + span, i)                       # first term of the far tail
+    fj = js.astype(np.float64)
+    logp = (_lgamma(fi + 1.0) - _lgamma(fj + 1.0) - _lgamma(fi - fj + 1.0)
+            + fj * np.log(0.1) + (fi - fj) * np.log(0.9))
+    top = np.exp(logp)                                    # pmf(js)
+    # far tail: sum_{j >= js} pmf(j) by pmf(j + 1) = pmf(j) (i - j) / (9 (j + 1)); ~10 sigma of terms is everything
+    nterms = int(10 * 0.3 * np.sqrt(float(fi.max())) + 40)
+    term, tail, j = top.copy(), top.copy(), fj.copy()
+    for _ in range(nterms):
+        term = term * np.maximum(fi - j, 0.0) / (9.0 * (j + 1.0))
+        tail += term
+        j += 1.0
+    tail = np.where(r_lo + span > i, 0.0, tail)           # the window reaches past i: nothing beyond it
+    # sf(r) for r = js - 1 down to r_lo: sf(r) = sf(r + 1) + pmf(r + 1), pmf downwards by the inverse ratio
+    sf = np.empty((span, i.shape[0]))
+    cur_sf, pm, jj = tail - top, top.copy(), fj.copy()    # cur_sf = sf(js) = sum_{j > js}
+    cur_sf = np.where(r_lo + span > i, 0.0, cur_sf)
+    # walk r from r_lo + span - 1 down to r_lo; where js was clipped to i the rows above i hold sf = 0
+    for d in range(span - 1, -1, -1):
+        r = r_lo + d
+        active = r < js                                   # rows at or above js (clipped case) keep sf(js) = 0 ...
+        add = np.where(active, pm, 0.0)                   # pmf(r + 1) with r + 1 == jj
+        cur_sf = cur_sf + add
+        sf[d] = np.where(r >= i, 0.0, cur_sf)
+        step = active & (jj > 0)
+        pm = np.where(step, pm * (9.0 * jj) / np.maximum(fi - jj + 1.0, 1.0), pm)
+        jj = np.where(step, jj - 1.0, jj)
+    ok = sf < 0.05
+    first = np.argmax(ok, axis=0)                         # smallest d with sf < 0.05
+    thr = r_lo + first
+    col = np.arange(i.shape[0])
+    undecided = ~ok.any(axis=0) | ((first == 0) & (r_lo > 0))          # not bracketed from below / above
+    near = np.abs(sf - 0.05) < 1e-9
+    undecided |= near[first, col] | near[np.maximum(first - 1, 0), col]
+    return thr, undecided
+
+
 def _abort_thresholds(P):
-    """For i in [30, P): smallest r with 1 - binom.cdf(r, i, 0.1) < 0.05
-    (methods.py:1360-1361), evaluated with SciPy's binom.cdf exactly as the
-    reference evaluates it (candidates bracketed by the 0.95 quantile)."""
+    """For i in [30, P): smallest r with 1 - binom.cdf(r, i, 0.1) < 0.05 (methods.py:1360-1361)."""
     if P not in _ABORT_CACHE:
-        import scipy.stats as ss
         thr = np.full(P, np.iinfo(np.int64).max, dtype=np.int64)
         if P > 30:
             i = np.arange(30, P)
-            r0 = ss.binom.ppf(0.95, i, 0.1).astype(np.int64)
-            best = np.full(i.shape, np.iinfo(np.int64).max, dtype=np.int64)
-            for d in (3, 2, 1, 0, -1, -2, -3):          # descending: smallest r wins last
-                r = np.maximum(r0 + d, 0)
-                ok = (1 - ss.binom.cdf(r, i, 0.1)) < 0.05
-                best = np.where(ok, r, best)
-            # guard the bracketing assumption: below `best` the test must fail
-            below = np.maximum(best - 1, 0)
-            bad = (best > 0) & ((1 - ss.binom.cdf(below, i, 0.1)) < 0.05)
-            if bad.any() or (best == np.iinfo(np.int64).max).any():
-                for k in np.nonzero(bad | (best == np.iinfo(np.int64).max))[0]:
-                    rr = np.arange(0, i[k] + 1)
-                    hit = np.nonzero((1 - ss.binom.cdf(rr, i[k], 0.1)) < 0.05)[0]
-                    best[k] = hit[0] if hit.size else np.iinfo(np.int64).max
+            if P > 50000:                                 # hours of permutations: SciPy's half second is nothing
+                best = _abort_thresholds_scipy(i)
+            else:
+                best, undecided = _abort_thresholds_direct(i)
+                if undecided.any():
+                    best[undecided] = _abort_thresholds_scipy(i[undecided])
             thr[30:] = best
         _ABORT_CACHE[P] = thr
     return _ABORT_CACHE[P]
@@ -486,3 +570,21 @@ def empirical_p_sequential(exceed):
         i = int(hit[0])
         return (float(r[i]) + 1.0) / (i + 2.0)
     return (float(r[-1]) + 1.0) / (P + 1.0)
+
+
+def empirical_p_sequential_many(exceed, chunk_elems=1 << 22):
+    """empirical_p_sequential for every row of a (genes, P) array of exceedance flags, a few thousand rows at a time."""
+    ex = np.asarray(exceed)
+    K, P = ex.shape
+    out = np.empty(K, dtype=np.float64)
+    thr = _abort_thresholds(P)
+    step = max(1, chunk_elems // max(P, 1))
+    for k0 in range(0, K, step):
+        r = np.cumsum(ex[k0:k0 + step], axis=1, dtype=np.int64)
+        hit = r >= thr[None, :]
+        any_hit = hit.any(axis=1)
+        i = np.argmax(hit, axis=1)
+        rows = np.arange(r.shape[0])
+        out[k0:k0 + step] = np.where(any_hit, (r[rows, i].astype(np.float64) + 1.0) / (i + 2.0),
+                                     (r[:, -1].astype(np.float64) + 1.0) / (P + 1.0))
+    return out

@@ -911,3 +911,20 @@ def test_binomial_p_is_scipys_double():
         for x in range(0, n + 1, 1 if n < 130 else 37):
             want = ss.binomtest(x, n, 0.5).pvalue
             assert abs(T.binom_two_sided(x, n) - want) <= 1e-12 * want, (x, n)
+
+
+def test_abort_thresholds_without_scipy_equal_scipys():
+    """The early-abort thresholds of the sequential permutation estimator (smallest r with 1 - binom.cdf(r, i, 0.1) <
+    0.05, scoary/methods.py:1360-1361): the SciPy-free evaluation (tree._abort_thresholds_direct) gives SciPy's answer
+    for every i in [30, 6000) and calls nothing undecided; the cached table is what empirical_p_sequential reads."""
+    from scoary_amd import tree as T
+    i = np.arange(30, 6000)
+    thr, undecided = T._abort_thresholds_direct(i)
+    assert not undecided.any()
+    assert np.array_equal(thr, T._abort_thresholds_scipy(i))
+    T._ABORT_CACHE.clear()
+    table = T._abort_thresholds(700)
+    assert np.array_equal(table[30:], thr[:670]) and (table[:30] == np.iinfo(np.int64).max).all()
+    x = np.arange(2000, dtype=np.float64)
+    import math
+    assert np.allclose(T._lgamma(x + 1.0), [math.lgamma(v + 1.0) for v in x], rtol=1e-14, atol=1e-13)
