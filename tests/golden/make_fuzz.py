@@ -49,6 +49,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SEED = int(os.environ.get("FUZZ_SEED", "20261001"))
 NCASES = int(os.environ.get("FUZZ_NCASES", "200"))
 NS = [int(x) for x in os.environ.get("FUZZ_NS", "4,5,7,12,20,33,48,64,65,70,180,256,400").split(",")]   # isolates
+DEFAULT_GS = [1, 2, 5, 17, 40, 40, 90, 90, 150]                                                           # genes
+GS = [int(x) for x in os.environ["FUZZ_GS"].split(",")] if os.environ.get("FUZZ_GS") else DEFAULT_GS     # one-off: big tables
 ARGS_SEED, ARGS_NS = 20261002, [4, 7, 12, 20, 33, 48, 70]
 ARGMUT = os.environ.get("FUZZ_ARGMUT") == "1"          # set per corpus by build()
 ODD_NAMES = os.environ.get("FUZZ_ODD_NAMES") == "1"    # one-off: non-ASCII / quoted / delimiter-holding isolate and gene names
@@ -106,8 +108,8 @@ def write_table(rows, delimiter, quote_all=False):
 
 def make_case(rng, k):
     N = int(rng.choice(NS))
-    G = int(rng.choice([1, 2, 5, 17, 40, 40, 90, 90, 150]))
-    if N > 170:
+    G = int(rng.choice(GS))
+    if N > 170 and GS is DEFAULT_GS:
         # beyond SciPy's factorial table a gene and its complement get the SAME double (below: a coin flip),
         # so here the order of such rows in the reference's CSV is the dictionary's and can be held to it
         G = min(G, 40)
@@ -471,7 +473,7 @@ def build(seed, ncases, ns, argmut, path, keep_crashes=False):
 
 def main():
     one_off = any(os.environ.get(k) for k in ("FUZZ_SEED", "FUZZ_NCASES", "FUZZ_NS", "FUZZ_ARGMUT", "FUZZ_OUT",
-                                              "FUZZ_KEEP_CRASHES", "FUZZ_ODD_NAMES"))
+                                              "FUZZ_KEEP_CRASHES", "FUZZ_ODD_NAMES", "FUZZ_GS"))
     if one_off:
         build(SEED, NCASES, NS, ARGMUT, os.environ.get("FUZZ_OUT") or os.path.join(HERE, "fuzz_corpus.json.gz"),
               keep_crashes=os.environ.get("FUZZ_KEEP_CRASHES") == "1")

@@ -147,7 +147,7 @@ for t in lists tiles listbuild seglists counts; do
 done
 cat $O/stress_soak.txt
 fi
-for f in $O/bench_*.json; do python - "$f" <<'PY'
+for f in $(ls $O/bench_*.json 2>/dev/null); do python - "$f" <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
