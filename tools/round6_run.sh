@@ -135,7 +135,7 @@ fi
 if has longsoak; then
 # new cases of the five randomised cross-checks (case numbers 600 ... : the generator is seeded by the case number)
 for t in lists tiles listbuild seglists counts; do
-  timeout ${SOAK_SECONDS:-240} python tools/stress_$t.py 100000 600 > $O/longsoak_$t.log 2>&1
+  timeout ${SOAK_SECONDS:-240} python tools/stress_$t.py 1000000 ${SOAK_FIRST:-600} > $O/longsoak_$t.log 2>&1
   echo "$t rc=$? (124 = stopped by the clock) cases $(grep -c ' ok$' $O/longsoak_$t.log) ok, $(grep -c MISMATCH $O/longsoak_$t.log) mismatching" >> $O/longsoak.txt
 done
 cat $O/longsoak.txt
