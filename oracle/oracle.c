@@ -29,6 +29,7 @@
  * mode (an lgamma table loses ~ulp(lgamma(N)) and misses 1e-12 at N >= 2000,
  * SURVEY finding 4).
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -270,9 +271,90 @@ static const double orc_factorial[ORC_SCIPY_SMALL_N + 1] = {
     9.003691705778438e+297, 1.503616514864999e+300, 2.5260757449731984e+302, 4.269068009004705e+304,
     7.257415615307999e+306};
 
+/* Above N = 170 (and up to the 10 000th prime, 104 729) Boost evaluates the same quotient of factorials through its
+ * PRIME FACTORISATION (boost/math/distributions/detail/hypergeometric_pdf.hpp, hypergeometric_pdf_prime_loop_imp):
+ * for every prime p <= N the exponent of p in n! r! (N-n)! (N-r)! / (N! x! (n-x)! (r-x)! (N-n-r+x)!) by Legendre's
+ * formula, the running product multiplied by p^e in ascending order of p -- a partial product that would overflow or
+ * underflow is set aside and a new one started --, and at the end the partial products multiplied together, taking
+ * one >= 1 while the running value is <= 1 and one < 1 otherwise.  p^|e| is an exact double for every exponent that
+ * can occur (|e| <= 2 log_p N), so only the order of the multiplications matters; a negative exponent is 1 / p^|e|
+ * (one rounding).  Restated from the published algorithm and PINNED bit for bit against scipy.stats.hypergeom.pmf
+ * and scipy.stats.fisher_exact (tests/test_oracle_golden.py, fisher_grid.npz: every table above N = 170). */
+#define ORC_SCIPY_MAX_N 104723
+static uint32_t *orc_primes = NULL;
+static int64_t orc_nprimes = 0;
+static void orc_primes_init(void)
+{
+    if (orc_primes)
+        return;
+    const int64_t top = 104730;
+    uint8_t *sieve = (uint8_t *)calloc((size_t)top + 1, 1);
+    uint32_t *pr = (uint32_t *)malloc(10001 * sizeof(uint32_t));
+    int64_t np = 0;
+    for (int64_t i = 2; i <= top; ++i) {
+        if (sieve[i])
+            continue;
+        pr[np++] = (uint32_t)i;
+        for (int64_t j = i * i; j <= top; j += i)
+            sieve[j] = 1;
+    }
+    free(sieve);
+    orc_nprimes = np;
+    orc_primes = pr;
+}
+static double bm_hypergeometric_pdf_prime(int64_t x, int64_t r, int64_t n, int64_t N)
+{
+    /* partial products, part[np - 1] the current one (Boost: a linked list on its call stack); N = 10^5 can need
+     * more than a thousand of them (the >= 1 factors alone reach 10^450000) */
+    int cap = 64, np = 1;
+    double *part = (double *)malloc((size_t)cap * sizeof(double));
+    part[0] = 1.0;
+    for (int64_t k = 0; k < orc_nprimes && (int64_t)orc_primes[k] <= N; ++k) {
+        const int64_t p = orc_primes[k];
+        int64_t e = 0;
+        for (int64_t base = p; base <= N; base *= p) {
+            e += n / base + r / base + (N - n) / base + (N - r) / base;
+            e -= N / base + x / base + (n - x) / base + (r - x) / base + (N - n - r + x) / base;
+        }
+        if (!e)
+            continue;
+        double v = 1.0;
+        for (int64_t i = 0; i < (e < 0 ? -e : e); ++i)
+            v *= (double)p;                /* exact */
+        if (e < 0)
+            v = 1.0 / v;
+        if ((v > 1 && DBL_MAX / v < part[np - 1]) || (v < 1 && DBL_MIN / v > part[np - 1])) {
+            if (np == cap)
+                part = (double *)realloc(part, (size_t)(cap *= 2) * sizeof(double));
+            part[np++] = v;                /* the next product would overflow / underflow: set aside, start anew */
+            continue;
+        }
+        part[np - 1] *= v;
+    }
+    /* newest first, as Boost walks its list: i over the entries >= 1, j over those < 1 */
+    int i = np - 1, j = np - 1;
+    while (i >= 0 && part[i] < 1) --i;
+    while (j >= 0 && part[j] >= 1) --j;
+    double prod = 1.0;
+    while (i >= 0 || j >= 0) {
+        while (i >= 0 && (prod <= 1 || j < 0)) {
+            prod *= part[i--];
+            while (i >= 0 && part[i] < 1) --i;
+        }
+        while (j >= 0 && (prod >= 1 || i < 0)) {
+            prod *= part[j--];
+            while (j >= 0 && part[j] >= 1) --j;
+        }
+    }
+    free(part);
+    return prod;
+}
+
 /* pmf of x successes in n draws, r successes among N items */
 static double bm_hypergeometric_pdf(int64_t x, int64_t r, int64_t n, int64_t N)
 {
+    if (N > ORC_SCIPY_SMALL_N)
+        return bm_hypergeometric_pdf_prime(x, r, n, N);
     const double up[3] = {orc_factorial[r], orc_factorial[N - n], orc_factorial[N - r]};
     const double down[5] = {orc_factorial[N], orc_factorial[x], orc_factorial[n - x],
                             orc_factorial[r - x], orc_factorial[N - n - r + x]};
@@ -418,6 +500,27 @@ void orc_fisher(int64_t a, int64_t b, int64_t c, int64_t d, double *p_out,
     double p = all ? 1.0 : inc / tot;
     *p_out = p < 1.0 ? p : 1.0;
     free(w);
+}
+
+/* scipy.stats.fisher_exact(...)[1] itself, to the last bit, for tables of up to ORC_SCIPY_MAX_N isolates (what the
+ * command line's result files print: scoary_fisher_scipy, k_fisher_scipy); NaN beyond or with an empty margin. */
+double orc_fisher_scipy(int64_t a, int64_t b, int64_t c, int64_t d)
+{
+    if (a + b == 0 || c + d == 0 || a + c == 0 || b + d == 0)
+        return 1.0;
+    if (a + b + c + d > ORC_SCIPY_MAX_N)
+        return NAN;
+    orc_primes_init();
+    return scipy_fisher_two_sided(a, b, c, d);
+}
+void orc_fisher_scipy_many(const int32_t *counts, int64_t M, double *p)
+{
+    orc_primes_init();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int64_t i = 0; i < M; ++i)
+        p[i] = orc_fisher_scipy(counts[i * 4], counts[i * 4 + 1], counts[i * 4 + 2], counts[i * 4 + 3]);
 }
 
 void orc_fisher_many(const int32_t *counts, int64_t M, double *p, double *orr)
