@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SCOARY_ABI_VERSION 8
+#define SCOARY_ABI_VERSION 9
 
 /* error codes */
 #define SCOARY_OK 0
@@ -141,6 +141,19 @@ int scoary_counts_planned(scoary_handle h, const uint32_t *d_tiled, const void *
 int scoary_fisher(scoary_handle h, const int32_t *d_tables, int64_t M,
                   double *d_p, double *d_or, uint32_t *d_crit,
                   scoary_stream_t stream);
+/* scipy.stats.fisher_exact's OWN double for the tables of 171 ... scoary_fisher_scipy_max_isolates() (104 723)
+ * isolates: d_p[m] is overwritten with the value SciPy >= 1.7 returns for table m, to the last bit (Boost.Math's
+ * prime-factorised hypergeometric pmf, its tail recurrences and fisher_exact's binary search restated in fp64;
+ * scoary_amd/csrc/scoary_scipy.hip).  Replaces, for what a caller PRINTS, the per-gene call the reference makes
+ * (scoary/methods.py:854): with it the result files are the reference's bytes at any size, not only up to 170
+ * isolates where scoary_fisher already returns SciPy's double.  Tables with an empty margin, with fewer than 171
+ * isolates or with more than the maximum are left as they are; *d_skipped (uint64, may be NULL; zero it first)
+ * counts the tables above the maximum.  About 50 x the work of scoary_fisher per table (15 pmf evaluations over the
+ * primes up to N): an output-fidelity pass for the command line, not part of the association step bench.py times.
+ * The first call on a device uploads the prime table (a synchronous 40 KB copy: not inside a graph capture). */
+int64_t scoary_fisher_scipy_max_isolates(void);
+int scoary_fisher_scipy(scoary_handle h, const int32_t *d_tables, int64_t M, double *d_p,
+                        uint64_t *d_skipped, scoary_stream_t stream);
 /* The same test for the list-driven permutation path, one launch fewer per step:
  * tables [T][G][4] are visited in LIST-SLOT order (slot k of trait t = gene
  * d_lorder[k]; slots are sorted by minority count, so the lanes of a wavefront walk

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCOARY_HIP_LIB") or os.path.join(_HERE, "csrc", "libscoary_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "scoary_hip.h")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _i64, _u64, _i32, _vp, _cp = (ctypes.c_int64, ctypes.c_uint64, ctypes.c_int,
                               ctypes.c_void_p, ctypes.c_char_p)
@@ -35,6 +35,8 @@ SIGNATURES = {
     "scoary_counts_planned": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "scoary_fisher": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "scoary_fisher_lists": (_i32, [_vp, _vp, _i64, _i64] + [_vp] * 7),
+    "scoary_fisher_scipy": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "scoary_fisher_scipy_max_isolates": (_i64, []),
     "scoary_perm_generate": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _u64, _vp, _vp]),
     "scoary_permute": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "scoary_permute_seq": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp,

@@ -433,6 +433,23 @@ class AssociationEngine:
                                            self._stream()), "scoary_fisher")
         return p, odds, crit
 
+    def fisher_scipy(self, tables, p):
+        """SciPy's own double for every table of 171 ... fisher_scipy_max_isolates() isolates, written over the
+        entries of ``p`` (float64 device tensor shaped like tables[..., 0]; scoary_fisher_scipy): what the command
+        line prints.  Returns the number of tables above the maximum (left as they were)."""
+        torch = _torch()
+        tables = tables.contiguous()
+        if not p.is_contiguous() or p.dtype != torch.float64 or tuple(p.shape) != tuple(tables.shape[:-1]):
+            raise ValueError("fisher_scipy: p must be a contiguous float64 tensor shaped like the tables")
+        M = int(np.prod(tables.shape[:-1])) if len(tables.shape) > 1 else 1
+        skipped = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._check(self.lib.scoary_fisher_scipy(self.h, self._ptr(tables), M, self._ptr(p), self._ptr(skipped),
+                                                 self._stream()), "scoary_fisher_scipy")
+        return int(skipped.item())
+
+    def fisher_scipy_max_isolates(self):
+        return int(self.lib.scoary_fisher_scipy_max_isolates())
+
     # -- a8 / a7: permutations -------------------------------------------------
     def perm_generate(self, masks, margins, N, P, perm_base, seed, out=None, trait_base=0):
         torch = _torch()
