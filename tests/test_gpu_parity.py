@@ -269,6 +269,51 @@ def test_fisher_small_populations_equal_scipy_bit_for_bit(eng, orc):
     assert np.max(np.abs(p.cpu().numpy() - o_p) / o_p) < 1e-11
 
 
+def test_fisher_scipy_digits_at_any_size(eng, orc):
+    """scoary_fisher_scipy (k_fisher_scipy, what the command line prints above 170 isolates): SciPy's own double,
+    bit for bit -- against the golden grid (every table above N = 170: SciPy 1.15.3), against the oracle's
+    restatement of Boost's prime-factorised pmf on 12 000 random tables up to 104 723 isolates, and against the
+    SciPy installed on this box; tables below 171 isolates, with an empty margin or above the maximum are left as
+    scoary_fisher wrote them, the last kind counted."""
+    import torch
+    z = np.load(os.path.join(GOLDEN, "fisher_grid.npz"))
+    tabs, gp = z["tables"].astype(np.int32), z["p"]
+    dt = torch.from_numpy(tabs).to(eng.device)
+    p = eng.fisher(dt)[0]
+    assert eng.fisher_scipy(dt, p) == 0
+    assert np.array_equal(p.cpu().numpy().view(np.uint64), gp.view(np.uint64))       # the whole grid, N <= 170 included
+    rng = np.random.default_rng(2026)
+    rand = []
+    for k in range(12000):
+        N = int(rng.choice([171, 200, 997, 2000, 5000, 10007, 40000, 104723])) if k % 3 == 0 else int(rng.integers(2, 12000))
+        npos, g = int(rng.integers(1, N)), int(rng.integers(1, N))
+        lo, hi = max(0, g + npos - N), min(g, npos)
+        mu = g * npos / N
+        sd = max(1.0, (mu * (1 - npos / N)) ** 0.5)
+        a = int(min(max(round(mu + rng.normal() * sd * rng.choice([0.3, 1, 3, 10])), lo), hi))
+        rand.append((a, npos - a, g - a, N - npos - g + a))
+    rand += [(60000, 20000, 20000, 20000), (70000, 20000, 20000, 20000), (0, 0, 100, 200), (5, 0, 300, 0)]
+    rand = np.array(rand, dtype=np.int32)
+    dt = torch.from_numpy(rand).to(eng.device)
+    walk = eng.fisher(dt)[0]
+    p = walk.clone()
+    assert eng.fisher_scipy(dt, p) == 2                                               # the two tables above the maximum
+    got, walk = p.cpu().numpy(), walk.cpu().numpy()
+    n = rand.sum(1)
+    margins = np.minimum(np.minimum(rand[:, 0] + rand[:, 1], rand[:, 2] + rand[:, 3]),
+                         np.minimum(rand[:, 0] + rand[:, 2], rand[:, 1] + rand[:, 3]))
+    inside = (n >= 171) & (n <= eng.fisher_scipy_max_isolates()) & (margins > 0)
+    assert inside.sum() > 11000
+    want = orc.fisher_scipy_many(rand)
+    assert np.array_equal(got[inside].view(np.uint64), want[inside].view(np.uint64))
+    assert np.array_equal(got[~inside].view(np.uint64), walk[~inside].view(np.uint64))
+    assert np.max(np.abs(walk[inside] - want[inside])) < 1e-12                         # and the walk is within the path's 1e-12
+    ss = pytest.importorskip("scipy.stats")
+    for k in np.nonzero(inside)[0][:600]:
+        a, b, c, d = rand[k].tolist()
+        assert got[k] == float(ss.fisher_exact([[a, b], [c, d]])[1]), rand[k]
+
+
 def test_fisher_of_a_gene_and_of_its_complement_are_the_same_double(eng, orc):
     """[[a, b], [c, d]] and [[b, a], [d, c]] (a gene / the complementary gene under one trait): the same
     p bit for bit -- as SciPy returns for tables beyond its factorial table (N > 170), which is what keeps
