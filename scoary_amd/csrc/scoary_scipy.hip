@@ -19,9 +19,9 @@
 //     recurrence towards that end until a term no longer counts; the far side as 1 - sum.
 //   * fisher_exact: pmf at the observed table and at the mode (equal to 1e-14: p = 1), a binary search over the pmf
 //     for the point on the other side of the mode, the two tails added, min(p, 1).
-// Restated operation by operation in plain fp64 (-ffp-contract=off); the CPU checker (oracle/oracle.c,
-// orc_fisher_scipy) is pinned against SciPy bit for bit and this kernel against the checker
-// (tests/test_gpu_parity.py) and against the SciPy of the GPU box directly.
+// Restated operation by operation in plain fp64 (-ffp-contract=off); the CPU checker of the tests has its own
+// restatement, pinned against SciPy bit for bit, and this kernel is held to the checker
+// (tests/test_gpu_parity.py) and to the SciPy of the GPU box directly.
 #include "scoary_common.hpp"
 
 namespace {

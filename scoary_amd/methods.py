@@ -303,6 +303,20 @@ _stage = _Stages()
 _ENGINE = None
 
 
+def _preload_scipy():
+    """Default (pairwise) mode may ask SciPy for a few binomial tails (tree.binom_two_sided_many: the central pairs of
+    genes with 79 or more contrasting pairs); importing scipy.stats takes 0.3-0.5 s, so it starts here, on a helper
+    thread under the association stage, instead of in the middle of the first trait's pairwise stage."""
+    import threading
+
+    def load():
+        try:
+            import scipy.stats  # noqa: F401
+        except ImportError:
+            pass
+    threading.Thread(target=load, name="scoary-scipy-preload", daemon=True).start()
+
+
 def get_engine():
     global _ENGINE
     if _ENGINE is None:
@@ -1215,20 +1229,12 @@ def _pairwise_stage(Trait, Traitname, order, cutoffs, upgmatree, GTC, Prunedic, 
     extra["max_total_pairs"] = obs[:, 0].astype(np.int64)
     extra["max_propairs"] = obs[:, 1].astype(np.int64)
     extra["max_antipairs"] = obs[:, 2].astype(np.int64)
-    memo = {}
-    small = len(table.strains) <= 170      # files held to the reference's bytes: SciPy may be asked (tree.binom_two_sided)
-
-    def bt(x, n):
-        if (x, n) not in memo:
-            memo[(x, n)] = T.binom_two_sided(x, n, ask_scipy=small)
-        return memo[(x, n)]
-    for k in range(len(keep)):
-        tot, pro, anti = (int(v) for v in obs[k])
-        a, b = bt(pro, tot), bt(tot - anti, tot)
-        if pro >= anti:                     # methods.py:1259-1275
-            extra["Pbest"][k], extra["Pworst"][k] = a, b
-        else:
-            extra["Pworst"][k], extra["Pbest"][k] = a, b
+    # the two binomial p-values of every gene (methods.py:1259-1275), SciPy's doubles (tree.binom_two_sided_many)
+    tot, pro, anti = (obs[:, j].astype(np.int64) for j in range(3))
+    both = T.binom_two_sided_many(np.concatenate([pro, tot - anti]), np.concatenate([tot, tot]))
+    a, b = both[:len(keep)], both[len(keep):]
+    best_is_a = pro >= anti
+    extra["Pbest"], extra["Pworst"] = np.where(best_is_a, a, b), np.where(best_is_a, b, a)
     extra["Plowest"] = np.minimum(extra["Pbest"], extra["Pworst"])
     extra["Pboth"] = np.maximum(extra["Pbest"], extra["Pworst"])
     if permutations >= 10:
@@ -1663,6 +1669,7 @@ def main(**kwargs):
                 from . import tree as T
                 log.info("Building UPGMA tree from distance matrix")
                 upgmatree = T.upgma(get_engine(), gd["Zero_ones_matrix"].file_rows(), strains)
+                _preload_scipy()
             elif args.no_pairwise:
                 log.info("Ignoring relatedness among input sample and performing only "
                          "population structure-naive analysis.")

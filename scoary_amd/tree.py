@@ -454,6 +454,41 @@ def binom_two_sided(x, n, ask_scipy=True):
 _BINOM_PREFIX = {}
 
 
+def binom_two_sided_many(xs, ns):
+    """binom_two_sided for arrays of (x, n): SciPy's double for every pair -- restated where Boost sums a finite
+    series (_boost_binom_tail_half), and for the central pairs of n >= 79 (Boost's continued fraction, not restated)
+    asked from SciPy itself in ONE vectorised binom.cdf / binom.sf call, the arithmetic behind binom_test /
+    binomtest: min(1, cdf(k) + sf(n - k - 1)).  Without SciPy those pairs get the exact dyadic tail."""
+    xs = np.asarray(xs, dtype=np.int64)
+    ns = np.asarray(ns, dtype=np.int64)
+    out = np.empty(xs.shape[0], dtype=np.float64)
+    memo, ask = {}, []
+    for i, (x, n) in enumerate(zip(xs.tolist(), ns.tolist())):
+        v = memo.get((x, n))
+        if v is None:
+            if 2 * x == n:
+                v = 1.0
+            else:
+                k = min(x, n - x)
+                lo, hi = _boost_binom_tail_half(k, n, False), _boost_binom_tail_half(n - k - 1, n, True)
+                v = min(1.0, lo + hi) if (lo is not None and hi is not None) else ("ask", k)
+            memo[(x, n)] = v
+        if isinstance(v, tuple):
+            ask.append(i)
+        else:
+            out[i] = v
+    if ask:
+        ask = np.array(ask)
+        n_a = ns[ask]
+        k_a = np.minimum(xs[ask], n_a - xs[ask])
+        try:
+            from scipy.stats import binom
+            out[ask] = np.minimum(1.0, binom.cdf(k_a, n_a, 0.5) + binom.sf(n_a - k_a - 1, n_a, 0.5))
+        except ImportError:
+            out[ask] = [binom_two_sided(int(x), int(n), ask_scipy=False) for x, n in zip(xs[ask], n_a)]
+    return out
+
+
 _ABORT_CACHE = {}
 
 

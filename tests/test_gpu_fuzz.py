@@ -98,23 +98,6 @@ def _pcell(row, header, name="Naive_p"):
 SCIPY_DIGITS_MAX_N = 104723 if os.environ.get("SCOARY_FISHER_SCIPY", "1") != "0" else 170
 
 
-def _equal_but_binomials(got, want, delimiter):
-    """The same bytes except the Best / Worst_pairwise_comp_p cells, which agree to 1e-13."""
-    g = list(csv.reader(io.StringIO(got), delimiter=delimiter))
-    w = list(csv.reader(io.StringIO(want), delimiter=delimiter))
-    if len(g) != len(w) or g[0] != w[0]:
-        return False
-    loose = {g[0].index(c) - len(g[0]) for c in ("Best_pairwise_comp_p", "Worst_pairwise_comp_p") if c in g[0]}
-    for a, b in zip(g[1:], w[1:]):
-        if len(a) != len(b):
-            return False
-        for j in range(len(a)):
-            if a[j] != b[j] and not (j - len(a) in loose and _is_float(a[j]) and _is_float(b[j])
-                                     and abs(float(a[j]) - float(b[j])) <= 1e-13 * abs(float(b[j]))):
-                return False
-    return True
-
-
 METHOD_COLUMN = {"I": "Naive_p", "B": "Bonferroni_p", "BH": "Benjamini_H_p", "PW": "Best_pairwise_comp_p",
                  "EPW": "Worst_pairwise_comp_p"}
 
@@ -238,13 +221,10 @@ def compare_case(case, got):
     cutoffs = [(METHOD_COLUMN[m_], v) for m_, v in zip(methods, values)]
     for fn in sorted(ref["files"]):
         if got["files"][fn] != ref["files"][fn] and case["N"] <= SCIPY_DIGITS_MAX_N:
-            # Up to 170 isolates k_fisher returns SciPy's own double (spec S3) and above the command line passes what
-            # it prints through scoary_fisher_scipy: the file is the reference's, byte for byte.  The one exception:
-            # the two binomial p cells of the pairwise stage when a gene has 79 or more contrasting pairs in a run
-            # of more than 170 isolates (tree.binom_two_sided: SciPy's continued fraction is not restated).
-            if case["N"] <= 170 or "--no_pairwise" in argv or \
-                    not _equal_but_binomials(got["files"][fn], ref["files"][fn], delimiter):
-                diffs.append("%s: not byte-identical" % fn)
+            # Up to 170 isolates k_fisher returns SciPy's own double (spec S3), above the command line passes what it
+            # prints through scoary_fisher_scipy, and the pairwise stage's binomial cells are SciPy's too
+            # (tree.binom_two_sided_many): the file is the reference's, byte for byte.
+            diffs.append("%s: not byte-identical" % fn)
         d = compare_csv(got["files"][fn], ref["files"][fn], delimiter, cutoffs, "-m" in argv,
                         woven="--threads" in argv and "--no_pairwise" not in argv,
                         by_pairs="--no_pairwise" not in argv and not {"I", "B", "BH"} & set(methods))
