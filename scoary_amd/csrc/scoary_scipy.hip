@@ -34,24 +34,29 @@ constexpr double kDblMax = 1.7976931348623157e308, kDblMin = 2.2250738585072014e
 constexpr double kEps = 2.220446049250313e-16;
 constexpr double kGammaS = 1.0 + 1e-14;  // fisher_exact: gamma = 1 + epsilon
 
-struct Primes { const uint32_t* q; int n; };
+struct Primes { const uint32_t* q; const float* inv; int n; };   // inv[k] = 1.0f / q[k]
 
-// floor(x / base) for 0 <= x < 2^24, 1 <= base < 2^24 with inv = 1.0 / base: the quotients' fractional parts are
-// multiples of 1 / base >= 2^-24 apart from an integer, so 2^-30 of slack absorbs the rounding of x * inv
-__device__ __forceinline__ int fdiv(int x, double inv) { return (int)((double)x * inv + 9.313225746154785e-10); }
+// floor(x / base) in fp32 for 0 <= x <= 104 723, 1 <= base <= 104 729: xh = x + 0.5 (exact in fp32), inv = 1 / base to
+// one ulp.  (x + 0.5) / base lies at least 0.5 / base away from every integer and the product's error is below
+// (x / base) 2^-22 < 0.5 / base (x base < 2^21 ... x < 2^21), so truncation gives the quotient.  fp32 because
+// v_cvt_i32_f64 runs at a quarter of the rate: the nine quotients per prime are the kernel's inner loop.
+__device__ __forceinline__ int fdiv(float xh, float inv) { return (int)(xh * inv); }
 
 // Boost's prime-factorised pmf of x successes in n draws, r successes among N items.  `part` = this lane's scratch.
 // Returns a negative value if more than kMaxParts partial products were needed (the caller leaves the table alone).
 __device__ __noinline__ double pdf_prime(int x, int r, int n, int N, Primes pr, double* part) {
   int np = 1;
   part[0] = 1.0;
-  const int t0 = n, t1 = r, t2 = N - n, t3 = N - r, u0 = N, u1 = x, u2 = n - x, u3 = r - x, u4 = N - n - r + x;
+  const float t0 = (float)n + 0.5f, t1 = (float)r + 0.5f, t2 = (float)(N - n) + 0.5f, t3 = (float)(N - r) + 0.5f,
+              u0 = (float)N + 0.5f, u1 = (float)x + 0.5f, u2 = (float)(n - x) + 0.5f, u3 = (float)(r - x) + 0.5f,
+              u4 = (float)(N - n - r + x) + 0.5f;
   for (int k = 0; k < pr.n; ++k) {
     const int q = (int)pr.q[k];
     if (q > N) break;
     int e = 0;
+    float inv = pr.inv[k];
     for (int64_t base = q; base <= N; base *= q) {
-      const double inv = 1.0 / (double)base;
+      if (base != q) inv = 1.0f / (float)base;
       e += fdiv(t0, inv) + fdiv(t1, inv) + fdiv(t2, inv) + fdiv(t3, inv);
       e -= fdiv(u0, inv) + fdiv(u1, inv) + fdiv(u2, inv) + fdiv(u3, inv) + fdiv(u4, inv);
     }
@@ -180,7 +185,8 @@ __device__ double fisher_two_sided(int a, int b, int c, int d, Primes pr, double
 // One lane per table.  Tables with an empty margin or outside [kScipyMinN, kScipyMaxN] are left as they are.
 __global__ __launch_bounds__(64) void k_fisher_scipy(const int4* __restrict__ tables, int64_t M,
                                                      double* __restrict__ p_out, const uint32_t* __restrict__ primes,
-                                                     int nprimes, unsigned long long* __restrict__ skipped) {
+                                                     const float* __restrict__ inv, int nprimes,
+                                                     unsigned long long* __restrict__ skipped) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
   const int4 t = tables[i];
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(64) void k_fisher_scipy(const int4* __restrict__ ta
   }
   double part[kMaxParts];
   bool bad = false;
-  const double p = fisher_two_sided(a, b, c, d, Primes{primes, nprimes}, part, &bad);
+  const double p = fisher_two_sided(a, b, c, d, Primes{primes, inv, nprimes}, part, &bad);
   if (bad) {
     if (skipped) atomicAdd(skipped, 1ull);
     return;
@@ -205,9 +211,10 @@ __global__ __launch_bounds__(64) void k_fisher_scipy(const int4* __restrict__ ta
 // the primes up to 104 729, once per device (40 KB; lives until the process ends)
 constexpr int kMaxDevices = 64;
 uint32_t* g_primes[kMaxDevices] = {};
+float* g_inv[kMaxDevices] = {};
 int g_nprimes = 0;
 
-int primes_on_device(scoary_handle h, const uint32_t** out, int* n) {
+int primes_on_device(scoary_handle h, const uint32_t** out, const float** inv_out, int* n) {
   if (h->device < 0 || h->device >= kMaxDevices) return fail(h, SCOARY_ERR_ARG, "scoary_fisher_scipy: device index");
   if (!g_primes[h->device]) {
     const int top = 104730;
@@ -219,13 +226,20 @@ int primes_on_device(scoary_handle h, const uint32_t** out, int* n) {
       pr.push_back((uint32_t)i);
       for (int64_t j = (int64_t)i * i; j <= top; j += i) sieve[(size_t)j] = 1;
     }
+    std::vector<float> inv(pr.size());
+    for (size_t i = 0; i < pr.size(); ++i) inv[i] = 1.0f / (float)pr[i];
     uint32_t* dev = nullptr;
+    float* dinv = nullptr;
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&dev), pr.size() * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&dinv), pr.size() * sizeof(float)));
     HIP_TRY(h, hipMemcpy(dev, pr.data(), pr.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(dinv, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice));
     g_nprimes = (int)pr.size();
+    g_inv[h->device] = dinv;
     g_primes[h->device] = dev;
   }
   *out = g_primes[h->device];
+  *inv_out = g_inv[h->device];
   *n = g_nprimes;
   return SCOARY_OK;
 }
@@ -243,13 +257,14 @@ int scoary_fisher_scipy(scoary_handle h, const int32_t* d_tables, int64_t M, dou
   if ((M + kWave - 1) / kWave > 0x7fffffffLL) return fail(h, SCOARY_ERR_SIZE, "scoary_fisher_scipy: M too large");
   DeviceGuard guard(h->device);
   const uint32_t* primes = nullptr;
+  const float* inv = nullptr;
   int nprimes = 0;
-  const int rc = primes_on_device(h, &primes, &nprimes);
+  const int rc = primes_on_device(h, &primes, &inv, &nprimes);
   if (rc != SCOARY_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   KernelTimer kt(h, s, "k_fisher_scipy");
   hipLaunchKernelGGL(k_fisher_scipy, dim3((unsigned)((M + kWave - 1) / kWave)), dim3(kWave), 0, s,
-                     reinterpret_cast<const int4*>(d_tables), M, d_p, primes, nprimes,
+                     reinterpret_cast<const int4*>(d_tables), M, d_p, primes, inv, nprimes,
                      reinterpret_cast<unsigned long long*>(d_skipped));
   HIP_TRY(h, hipGetLastError());
   return SCOARY_OK;
