@@ -66,7 +66,10 @@ __device__ __noinline__ double pdf_prime(int x, int r, int n, int N, Primes pr, 
     for (int i = e < 0 ? -e : e; i > 0; --i) v *= dq;      // exact
     if (e < 0) v = 1.0 / v;
     const double cur = part[np - 1];
-    if ((v > 1.0 && kDblMax / v < cur) || (v < 1.0 && kDblMin / v > cur)) {
+    // Boost's tests "would the product overflow / underflow" each cost a division; with both factors far from the
+    // ends of the range neither can be true (max / 1e100 > 1e200, min / 1e-100 < 1e-200) and they are not evaluated
+    const bool far = cur < 1e200 && cur > 1e-200 && v < 1e100 && v > 1e-100;
+    if (!far && ((v > 1.0 && kDblMax / v < cur) || (v < 1.0 && kDblMin / v > cur))) {
       if (np == kMaxParts) return -1.0;
       part[np++] = v;
       continue;
