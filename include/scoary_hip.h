@@ -149,7 +149,7 @@ int scoary_fisher(scoary_handle h, const int32_t *d_tables, int64_t M,
  * isolates where scoary_fisher already returns SciPy's double.  Tables with an empty margin, with fewer than 171
  * isolates or with more than the maximum are left as they are; *d_skipped (uint64, may be NULL; zero it first)
  * counts the tables above the maximum.  About 50 x the work of scoary_fisher per table (15 pmf evaluations over the
- * primes up to N; 10 ms per 500 000 tables at N = 2000): an output-fidelity pass for the command line, not part of the association step bench.py times.
+ * primes up to N; 9.5 ms per 500 000 tables at N = 2000): an output-fidelity pass for the command line, not part of the association step bench.py times.
  * The first call on a device uploads the prime table (a synchronous 40 KB copy: not inside a graph capture). */
 int64_t scoary_fisher_scipy_max_isolates(void);
 int scoary_fisher_scipy(scoary_handle h, const int32_t *d_tables, int64_t M, double *d_p,

@@ -791,7 +791,7 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
         # rule to ~3e-15 -- inside the path's 1e-12, not the digits the reference writes.  What gets PRINTED is
         # therefore passed through scoary_fisher_scipy (Boost's prime-factorised pmf restated, bit for bit SciPy up
         # to 104 723 isolates): the result files are the reference's bytes at any realistic size.  An
-        # output-fidelity pass, ~50 x k_fisher per table (10 ms per 500 000 tables at N = 2000) and not part of the
+        # output-fidelity pass, ~50 x k_fisher per table (9.5 ms per 500 000 tables at N = 2000) and not part of the
         # step bench.py times; SCOARY_FISHER_SCIPY=0 keeps k_fisher's value.
         if N <= 170 or os.environ.get("SCOARY_FISHER_SCIPY", "1") == "0":
             return
