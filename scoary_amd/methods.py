@@ -799,8 +799,9 @@ def _associate(table, tarr, permutations=0, seed=DEFAULT_SEED, early_abort=False
             skipped = eng.fisher_scipy(res["counts"], res["p"])
             torch.cuda.synchronize(eng.device)
         if skipped:
-            log.info("%d tables have more than %d isolates: their p is the exact value of SciPy's rule (within 1e-12 "
-                     "of SciPy), not SciPy's last digits" % (skipped, eng.fisher_scipy_max_isolates()))
+            log.info("%d tables are outside what scoary_fisher_scipy takes (more than %d isolates): their p is the exact "
+                     "value of SciPy's rule (within 1e-12 of SciPy), not SciPy's last digits"
+                     % (skipped, eng.fisher_scipy_max_isolates()))
 
     def local(sel):
         a = sel.start
